@@ -1,0 +1,96 @@
+"""Generate tests/golden/*.npz from the reference itself (container only; needs /root/reference).
+
+    python oracle/make_golden.py [celeba] [affine] ...
+
+Each fixture holds inputs (or the seeds that regenerate them) and the reference's outputs; no reference
+source travels.  Fixtures are committed; this script is committed so they can be regenerated.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ref_harness as rh            # noqa: E402
+from oracle import celeba_oracle as co          # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def probe_state(prefix, sd, out):
+    """Small fingerprints of every tensor: first 8 values, sum, abs-sum (float64)."""
+    for k, v in sd.items():
+        t = v.detach().double().flatten()
+        out[f"{prefix}/{k}/head"] = t[:8].numpy()
+        out[f"{prefix}/{k}/sum"] = np.array(t.sum().item())
+        out[f"{prefix}/{k}/abs"] = np.array(t.abs().sum().item())
+
+
+def probe_grads(prefix, module, out):
+    for k, p in module.named_parameters():
+        if p.grad is None:
+            continue
+        t = p.grad.detach().double().flatten()
+        out[f"{prefix}/{k}/head"] = t[:8].numpy()
+        out[f"{prefix}/{k}/sum"] = np.array(t.sum().item())
+        out[f"{prefix}/{k}/abs"] = np.array(t.abs().sum().item())
+
+
+def make_celeba(B=4, steps=3, seed=0):
+    """Losses of `steps` iterations + state/gradient fingerprints after the FIRST iteration.
+
+    Post-Adam parameters amplify rounding noise wherever a gradient is ~0 (e.g. conv biases in front of
+    a BatchNorm), so multi-step states are only comparable loosely; the 1-step gradients left in
+    ``.grad`` by the info step are smooth and pin the backward pass tightly."""
+    torch.set_num_threads(8)
+    real = co.synthetic_real(B * steps, seed=1234).view(steps, B, 3, 64, 64)
+    out = {"B": np.array(B), "steps": np.array(steps), "seed": np.array(seed), "real_seed": np.array(1234)}
+    names = ("d_loss", "g_loss", "info_loss")
+    for n in (1, steps):
+        batches = [(real[i].clone(), torch.zeros(B, dtype=torch.int64)) for i in range(n)]
+        g, recs = rh.run_script_loop("celebA/EAD-GAN_celebA.py", rh.celeba_opt(B), batches, names, seed)
+        if n == 1:
+            probe_state("G1", g["generator"].state_dict(), out)
+            probe_state("D1", g["discriminator"].state_dict(), out)
+            probe_grads("gG1", g["generator"], out)
+            probe_grads("gD1", g["discriminator"], out)
+    for k in names:
+        out[k] = np.array([r[k] for r in recs], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, f"celeba_b{B}_s{steps}.npz"), **out)
+    print("celeba golden:", {k: out[k] for k in names})
+
+
+def make_celeba_affine(B=16, seed=3):
+    """Function-level vectors for utils_rpqxy.get_matrix / affine_regularzier and transformation_2D."""
+    names = ("from_latent_vector_2_affine_para", "from_affine_para_2_latent_vector", "get_matrix", "affine_regularzier")
+    g = rh.load_defs("celebA/utils_rpqxy.py", names)
+    gm = rh.load_defs("celebA/EAD-GAN_celebA.py", ("transformation_2D",), opt=rh.celeba_opt(B))
+    rng = np.random.RandomState(seed)
+    code = torch.tensor(rng.uniform(-1, 1, (B, 8)), dtype=torch.float32)
+    real_code = torch.tensor(rng.uniform(-1, 1, (B, 8)), dtype=torch.float32, requires_grad=True)
+    trans_code = torch.tensor(rng.uniform(-1, 1, (B, 8)), dtype=torch.float32, requires_grad=True)
+    img = co.synthetic_real(4, seed=77)
+    with rh._cpu_only_patches():
+        A = g["get_matrix"](code[:, :5])
+        warped = gm["transformation_2D"]()(img, A[:4, 0:2])
+        pred = g["affine_regularzier"](real_code, trans_code)
+        w = torch.tensor(rng.normal(0, 1, (B, 5)), dtype=torch.float32)
+        (pred * w).sum().backward()
+    np.savez_compressed(os.path.join(GOLD, "celeba_affine.npz"), code=code.numpy(), A=A.detach().numpy(),
+                        img_seed=np.array(77), warped=warped.detach().numpy(),
+                        real_code=real_code.detach().numpy(), trans_code=trans_code.detach().numpy(),
+                        pred=pred.detach().numpy(), w=w.numpy(), d_real=real_code.grad.numpy(),
+                        d_trans=trans_code.grad.numpy())
+    print("celeba affine golden written")
+
+
+MAKERS = {"celeba": make_celeba, "celeba_affine": make_celeba_affine}
+
+if __name__ == "__main__":
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or list(MAKERS)
+    for w in which:
+        MAKERS[w]()

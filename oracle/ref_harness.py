@@ -1,0 +1,173 @@
+"""Container-only loader for the read-only reference at /root/reference  --  TEST INFRASTRUCTURE.
+
+The reference's training files are scripts (argparse + dataset + epoch loop run at import time,
+unconditional ``.cuda()``, torchvision imports).  This module parses them with ``ast`` and executes
+(a) only the class/function definitions, or (b) the whole script with its dataset / argparse /
+makedirs statements removed and a synthetic ``dataloader`` injected, so that the reference's own loop
+body runs unmodified on torch-CPU.  Nothing from the reference is copied into this repository: the
+source is read from /root/reference at run time and only numbers are written out
+(``oracle/make_golden.py``).  This module is never imported on the GPU box.
+"""
+from __future__ import annotations
+
+import argparse
+import ast
+import contextlib
+import itertools
+import math
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Variable
+from torch.nn.utils import spectral_norm
+
+REF_ROOT = "/root/reference"
+
+
+def available() -> bool:
+    return os.path.isdir(REF_ROOT)
+
+
+@contextlib.contextmanager
+def _cpu_only_patches():
+    """identity .cuda(), stub torchvision, no-op torch.save  (oracle process only)."""
+    saved = (torch.Tensor.cuda, torch.nn.Module.cuda, torch.save)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.save = lambda *a, **k: None
+    stubs = {}
+    for name in ("torchvision", "torchvision.transforms", "torchvision.utils", "torchvision.datasets"):
+        stubs[name] = sys.modules.get(name)
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision.utils"].save_image = lambda *a, **k: None
+    sys.modules["torchvision.utils"].make_grid = lambda t, *a, **k: t
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
+    sys.modules["torchvision"].datasets = sys.modules["torchvision.datasets"]
+    try:
+        yield
+    finally:
+        torch.Tensor.cuda, torch.nn.Module.cuda, torch.save = saved
+        for name, mod in stubs.items():
+            if mod is None:
+                sys.modules.pop(name, None)
+            else:
+                sys.modules[name] = mod
+
+
+def _base_globals(opt):
+    return dict(torch=torch, nn=nn, F=F, np=np, spectral_norm=spectral_norm, Variable=Variable,
+                itertools=itertools, math=math, os=os, argparse=argparse, opt=opt,
+                FloatTensor=torch.FloatTensor, LongTensor=torch.LongTensor, __name__="ref_exec")
+
+
+def load_defs(rel_path: str, names, opt=None, extra=None):
+    """Exec only the named ClassDef/FunctionDef nodes of a reference file; returns the globals."""
+    path = os.path.join(REF_ROOT, rel_path)
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in names]
+    g = _base_globals(opt)
+    if extra:
+        g.update(extra)
+    with _cpu_only_patches():
+        exec(compile(ast.Module(keep, []), path, "exec"), g)
+    return g
+
+
+_DROP_ASSIGN = {"parser", "opt", "dataloader", "dataset", "transform", "dataset_zip", "x_train", "x_train_tensor"}
+
+
+def _filter_script(tree, drop_funcs):
+    body = []
+    for n in tree.body:
+        if isinstance(n, (ast.Import, ast.ImportFrom)):
+            mod = getattr(n, "module", None) or ""
+            names = [a.name for a in n.names]
+            if mod.startswith("torchvision") or any(x.startswith("torchvision") for x in names):
+                continue
+        if isinstance(n, ast.Assign):
+            tg = {t.id for t in n.targets if isinstance(t, ast.Name)}
+            if tg & _DROP_ASSIGN:
+                continue
+        if isinstance(n, ast.Expr):
+            s = ast.unparse(n)
+            if "parser.add_argument" in s or "os.makedirs" in s or s.startswith("print(opt"):
+                continue
+        if isinstance(n, ast.FunctionDef) and n.name in drop_funcs:
+            continue
+        body.append(n)
+    return ast.Module(body, [])
+
+
+class RecordingLoader:
+    """Synthetic ``dataloader``: yields the given batches; before handing out batch i+1 (and at the
+    end) it snapshots the loss globals that iteration i left behind."""
+
+    def __init__(self, batches, loss_names):
+        self.batches, self.loss_names = batches, loss_names
+        self.g = None
+        self.records = []
+
+    def __len__(self):
+        return len(self.batches)
+
+    def _snap(self):
+        rec = {}
+        for k in self.loss_names:
+            v = self.g.get(k)
+            if v is not None:
+                rec[k] = float(v)
+        self.records.append(rec)
+
+    def __iter__(self):
+        for i, b in enumerate(self.batches):
+            if i > 0:
+                self._snap()
+            yield b
+        self._snap()
+
+
+def run_script_loop(rel_path: str, opt, batches, loss_names, seed: int, prereq=None,
+                    drop_funcs=("sample_image",)):
+    """Run the reference script's training loop on synthetic ``batches``.
+
+    ``sample_image`` (PNG visualisation, out of scope) is replaced by a no-op, so its np.random draw at
+    batches_done==0 is absent from the RNG stream; ``torch.save`` is a no-op.  Returns
+    (globals, per-step loss records)."""
+    path = os.path.join(REF_ROOT, rel_path)
+    tree = _filter_script(ast.parse(open(path).read()), set(drop_funcs))
+    loader = RecordingLoader(batches, loss_names)
+    g = _base_globals(opt)
+    g.update(dataloader=loader, sample_image=lambda *a, **k: None,
+             save_image=lambda *a, **k: None, make_grid=lambda t, *a, **k: t)
+    loader.g = g
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp(prefix="eadgan_ref_")
+    sys.path.insert(0, os.path.dirname(path))
+    try:
+        os.chdir(tmp)
+        with _cpu_only_patches():
+            if prereq:
+                prereq(tmp)
+            torch.manual_seed(seed)
+            np.random.seed(seed)
+            exec(compile(tree, path, "exec"), g)
+    finally:
+        os.chdir(cwd)
+        sys.path.pop(0)
+        for m in [m for m in sys.modules if m.startswith("utils_")]:
+            sys.modules.pop(m)
+    return g, loader.records
+
+
+def celeba_opt(batch_size):
+    """argparse defaults of celebA/EAD-GAN_celebA.py:39-51 with n_epochs=1."""
+    return argparse.Namespace(n_epochs=1, batch_size=batch_size, lr=0.0002, b1=0.5, b2=0.999, n_cpu=8,
+                              latent_dim=200, code_dim=8, n_classes=10, img_size=64, channels=3,
+                              sample_interval=4000)

@@ -1,0 +1,64 @@
+"""Oracle (CPU restatement) vs golden vectors produced by the reference itself (oracle/make_golden.py)."""
+import os
+
+import numpy as np
+import torch
+
+from conftest import GOLDEN
+from oracle import celeba_oracle as co
+
+
+def check_probes(prefix, tensors, gold, rtol, atol, noise_floor=0.0):
+    """tensors: name -> tensor; compares head/sum/abs fingerprints.  Scale-aware: tolerances are relative
+    to the mean |value| of the tensor so that near-zero entries do not dominate."""
+    for k, v in tensors.items():
+        t = v.detach().double().flatten().cpu()
+        ab = float(gold[f"{prefix}/{k}/abs"])
+        scale = ab / max(t.numel(), 1)
+        if scale < noise_floor:      # e.g. gradients of conv biases in front of a BatchNorm: pure rounding noise
+            continue
+        tol = rtol * scale + atol
+        np.testing.assert_allclose(t[:8].numpy(), gold[f"{prefix}/{k}/head"], rtol=0, atol=8 * tol, err_msg=f"{prefix}/{k}")
+        assert abs(t.abs().sum().item() - ab) <= rtol * ab + atol * t.numel() ** 0.5, f"{prefix}/{k} abs"
+        assert abs(t.sum().item() - float(gold[f"{prefix}/{k}/sum"])) <= rtol * ab + atol * t.numel() ** 0.5, f"{prefix}/{k} sum"
+
+
+def test_celeba_step_matches_reference():
+    gold = np.load(os.path.join(GOLDEN, "celeba_b4_s3.npz"))
+    B, steps, seed = int(gold["B"]), int(gold["steps"]), int(gold["seed"])
+    torch.set_num_threads(8)
+    orc = co.CelebAOracle(seed=seed)
+    rng = np.random.RandomState(seed)
+    real = co.synthetic_real(B * steps, seed=int(gold["real_seed"])).view(steps, B, 3, 64, 64)
+    for i in range(steps):
+        z, code, labels = co.draw_step_inputs(rng, B)
+        out = orc.train_step(real[i], z, code, labels)
+        # step 0 is a pure function of the seeded init; later steps pass through Adam's first-step
+        # sign amplification of rounding noise, hence the looser bound.
+        tol = (2e-6, 3e-4, 5e-3)[i]
+        for k in ("g_loss", "d_loss", "info_loss"):
+            assert abs(out[k] - gold[k][i]) < tol, (i, k, out[k], gold[k][i])
+        if i == 0:
+            # gradients left by the info step: smooth quantities -> tight
+            check_probes("gG1", {k: v.grad for k, v in orc.G.items() if getattr(v, "grad", None) is not None}, gold, 1e-2, 1e-9, noise_floor=1e-8)
+            check_probes("gD1", {k: v.grad for k, v in orc.D.items() if getattr(v, "grad", None) is not None}, gold, 1e-2, 1e-9, noise_floor=1e-8)
+            # post-Adam state: entries with ~0 gradient move by +-lr on rounding noise -> atol 2.5e-3 on heads
+            check_probes("G1", orc.G, gold, 2e-3, 3e-4)
+            check_probes("D1", orc.D, gold, 2e-3, 3e-4)
+
+
+def test_celeba_affine_functions_match_reference():
+    gold = np.load(os.path.join(GOLDEN, "celeba_affine.npz"))
+    code = torch.tensor(gold["code"])
+    A = co.get_matrix(code[:, :5])
+    np.testing.assert_allclose(A.numpy(), gold["A"], rtol=1e-6, atol=1e-7)
+    img = co.synthetic_real(4, seed=int(gold["img_seed"]))
+    warped = co.warp(img, A[:4, 0:2])
+    np.testing.assert_allclose(warped.numpy(), gold["warped"], rtol=1e-5, atol=1e-6)
+    rc = torch.tensor(gold["real_code"], requires_grad=True)
+    tc = torch.tensor(gold["trans_code"], requires_grad=True)
+    pred = co.affine_regularzier(rc, tc)
+    np.testing.assert_allclose(pred.detach().numpy(), gold["pred"], rtol=1e-4, atol=1e-5)
+    (pred * torch.tensor(gold["w"])).sum().backward()
+    np.testing.assert_allclose(rc.grad.numpy(), gold["d_real"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(tc.grad.numpy(), gold["d_trans"], rtol=1e-3, atol=1e-4)
