@@ -1,0 +1,603 @@
+"""CelebA 64x64 path of EAD-GAN on MI355X: drop-in ``Generator`` / ``Discriminator`` / ``transformation_2D`` /
+``get_matrix`` / ``affine_regularzier`` (names and signatures of celebA/EAD-GAN_celebA.py:67-158 and
+celebA/utils_rpqxy.py:59-116) plus the fused train-loop entry :class:`CelebATrainer` (loop body :299-401).
+
+Everything below the Python class surface runs as hand-written HIP kernels through the C ABI
+(include/eadgan_hip.h).  ``nn.ConvTranspose2d`` / ``nn.Conv2d`` / ``nn.BatchNorm2d`` objects are kept ONLY as
+parameter containers so that ``state_dict()`` keys, shapes and default initialisation are the reference's
+(incl. ``weight_orig`` / ``weight_u`` / ``weight_v``); their ``forward`` is never called.
+"""
+from __future__ import annotations
+
+import argparse
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.utils import spectral_norm
+
+from . import ops
+from .engine import Arena, ConvRec, Workspace, parse_dtype
+from .ops import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, EG_BF16, EG_F32, OUT_NCHW_F32)
+
+# module-level hyper-parameters, mirroring the reference's global ``opt`` (argparse defaults, :39-51)
+opt = argparse.Namespace(n_epochs=50, batch_size=16, lr=0.0002, b1=0.5, b2=0.999, n_cpu=8, latent_dim=200, code_dim=8,
+                         n_classes=10, img_size=64, channels=3, sample_interval=4000)
+
+G_WIDTHS = (1024, 512, 256, 128)
+D_WIDTHS = (128, 256, 512, 1024)
+LRELU_SLOPE = 0.1
+SN_EPS = 1e-12
+
+
+def to_categorical(y, num_columns, device=None):
+    """one-hot float tensor (celebA/EAD-GAN_celebA.py:56-62)."""
+    y = torch.as_tensor(np.asarray(y), dtype=torch.int64, device=device)
+    return torch.nn.functional.one_hot(y, num_columns).to(torch.float32)
+
+
+def _require_cuda(t):
+    if not t.is_cuda:
+        raise RuntimeError("ead-gan_amd runs on MI355X only: tensors must be on a HIP device (no CPU fallback)")
+
+
+# ================================================================================================
+# Generator
+# ================================================================================================
+class _GenEngine:
+    """Static-shape forward/backward of the generator at one batch size."""
+
+    def __init__(self, gen: "Generator", B: int, dtype: int):
+        self.gen, self.B, self.dtype = gen, B, dtype
+        dev = gen.arena.flat.device
+        tdt = ops.torch_dtype(dtype)
+        self.ws = ws = Workspace.get(dev)
+        self.cin = gen.input_dim
+        self.cpad = ops.round_up(self.cin, 8)
+        W = G_WIDTHS
+        s = gen.init_size                                              # 4
+        # L0: ConvTranspose2d(cin,1024,4,1,0) on a 1x1 input == GEMM [B,cin] x [cin, 16*1024]
+        self.l0 = ConvRec(dtype, B, 1, 1, self.cpad, 16 * W[0], 1, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
+        self.l0w = ConvRec(dtype, B, 1, 1, 16 * W[0], self.cpad, 1, 1, 0, device=dev, want_fwd=False, want_bwd=False, ws=ws)
+        # L1..L3: ConvTranspose2d(k4,s2,p1) in conv view (Cout_cv = ConvT in-channels)
+        self.mid = [ConvRec(dtype, B, s * 2 ** (i + 1), s * 2 ** (i + 1), W[i + 1], W[i], 4, 2, 1, device=dev, ws=ws) for i in range(3)]
+        self.l4 = ConvRec(dtype, B, s * 16, s * 16, gen.channels, W[3], 4, 2, 1, device=dev, want_fwd=False, want_wgrad=False, ws=ws)
+        ws.need_slab(ops.conv_img_wgrad_ws_bytes(B, gen.channels, W[3], 4))
+        # activations
+        e = lambda *shape, dt=tdt: torch.empty(shape, device=dev, dtype=dt)
+        self.inp = e(B, self.cpad)
+        self.h0 = e(B, s, s, W[0])
+        self.z = [e(B, s * 2 ** (i + 1), s * 2 ** (i + 1), W[i + 1]) for i in range(3)]
+        self.a = [torch.empty_like(t) for t in self.z]
+        self.mean = [e(W[i + 1], dt=torch.float32) for i in range(3)]
+        self.invstd = [e(W[i + 1], dt=torch.float32) for i in range(3)]
+        self.img = e(B, gen.channels, s * 16, s * 16, dt=torch.float32)
+        # gradient scratch (ping-pong between layers)
+        self.dimg_z = torch.empty_like(self.img)
+        self.da = [torch.empty_like(t) for t in self.z]
+        self.dz = [torch.empty_like(t) for t in self.z]
+        self.dh0 = torch.empty_like(self.h0)
+        for i in range(3):
+            ws.need_small(ops.bn_ws_floats(self.z[i].numel() // W[i + 1], W[i + 1]))
+        ws.need_small(ops.bias_grad_ws_floats(B * 16, W[0]))
+        ws.need_sums(2 * max(W))
+        self.repack()
+
+    def _p(self, idx, kind):
+        return getattr(self.gen.conv_blocks[idx], kind)
+
+    def repack(self):
+        g, dt = self.gen, self.dtype
+        w0 = self._p(0, "weight")                                      # [cin][1024][4][4]
+        ops.pack_strided(dt, w0, self.l0.wp_fwd, 16 * G_WIDTHS[0], self.cin, self.l0.Kpad_fwd, G_WIDTHS[0], 1, 16, 16 * G_WIDTHS[0])
+        for i, idx in enumerate((1, 4, 7)):
+            self.mid[i].pack(self._p(idx, "weight"))
+        self.l4.pack(self._p(10, "weight"))
+
+    def forward(self, noise, labels, code):
+        dt, B, W = self.dtype, self.B, G_WIDTHS
+        ops.concat_cast(dt, noise, labels, code, self.inp, B, self.cpad)
+        ops.conv_fwd(self.l0.c, dt, self.inp, self.l0.wp_fwd, self.h0, ops.epilogue(bias=self._p(0, "bias"), bias_mod=W[0]))
+        x = self.h0
+        for i, idx in enumerate((1, 4, 7)):
+            r = self.mid[i]
+            ops.conv_bwd_data(r.c, dt, x, r.wp_bwd, self.z[i], ops.epilogue(bias=self._p(idx, "bias")))
+            bn = self.gen.conv_blocks[idx + 1]
+            M = self.z[i].numel() // W[i + 1]
+            ops.bn_fwd_train(dt, self.z[i], self.a[i], M, W[i + 1], bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean,
+                             bn.running_var, bn.num_batches_tracked, self.mean[i], self.invstd[i], self.ws.small, ACT_RELU)
+            x = self.a[i]
+        ops.conv_bwd_data(self.l4.c, dt, x, self.l4.wp_bwd, self.img,
+                          ops.epilogue(bias=self._p(10, "bias"), act=ACT_TANH, out_mode=OUT_NCHW_F32))
+        return self.img
+
+    def backward(self, dimg, grad):
+        """Accumulates d(loss)/d(params) into the flat gradient tensor ``grad`` (arena layout)."""
+        dt, B, W, ws, gen = self.dtype, self.B, G_WIDTHS, self.ws, self.gen
+        gof = lambda name: gen.arena.grad_of(name, grad)
+        C, S = gen.channels, self.img.shape[-1]
+        # tanh
+        ops.act_grad_mul_f32(dimg, self.img, self.dimg_z, ACT_TANH)
+        # L4 = ConvTranspose2d(128 -> C): weight grad / bias grad / input grad through the image-side kernels
+        w4 = self._p(10, "weight")
+        ops.conv_img_wgrad(dt, self.a[2], self.dimg_z, ws.slab, B, C, S, S, W[3], 4, 2, 1)
+        ops.flat_reduce(ws.slab, B, w4.numel(), gof("conv_blocks.10.weight"))
+        ops.bias_grad_nchw(self.dimg_z, B, C, S * S, gof("conv_blocks.10.bias"))
+        ops.conv_img_fwd(dt, self.dimg_z, w4, self.da[2], B, C, S, S, W[3], 4, 2, 1, None)
+        # L3..L1
+        for i, idx in ((2, 7), (1, 4), (0, 1)):
+            r = self.mid[i]
+            bn = gen.conv_blocks[idx + 1]
+            M = self.z[i].numel() // W[i + 1]
+            ops.bn_bwd(dt, self.z[i], self.da[i], self.dz[i], M, W[i + 1], bn.weight, bn.bias, self.mean[i], self.invstd[i], ACT_RELU, 0.0,
+                       gof(f"conv_blocks.{idx + 1}.weight"), gof(f"conv_blocks.{idx + 1}.bias"), ws.sums, ws.small)
+            x_in = self.a[i - 1] if i > 0 else self.h0
+            ns = ops.conv_wgrad(r.c, dt, self.dz[i], x_in, ws.slab)
+            ops.wgrad_reduce(ws.slab, ns, r.Cout, r.Cout, r.Cin, 16, gof(f"conv_blocks.{idx}.weight"))
+            ops.bias_grad(dt, self.dz[i], M, W[i + 1], ws.small, gof(f"conv_blocks.{idx}.bias"))
+            ops.conv_fwd(r.c, dt, self.dz[i], r.wp_fwd, self.da[i - 1] if i > 0 else self.dh0, None)
+        # L0
+        ns = ops.conv_wgrad(self.l0w.c, dt, self.dh0, self.inp, ws.slab)
+        ops.wgrad_reduce(ws.slab, ns, self.cpad, self.cin, W[0], 16, gof("conv_blocks.0.weight"))
+        ops.bias_grad(dt, self.dh0, B * 16, W[0], ws.small, gof("conv_blocks.0.bias"))
+
+
+class _HipModule(nn.Module):
+    """Shared plumbing: flat arena, per-batch engines, invalidation when the module is moved."""
+
+    compute_dtype = EG_F32
+
+    def _init_engine_state(self, dtype):
+        self.compute_dtype = parse_dtype(dtype)
+        self._arena = None
+        self._engines = {}
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._arena, self._engines = None, {}
+        return out
+
+    @property
+    def arena(self) -> Arena:
+        if self._arena is None:
+            p = next(self.parameters())
+            _require_cuda(p)
+            self._arena = Arena(self)
+            self._engines = {}
+        return self._arena
+
+    def set_compute_dtype(self, dtype):
+        self.compute_dtype = parse_dtype(dtype)
+
+    def repack(self):
+        """Refresh the packed (kernel-layout, compute-dtype) weight panels after the fp32 masters changed."""
+        for e in self._engines.values():
+            e.repack()
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self.repack()
+        return out
+
+
+class Generator(_HipModule):
+    """Drop-in for celebA/EAD-GAN_celebA.py:67-102.  ``forward(noise, labels, code) -> img [B,3,64,64]``."""
+
+    def __init__(self, latent_dim=None, code_dim=None, n_classes=None, img_size=None, channels=None, dtype="f32"):
+        super().__init__()
+        g = lambda v, name: getattr(opt, name) if v is None else v
+        self.latent_dim, self.code_dim, self.n_classes = g(latent_dim, "latent_dim"), g(code_dim, "code_dim"), g(n_classes, "n_classes")
+        self.img_size, self.channels = g(img_size, "img_size"), g(channels, "channels")
+        if self.img_size != 64 or self.channels > 4:
+            raise ValueError("the CelebA generator is defined for 64x64 images (reference: img_size // 2**4 == 4)")
+        self.input_dim = self.latent_dim + self.code_dim + self.n_classes
+        self.init_size = self.img_size // 2 ** 4
+        W = G_WIDTHS
+        self.conv_blocks = nn.Sequential(
+            nn.ConvTranspose2d(self.input_dim, W[0], 4, 1, 0),
+            nn.ConvTranspose2d(W[0], W[1], 4, stride=2, padding=1), nn.BatchNorm2d(W[1]), nn.ReLU(),
+            nn.ConvTranspose2d(W[1], W[2], 4, stride=2, padding=1), nn.BatchNorm2d(W[2]), nn.ReLU(),
+            nn.ConvTranspose2d(W[2], W[3], 4, stride=2, padding=1), nn.BatchNorm2d(W[3]), nn.ReLU(),
+            nn.ConvTranspose2d(W[3], self.channels, 4, stride=2, padding=1), nn.Tanh())
+        self._init_engine_state(dtype)
+
+    def engine(self, B) -> _GenEngine:
+        self.arena
+        key = (B, self.compute_dtype)
+        if key not in self._engines:
+            self._engines[key] = _GenEngine(self, B, self.compute_dtype)
+        return self._engines[key]
+
+    def forward(self, noise, labels, code):
+        _require_cuda(noise)
+        if not self.training:
+            raise NotImplementedError("eval-mode generator (running-stat BN) is outside the training hot path of this round")
+        eng = self.engine(noise.shape[0])
+        params = [p for p in self.parameters()]
+        return _GenFn.apply(eng, noise.float().contiguous(), labels.float().contiguous(), code.float().contiguous(), *params)
+
+
+class _GenFn(torch.autograd.Function):
+    """autograd bridge so the drop-in modules compose with torch losses/optimizers (eager mode)."""
+
+    @staticmethod
+    def forward(ctx, eng, noise, labels, code, *params):
+        ctx.eng = eng
+        return eng.forward(noise, labels, code).clone()
+
+    @staticmethod
+    def backward(ctx, dimg):
+        eng = ctx.eng
+        scratch = torch.zeros_like(eng.gen.arena.grad)
+        eng.backward(dimg.contiguous(), scratch)
+        grads = [scratch[off:off + k].view(p.shape) for p, (off, k) in zip(eng.gen.parameters(), eng.gen.arena.slices.values())]
+        return (None, None, None, None, *grads)
+
+
+# ================================================================================================
+# Discriminator / Q network
+# ================================================================================================
+class _DTape:
+    """Everything one discriminator forward must keep for its backward (sigma/u/v are per-forward:
+    torch's hook clones u and v after the power iteration)."""
+
+    def __init__(self, B, dtype, dev, C, S):
+        tdt = ops.torch_dtype(dtype)
+        W = D_WIDTHS
+        self.img = None
+        self.a = [torch.empty(B, S >> (i + 1), S >> (i + 1), W[i], device=dev, dtype=tdt) for i in range(4)]
+        self.out = torch.empty(B, 19, device=dev, dtype=torch.float32)
+        kd = [C * 16] + [W[i] * 16 for i in range(3)]
+        self.sigma = [torch.empty(1, device=dev, dtype=torch.float32) for _ in range(4)]
+        self.u = [torch.empty(W[i], device=dev, dtype=torch.float32) for i in range(4)]
+        self.v = [torch.empty(kd[i], device=dev, dtype=torch.float32) for i in range(4)]
+
+
+class _DiscEngine:
+    NT = 3     # tapes alive at once: the info step runs three forwards before one backward
+
+    def __init__(self, disc: "Discriminator", B: int, dtype: int):
+        self.disc, self.B, self.dtype = disc, B, dtype
+        dev = disc.arena.flat.device
+        self.ws = ws = Workspace.get(dev)
+        W, C, S = D_WIDTHS, disc.channels, disc.img_size
+        self.C, self.S = C, S
+        self.nout = disc.n_out
+        self.l1 = ConvRec(dtype, B, S, S, C, W[0], 4, 2, 1, device=dev, want_fwd=False, want_wgrad=False, ws=ws)
+        self.mid = [ConvRec(dtype, B, S >> (i + 1), S >> (i + 1), W[i], W[i + 1], 4, 2, 1, device=dev, ws=ws) for i in range(3)]
+        self.head = ConvRec(dtype, B, 4, 4, W[3], self.nout, 4, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
+        ws.need_slab(ops.conv_img_wgrad_ws_bytes(B, C, W[0], 4))
+        ws.need_gtmp(W[0] * C * 16)
+        for i in range(4):
+            ws.need_small(ops.sn_ws_floats(W[i], (C if i == 0 else W[i - 1]) * 16))
+        self.tapes = [_DTape(B, dtype, dev, C, S) for _ in range(self.NT)]
+        tdt = ops.torch_dtype(dtype)
+        self.dz = [torch.empty(B, S >> (i + 1), S >> (i + 1), W[i], device=dev, dtype=tdt) for i in range(4)]
+        self.dimg = torch.empty(B, C, S, S, device=dev, dtype=torch.float32)
+        self.repack()
+
+    def _m(self, i):
+        return self.disc.main[2 * i]
+
+    def repack(self):
+        self.l1.pack(self._m(0).weight_orig)
+        for i in range(3):
+            self.mid[i].pack(self._m(i + 1).weight_orig)
+        self.head.pack(self._m(4).weight)
+
+    def forward(self, img, t: int, training=True):
+        dt, B, W, ws = self.dtype, self.B, D_WIDTHS, self.ws
+        tp = self.tapes[t]
+        tp.img = img
+        for i in range(4):
+            m = self._m(i)
+            w = m.weight_orig
+            ops.sn_power_iter(w, w.shape[0], w.numel() // w.shape[0], m.weight_u, m.weight_v, tp.sigma[i], tp.u[i], tp.v[i], ws.small,
+                              training, SN_EPS)
+            if not training:
+                tp.u[i].copy_(m.weight_u)
+                tp.v[i].copy_(m.weight_v)
+        ep = lambda i: ops.epilogue(bias=self._m(i).bias, sigma=tp.sigma[i], act=ACT_LRELU, slope=LRELU_SLOPE)
+        ops.conv_img_fwd(dt, img, self._m(0).weight_orig, tp.a[0], B, self.C, self.S, self.S, W[0], 4, 2, 1, ep(0))
+        for i in range(3):
+            r = self.mid[i]
+            ops.conv_fwd(r.c, dt, tp.a[i], r.wp_fwd, tp.a[i + 1], ep(i + 1))
+        K = 16 * W[3]
+        ops.dense_small_fwd(dt, tp.a[3], self.head.wp_fwd, self._m(4).bias, tp.out, B, K, self.head.Kpad_fwd, self.nout)
+        return tp.out
+
+    def backward(self, t: int, dout, grad, need_wgrad=True, need_dimg=False):
+        """``dout``: d(loss)/d(head output) [B,19] fp32.  Accumulates into flat ``grad`` (arena layout)."""
+        dt, B, W, ws, disc = self.dtype, self.B, D_WIDTHS, self.ws, self.disc
+        tp = self.tapes[t]
+        gof = lambda name: disc.arena.grad_of(name, grad)
+        K = 16 * W[3]
+        if need_wgrad:
+            ops.dense_small_wgrad(dt, dout, tp.a[3], gof("main.8.weight"), gof("main.8.bias"), B, K, self.nout, W[3], 16)
+        ops.dense_small_bwd(dt, dout, self.head.wp_fwd, tp.a[3], self.dz[3], B, K, self.head.Kpad_fwd, self.nout, ACT_LRELU, LRELU_SLOPE)
+        for i in (3, 2, 1):
+            r = self.mid[i - 1]
+            m = self._m(i)
+            rows = B * r.OH * r.OW
+            if need_wgrad:
+                ns = ops.conv_wgrad(r.c, dt, tp.a[i - 1], self.dz[i], ws.slab)
+                ops.wgrad_reduce_sn(r.c, ws.slab, ns, m.weight_orig, tp.sigma[i], tp.u[i], tp.v[i], ws.gtmp, ws.partials,
+                                    gof(f"main.{2 * i}.weight_orig"))
+                ops.bias_grad(dt, self.dz[i], rows, W[i], ws.small, gof(f"main.{2 * i}.bias"))
+            ops.conv_bwd_data(r.c, dt, self.dz[i], r.wp_bwd, self.dz[i - 1],
+                              ops.epilogue(sigma=tp.sigma[i], mask=tp.a[i - 1], mask_act=ACT_LRELU, mask_slope=LRELU_SLOPE))
+        m = self._m(0)
+        if need_wgrad:
+            ops.conv_img_wgrad(dt, self.dz[0], tp.img, ws.slab, B, self.C, self.S, self.S, W[0], 4, 2, 1)
+            ops.flat_reduce_sn(ws.slab, B, W[0], self.C * 16, m.weight_orig, tp.sigma[0], tp.u[0], tp.v[0], ws.gtmp, ws.partials,
+                               gof("main.0.weight_orig"))
+            ops.bias_grad(dt, self.dz[0], B * (self.S // 2) ** 2, W[0], ws.small, gof("main.0.bias"))
+        if need_dimg:
+            ops.conv_bwd_data(self.l1.c, dt, self.dz[0], self.l1.wp_bwd, self.dimg, ops.epilogue(sigma=tp.sigma[0], out_mode=OUT_NCHW_F32))
+            return self.dimg
+        return None
+
+
+class Discriminator(_HipModule):
+    """Drop-in for celebA/EAD-GAN_celebA.py:105-138.  ``forward(img) -> (cat, cont, validity)``; the one
+    19-channel head plays discriminator and Q-network (cat = softmax(out[:,9:19]), cont = out[:,1:9],
+    validity = sigmoid(out[:,0]))."""
+
+    def __init__(self, code_dim=None, n_classes=None, img_size=None, channels=None, dtype="f32"):
+        super().__init__()
+        g = lambda v, name: getattr(opt, name) if v is None else v
+        self.code_dim, self.n_classes = g(code_dim, "code_dim"), g(n_classes, "n_classes")
+        self.img_size, self.channels = g(img_size, "img_size"), g(channels, "channels")
+        if self.img_size != 64 or self.channels > 4:
+            raise ValueError("the CelebA discriminator is defined for 64x64 images")
+        self.n_out = 1 + self.n_classes + self.code_dim
+        W = D_WIDTHS
+        self.main = nn.Sequential(
+            spectral_norm(nn.Conv2d(self.channels, W[0], 4, 2, 1)), nn.LeakyReLU(LRELU_SLOPE, inplace=True),
+            spectral_norm(nn.Conv2d(W[0], W[1], 4, 2, 1)), nn.LeakyReLU(LRELU_SLOPE, inplace=True),
+            spectral_norm(nn.Conv2d(W[1], W[2], 4, 2, 1)), nn.LeakyReLU(LRELU_SLOPE, inplace=True),
+            spectral_norm(nn.Conv2d(W[2], W[3], 4, 2, 1)), nn.LeakyReLU(LRELU_SLOPE, inplace=True),
+            nn.Conv2d(W[3], self.n_out, 4, 1, 0))
+        self._init_engine_state(dtype)
+        self._next_tape = 0
+
+    def engine(self, B) -> _DiscEngine:
+        self.arena
+        key = (B, self.compute_dtype)
+        if key not in self._engines:
+            self._engines[key] = _DiscEngine(self, B, self.compute_dtype)
+        return self._engines[key]
+
+    def raw_forward(self, img):
+        """head output [B,19] with autograd support (eager path)."""
+        _require_cuda(img)
+        eng = self.engine(img.shape[0])
+        t = self._next_tape
+        self._next_tape = (t + 1) % _DiscEngine.NT
+        return _DiscFn.apply(eng, t, self.training, img.float().contiguous(), *list(self.parameters()))
+
+    def forward(self, img):
+        out = self.raw_forward(img)
+        cd, nc = self.code_dim, self.n_classes
+        validity = torch.sigmoid(out[:, 0])
+        cat = torch.softmax(out[:, cd + 1: cd + 1 + nc], dim=1)
+        cont = out[:, 1: cd + 1]
+        return cat, cont, validity
+
+
+class _DiscFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, t, training, img, *params):
+        ctx.eng, ctx.t = eng, t
+        ctx.need_w = any(p.requires_grad for p in params)
+        ctx.need_img = img.requires_grad
+        return eng.forward(img, t, training).clone()
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng = ctx.eng
+        scratch = torch.zeros_like(eng.disc.arena.grad)
+        dimg = eng.backward(ctx.t, dout.contiguous(), scratch, need_wgrad=ctx.need_w, need_dimg=ctx.need_img)
+        grads = [scratch[off:off + k].view(p.shape) for p, (off, k) in zip(eng.disc.parameters(), eng.disc.arena.slices.values())]
+        return (None, None, None, dimg.clone() if dimg is not None else None, *grads)
+
+
+# ================================================================================================
+# affine utilities (celebA/utils_rpqxy.py) and the STN warp
+# ================================================================================================
+def get_matrix(code_input_raw):
+    """[B,>=5] latent codes -> [B,3,3] affine matrices R(theta) Z(p,q) T(x,y)  (utils_rpqxy.py:59-80)."""
+    _require_cuda(code_input_raw)
+    c = code_input_raw.float().contiguous()
+    B = c.shape[0]
+    theta = torch.empty(B, 2, 3, device=c.device, dtype=torch.float32)
+    ops.theta_rpqxy(c, c.shape[1], B, theta)
+    A = torch.zeros(B, 3, 3, device=c.device, dtype=torch.float32)
+    A[:, :2] = theta
+    A[:, 2, 2] = 1.0
+    return A
+
+
+class transformation_2D(nn.Module):
+    """affine_grid + grid_sample(bilinear, border, align_corners=False) as one HIP kernel (:144-158)."""
+
+    def stn(self, x, matrix_2D):
+        _require_cuda(x)
+        x = x.float().contiguous()
+        out = torch.empty_like(x)
+        B, C, H, W = x.shape
+        ops.warp_affine(x, matrix_2D.float().contiguous(), out, B, C, H, W)
+        return out
+
+    def forward(self, img, matrix_2D):
+        return self.stn(img, matrix_2D)
+
+
+class _AffineRegFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, real_code, trans_code):
+        B, ld = real_code.shape
+        pred = torch.empty(B, 5, device=real_code.device, dtype=torch.float32)
+        zero_code = torch.zeros(B, 5, device=real_code.device, dtype=torch.float32)
+        ops.loss_affine_rpqxy(real_code, trans_code, ld, 0, B, zero_code, 5, 1.0, None, None, None, pred)
+        ctx.save_for_backward(real_code, trans_code)
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        # d/dcode of sum_j dpred_j * pred_j  ==  gradient of the MSE kernel with target = pred - dpred*(5B/2)
+        real_code, trans_code = ctx.saved_tensors
+        B, ld = real_code.shape
+        pred = torch.empty(B, 5, device=real_code.device, dtype=torch.float32)
+        zero_code = torch.zeros(B, 5, device=real_code.device, dtype=torch.float32)
+        ops.loss_affine_rpqxy(real_code, trans_code, ld, 0, B, zero_code, 5, 1.0, None, None, None, pred)
+        tgt = pred - dpred.float() * (5.0 * B / 2.0)
+        d_real = torch.empty_like(real_code)
+        d_trans = torch.empty_like(trans_code)
+        ops.loss_affine_rpqxy(real_code, trans_code, ld, 0, B, tgt.contiguous(), 5, 1.0, None, d_real, d_trans, None)
+        return d_real, d_trans
+
+
+def affine_regularzier(real_code, trans_code):
+    """closed-form relative-transform recovery (utils_rpqxy.py:82-116); spelling follows the reference."""
+    _require_cuda(real_code)
+    return _AffineRegFn.apply(real_code.float().contiguous(), trans_code.float().contiguous())
+
+
+# ================================================================================================
+# fused train-loop entry
+# ================================================================================================
+class CelebATrainer:
+    """One call of :meth:`train_step` == one iteration of the reference loop body
+    (celebA/EAD-GAN_celebA.py:299-401): G adversarial step, D step, info+affine step, three Adams
+    (lr 1e-3 / 2e-4 / 2e-4, betas (.5,.999), :211-217) -- hand-scheduled over the C ABI with dead work removed
+    (no D weight gradients in the G step) and, optionally, replayed from one hipGraph.
+
+    ``allreduce``: optional callable(flat_grad_tensor) applied after each backward pass (data parallel)."""
+
+    def __init__(self, generator: Generator, discriminator: Discriminator, batch_size: int, dtype="bf16", allreduce=None,
+                 lr_g=1e-3, lr_d=2e-4, lr_info=2e-4, betas=(0.5, 0.999), lambda_cat=1.0, lambda_con=1.0, lambda_affine=1.0):
+        self.G, self.D, self.B = generator, discriminator, batch_size
+        dt = parse_dtype(dtype)
+        generator.set_compute_dtype(dt)
+        discriminator.set_compute_dtype(dt)
+        self.ge, self.de = generator.engine(batch_size), discriminator.engine(batch_size)
+        dev = generator.arena.flat.device
+        self.dev = dev
+        self.allreduce = allreduce
+        self.lr = (lr_g, lr_d, lr_info)
+        self.betas = betas
+        self.lam = (lambda_cat, lambda_con, lambda_affine)
+        ga, da = generator.arena, discriminator.arena
+        z = lambda n: torch.zeros(n, device=dev, dtype=torch.float32)
+        self.mG, self.vG = z(ga.numel), z(ga.numel)                     # optimizer_G
+        self.mD, self.vD = z(da.numel), z(da.numel)                     # optimizer_D
+        self.miG, self.viG, self.miD, self.viD = z(ga.numel), z(ga.numel), z(da.numel), z(da.numel)   # optimizer_info
+        self.steps = torch.zeros(3, device=dev, dtype=torch.int32)
+        self.losses = torch.zeros(4, device=dev, dtype=torch.float32)   # g, d, info
+        B = batch_size
+        C, S = generator.channels, generator.img_size
+        self.theta = torch.empty(B, 2, 3, device=dev, dtype=torch.float32)
+        self.scaled = torch.empty(B, C, S, S, device=dev, dtype=torch.float32)
+        self.dout = [torch.empty(B, 19, device=dev, dtype=torch.float32) for _ in range(3)]
+        # static input slots (a captured graph reads these)
+        self.real = torch.empty(B, C, S, S, device=dev, dtype=torch.float32)
+        self.z = torch.empty(B, generator.latent_dim, device=dev, dtype=torch.float32)
+        self.code = torch.empty(B, generator.code_dim, device=dev, dtype=torch.float32)
+        self.onehot = torch.empty(B, generator.n_classes, device=dev, dtype=torch.float32)
+        self.labels = torch.empty(B, device=dev, dtype=torch.int64)
+        self.graph = None
+
+    # -- the hot path ---------------------------------------------------------------------------------
+    def _adam(self, arena, m, v, lr, slot, tick):
+        ops.adam_step(arena.flat, arena.grad, m, v, arena.numel, lr, self.betas[0], self.betas[1], 1e-8, self.steps[slot:slot + 1], tick)
+
+    def _step_body(self):
+        G, D, ge, de, B = self.G, self.D, self.ge, self.de, self.B
+        ga, da = G.arena, D.arena
+        cd, nc = G.code_dim, G.n_classes
+        lcat, lcon, laff = self.lam
+        ops.fill_f32(self.losses)
+        # A = get_matrix(code[:, :5]); scaled = trans_2D(real, A[:, 0:2])           (:325-327)
+        ops.theta_rpqxy(self.code, cd, B, self.theta)
+        ops.warp_affine(self.real, self.theta, self.scaled, B, G.channels, G.img_size, G.img_size)
+        # ---- 1) generator adversarial step (:334-345) ----
+        ops.fill_f32(ga.grad)
+        gen = ge.forward(self.z, self.onehot, self.code)
+        out = de.forward(gen, 0)
+        ops.loss_bce_sigmoid(out, 19, 0, B, 1.0, 1.0, self.losses[0:1], self.dout[0])
+        dimg = de.backward(0, self.dout[0], da.grad, need_wgrad=False, need_dimg=True)
+        ge.backward(dimg, ga.grad)
+        if self.allreduce is not None:
+            self.allreduce(ga.grad)
+        self._adam(ga, self.mG, self.vG, self.lr[0], 0, True)
+        ge.repack()
+        # ---- 2) discriminator step (:353-366); gen is the (detached) output of step 1 ----
+        ops.fill_f32(da.grad)
+        o_real = de.forward(self.scaled, 0)
+        o_fake = de.forward(gen, 1)
+        ops.loss_bce_sigmoid(o_real, 19, 0, B, 1.0, 0.5, self.losses[1:2], self.dout[0])
+        ops.loss_bce_sigmoid(o_fake, 19, 0, B, 0.0, 0.5, self.losses[1:2], self.dout[1])
+        de.backward(1, self.dout[1], da.grad)
+        de.backward(0, self.dout[0], da.grad)
+        if self.allreduce is not None:
+            self.allreduce(da.grad)
+        self._adam(da, self.mD, self.vD, self.lr[1], 1, True)
+        de.repack()
+        # ---- 3) info + affine step (:375-401) ----
+        ops.fill_f32(ga.grad)
+        ops.fill_f32(da.grad)
+        gen = ge.forward(self.z, self.onehot, self.code)
+        o_gen = de.forward(gen, 0)
+        o_trans = de.forward(self.scaled, 1)
+        o_real = de.forward(self.real, 2)
+        ops.loss_mse(o_gen, 19, 1, cd, B, self.code, cd, 0.0, lcon, self.losses[2:3], self.dout[0])
+        ops.loss_ce_softmaxed(o_gen, 19, cd + 1, nc, B, self.labels, lcat, self.losses[2:3], self.dout[0])
+        ops.loss_affine_rpqxy(o_real, o_trans, 19, 1, B, self.code, cd, laff, self.losses[2:3], self.dout[2], self.dout[1])
+        de.backward(2, self.dout[2], da.grad)
+        de.backward(1, self.dout[1], da.grad)
+        dimg = de.backward(0, self.dout[0], da.grad, need_dimg=True)
+        ge.backward(dimg, ga.grad)
+        if self.allreduce is not None:
+            self.allreduce(ga.grad)
+            self.allreduce(da.grad)
+        self._adam(ga, self.miG, self.viG, self.lr[2], 2, True)
+        self._adam(da, self.miD, self.viD, self.lr[2], 2, False)
+        ge.repack()
+        de.repack()
+
+    # -- public API -----------------------------------------------------------------------------------
+    def load_inputs(self, real_imgs, z, code, labels):
+        self.real.copy_(real_imgs, non_blocking=True)
+        self.z.copy_(z, non_blocking=True)
+        self.code.copy_(code, non_blocking=True)
+        self.labels.copy_(labels, non_blocking=True)
+        self.onehot.zero_()
+        self.onehot.scatter_(1, self.labels.view(-1, 1), 1.0)
+
+    def capture(self, warmup: bool = False):
+        """Capture the whole iteration into one hipGraph (inputs are read from the static slots).
+
+        At least one eager iteration must have run before (it loads every kernel and sizes the workspace);
+        ``warmup=True`` runs that iteration here -- note that it IS a real training step on the current inputs."""
+        if warmup:
+            self._step_body()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._step_body()
+        return self
+
+    def step_resident(self):
+        """Run one iteration on whatever is in the static input slots; returns the device loss tensor [g,d,info,_]."""
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._step_body()
+        return self.losses
+
+    def train_step(self, real_imgs, z, code, labels):
+        """train-loop entry: real_imgs [B,3,64,64] in [-1,1], z [B,200], code [B,8], labels int64 [B]."""
+        self.load_inputs(real_imgs, z, code, labels)
+        l = self.step_resident().tolist()
+        return {"g_loss": l[0], "d_loss": l[1], "info_loss": l[2]}

@@ -1,0 +1,195 @@
+// Affine warp (F.affine_grid + F.grid_sample bilinear/border, celebA/EAD-GAN_celebA.py:146-152), latent-code ->
+// matrix kernels (celebA/utils_rpqxy.py:59-80) and the fused loss heads with their gradients
+// (celebA/EAD-GAN_celebA.py:161-169,342,355-362,383-395).  All reductions are single-block and deterministic.
+#include "affine_math.h"
+
+// theta[b][2][3] from 5 latent codes (row stride ldc)
+__global__ void theta_rpqxy_kernel(const float* __restrict__ code, int ldc, int B, float* __restrict__ theta) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float c[5];
+    for (int i = 0; i < 5; ++i) c[i] = code[(size_t)b * ldc + i];
+    const Aff<float> m = matrix_rpqxy<float>(c);
+    float* t = theta + (size_t)b * 6;
+    t[0] = m.a; t[1] = m.b; t[2] = m.c; t[3] = m.d; t[4] = m.e; t[5] = m.f;
+}
+
+extern "C" int eg_theta_rpqxy(const float* code, int ldc, int B, float* theta, eg_stream_t s) {
+    EG_REQUIRE(code && theta && ldc >= 5, "eg_theta_rpqxy: bad argument");
+    hipLaunchKernelGGL(theta_rpqxy_kernel, dim3(cdiv(B, 128)), dim3(128), 0, (hipStream_t)s, code, ldc, B, theta);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[b,c,y,x] = bilinear sample of img[b,c] at theta[b] * (xn, yn, 1), align_corners=False, border padding
+__global__ void warp_affine_kernel(const float* __restrict__ img, const float* __restrict__ theta, float* __restrict__ out, int B, int C,
+                                   int H, int W) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)B * H * W;
+    if (idx >= total) return;
+    const int x = (int)(idx % W), y = (int)((idx / W) % H), b = (int)(idx / ((size_t)W * H));
+    const float* t = theta + (size_t)b * 6;
+    const float xn = (2.f * x + 1.f) / W - 1.f, yn = (2.f * y + 1.f) / H - 1.f;
+    const float gx = t[0] * xn + t[1] * yn + t[2];
+    const float gy = t[3] * xn + t[4] * yn + t[5];
+    float ix = ((gx + 1.f) * W - 1.f) * 0.5f, iy = ((gy + 1.f) * H - 1.f) * 0.5f;
+    ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
+    iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx, wx0 = 1.f - wx1, wy1 = iy - fy, wy0 = 1.f - wy1;
+    const bool vx1 = x1 < W, vy1 = y1 < H;
+    for (int c = 0; c < C; ++c) {
+        const float* p = img + ((size_t)b * C + c) * H * W;
+        float v = p[y0 * W + x0] * (wx0 * wy0);
+        if (vx1) v += p[y0 * W + x1] * (wx1 * wy0);
+        if (vy1) v += p[y1 * W + x0] * (wx0 * wy1);
+        if (vx1 && vy1) v += p[y1 * W + x1] * (wx1 * wy1);
+        out[((size_t)b * C + c) * H * W + (size_t)y * W + x] = v;
+    }
+}
+
+extern "C" int eg_warp_affine(const float* img, const float* theta, float* out, int B, int C, int H, int W, eg_stream_t s) {
+    EG_REQUIRE(img && theta && out, "eg_warp_affine: null pointer");
+    const size_t total = (size_t)B * H * W;
+    hipLaunchKernelGGL(warp_affine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, img, theta, out, B, C, H, W);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- loss heads: operate on the raw head output `o` [B][ld] fp32; write d(loss)/d(o) into `dout` [B][ld] ------
+// BCELoss(sigmoid(o[:,col]), target) * scale ; loss[slot] += value ; dout row zero-filled first when zero_rows!=0
+__global__ void bce_sigmoid_kernel(const float* __restrict__ o, int ld, int col, int B, float target, float scale, float* loss,
+                                   float* __restrict__ dout, int zero_rows) {
+    __shared__ float sm[16];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float p = 1.f / (1.f + expf(-o[(size_t)b * ld + col]));
+        const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);
+        acc += -(target * lp + (1.f - target) * l1p);
+        if (dout) {
+            if (zero_rows)
+                for (int j = 0; j < ld; ++j) dout[(size_t)b * ld + j] = 0.f;
+            // torch binary_cross_entropy_backward: (p - t) / max((1-p) p, 1e-12), then sigmoid backward p (1-p)
+            const float gp = (p - target) / fmaxf((1.f - p) * p, 1e-12f) * (scale / (float)B);
+            dout[(size_t)b * ld + col] = gp * p * (1.f - p);
+        }
+    }
+    const float tot = block_sum(acc, sm);
+    if (threadIdx.x == 0 && loss) loss[0] += scale * tot / (float)B;
+}
+
+extern "C" int eg_loss_bce_sigmoid(const float* o, int ld, int col, int B, float target, float scale, float* loss, float* dout,
+                                   int zero_rows, eg_stream_t s) {
+    EG_REQUIRE(o && B > 0, "eg_loss_bce_sigmoid: bad argument");
+    hipLaunchKernelGGL(bce_sigmoid_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, o, ld, col, B, target, scale, loss, dout, zero_rows);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// MSE(o[:,col0:col0+n], target) * scale  (target: per-element tensor tgt[B][ldt] or constant when tgt==null)
+__global__ void mse_kernel(const float* __restrict__ o, int ld, int col0, int n, int B, const float* __restrict__ tgt, int ldt, float tconst,
+                           float scale, float* loss, float* __restrict__ dout, int zero_rows) {
+    __shared__ float sm[16];
+    float acc = 0.f;
+    const float gs = 2.f * scale / (float)(B * n);
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        if (dout && zero_rows)
+            for (int j = 0; j < ld; ++j) dout[(size_t)b * ld + j] = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const float d = o[(size_t)b * ld + col0 + j] - (tgt ? tgt[(size_t)b * ldt + j] : tconst);
+            acc += d * d;
+            if (dout) dout[(size_t)b * ld + col0 + j] = gs * d;
+        }
+    }
+    const float tot = block_sum(acc, sm);
+    if (threadIdx.x == 0 && loss) loss[0] += scale * tot / (float)(B * n);
+}
+
+extern "C" int eg_loss_mse(const float* o, int ld, int col0, int n, int B, const float* tgt, int ldt, float tconst, float scale, float* loss,
+                           float* dout, int zero_rows, eg_stream_t s) {
+    EG_REQUIRE(o && B > 0 && n > 0, "eg_loss_mse: bad argument");
+    hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, o, ld, col0, n, B, tgt, ldt, tconst, scale, loss, dout, zero_rows);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// CrossEntropyLoss applied to softmax(o[:,c0:c0+n]) (the reference feeds probabilities, i.e. a double softmax:
+// celebA/EAD-GAN_celebA.py:132,383 ; MNIST/EAD-GAN_rpqmnxy.py:161,427).  Adds into dout (does not zero).
+#define EG_MAXCAT 16
+__global__ void ce_softmaxed_kernel(const float* __restrict__ o, int ld, int c0, int n, int B, const long long* __restrict__ labels,
+                                    float scale, float* loss, float* __restrict__ dout) {
+    __shared__ float sm[16];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        float q[EG_MAXCAT], r[EG_MAXCAT];
+        float mx = -INFINITY;
+        for (int j = 0; j < n; ++j) mx = fmaxf(mx, o[(size_t)b * ld + c0 + j]);
+        float se = 0.f;
+        for (int j = 0; j < n; ++j) { q[j] = expf(o[(size_t)b * ld + c0 + j] - mx); se += q[j]; }
+        for (int j = 0; j < n; ++j) q[j] /= se;
+        float mq = -INFINITY;
+        for (int j = 0; j < n; ++j) mq = fmaxf(mq, q[j]);
+        float s2 = 0.f;
+        for (int j = 0; j < n; ++j) { r[j] = expf(q[j] - mq); s2 += r[j]; }
+        const int lab = (int)labels[b];
+        acc += -(q[lab] - mq - logf(s2));
+        if (dout) {
+            float dot = 0.f;
+            float gq[EG_MAXCAT];
+            for (int j = 0; j < n; ++j) { gq[j] = (r[j] / s2 - (j == lab ? 1.f : 0.f)) * (scale / (float)B); dot += gq[j] * q[j]; }
+            for (int j = 0; j < n; ++j) dout[(size_t)b * ld + c0 + j] += q[j] * (gq[j] - dot);
+        }
+    }
+    const float tot = block_sum(acc, sm);
+    if (threadIdx.x == 0 && loss) loss[0] += scale * tot / (float)B;
+}
+
+extern "C" int eg_loss_ce_softmaxed(const float* o, int ld, int c0, int n, int B, const long long* labels, float scale, float* loss,
+                                    float* dout, eg_stream_t s) {
+    EG_REQUIRE(o && labels && n <= EG_MAXCAT && B > 0, "eg_loss_ce_softmaxed: bad argument");
+    hipLaunchKernelGGL(ce_softmaxed_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, o, ld, c0, n, B, labels, scale, loss, dout);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// affine-consistency loss, CelebA variant:  MSE(regulariser(real_code, trans_code), code[:, :5]) * scale
+// o_real / o_trans: head outputs [B][ld], codes start at column c0.  d_real / d_trans rows are zero-filled.
+__global__ void affine_reg_rpqxy_kernel(const float* __restrict__ o_real, const float* __restrict__ o_trans, int ld, int c0, int B,
+                                        const float* __restrict__ code, int ldc, float scale, float* loss, float* __restrict__ d_real,
+                                        float* __restrict__ d_trans, float* __restrict__ pred_out) {
+    __shared__ float sm[16];
+    float acc = 0.f;
+    const float gs = 2.f * scale / (float)(B * 5);
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        Dual<10> rc[5], tc[5], out[5];
+        for (int i = 0; i < 5; ++i) {
+            rc[i] = dvar<10>(o_real[(size_t)b * ld + c0 + i], i);
+            tc[i] = dvar<10>(o_trans[(size_t)b * ld + c0 + i], 5 + i);
+        }
+        regularizer_rpqxy<Dual<10>>(rc, tc, out);
+        float gr[10];
+        for (int i = 0; i < 10; ++i) gr[i] = 0.f;
+        for (int j = 0; j < 5; ++j) {
+            const float d = out[j].v - code[(size_t)b * ldc + j];
+            acc += d * d;
+            if (pred_out) pred_out[(size_t)b * 5 + j] = out[j].v;
+            for (int i = 0; i < 10; ++i) gr[i] += gs * d * out[j].d[i];
+        }
+        if (d_real && d_trans) {
+            for (int j = 0; j < ld; ++j) { d_real[(size_t)b * ld + j] = 0.f; d_trans[(size_t)b * ld + j] = 0.f; }
+            for (int i = 0; i < 5; ++i) { d_real[(size_t)b * ld + c0 + i] = gr[i]; d_trans[(size_t)b * ld + c0 + i] = gr[5 + i]; }
+        }
+    }
+    const float tot = block_sum(acc, sm);
+    if (threadIdx.x == 0 && loss) loss[0] += scale * tot / (float)(B * 5);
+}
+
+extern "C" int eg_loss_affine_rpqxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc, float scale,
+                                    float* loss, float* d_real, float* d_trans, float* pred_out, eg_stream_t s) {
+    EG_REQUIRE(o_real && o_trans && code && B > 0, "eg_loss_affine_rpqxy: bad argument");
+    hipLaunchKernelGGL(affine_reg_rpqxy_kernel, dim3(1), dim3(128), 0, (hipStream_t)s, o_real, o_trans, ld, c0, B, code, ldc, scale, loss, d_real,
+                       d_trans, pred_out);
+    EG_LAUNCH_CHECK();
+    return 0;
+}

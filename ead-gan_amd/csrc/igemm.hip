@@ -1,0 +1,811 @@
+// Implicit-GEMM convolution family for gfx950 (MFMA, 64-wide waves, LDS-staged 128-byte K rows).
+//
+//   igemm_nt : C[m][n] = sum_k A[m][k] * Wp[n][k]       A rows gathered from an NHWC tensor
+//              (conv forward, conv backward-data == ConvTranspose forward, linear)
+//   igemm_tn : S[n][t][c] = sum_m P[m][n] * X[pix(m,t)][c]   (weight gradients, split over m)
+//
+// Both run in fp32 (v_mfma_f32_16x16x4_f32, exact fp32) or bf16 (v_mfma_f32_16x16x32_bf16, fp32
+// accumulate).  K rows in LDS are always 128 bytes (32 fp32 / 64 bf16) and XOR-swizzled in 16-byte
+// chunks so that ds_read_b128 fragment reads are bank-conflict free without padding.
+#include <type_traits>
+
+#include "eg_common.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// ------------------------------------------------------------------------------------------------
+// geometry derived from eg_conv
+// ------------------------------------------------------------------------------------------------
+struct NtPhase {
+    int TH, TW, dy0, dys, dx0, dxs, ooy, oox, K, Kpad;
+    long long w_off;   // element offset of this phase's packed weights
+};
+struct NtParams {
+    const void* src;
+    const void* wp;
+    void* dst;
+    const float* bias;
+    const float* sigma;
+    const void* mask;
+    int B, H, W, C;   // gathered source tensor (NHWC)
+    int lOH, lOW;     // log2 of the output lattice
+    int sy, sx, up;
+    int N, bias_mod;
+    int DH, DW, osy, osx;
+    int act;
+    float slope;
+    int mask_act;
+    float mask_slope;
+    int out_mode;
+    int M;
+    NtPhase ph[4];
+};
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline int bk_of(int dtype) { return dtype == EG_F32 ? 32 : 64; }
+static inline int vec_of(int dtype) { return dtype == EG_F32 ? 4 : 8; }
+
+static int conv_out_dim(const eg_conv* c, int in) { return ((in << c->up) + 2 * c->pad - c->k) / c->stride + 1; }
+
+enum { NEED_CIN = 1, NEED_COUT = 2 };
+static int check_conv(const eg_conv* c, int dtype, int need) {
+    EG_REQUIRE(c && c->B > 0 && c->k > 0 && c->stride > 0 && c->pad >= 0 && (c->up == 0 || c->up == 1), "eg_conv: bad field");
+    EG_REQUIRE(dtype == EG_F32 || dtype == EG_BF16, "dtype must be EG_F32 or EG_BF16");
+    const int OH = conv_out_dim(c, c->H), OW = conv_out_dim(c, c->W);
+    EG_REQUIRE(ilog2_exact(c->H) >= 0 && ilog2_exact(c->W) >= 0 && ilog2_exact(OH) >= 0 && ilog2_exact(OW) >= 0,
+               "spatial extents must be powers of two (H=%d W=%d OH=%d OW=%d)", c->H, c->W, OH, OW);
+    EG_REQUIRE((!(need & NEED_CIN) || c->Cin % vec_of(dtype) == 0) && (!(need & NEED_COUT) || c->Cout % vec_of(dtype) == 0),
+               "gathered channel count must be a multiple of %d for this dtype (Cin=%d Cout=%d); pad the tensor", vec_of(dtype), c->Cin, c->Cout);
+    return 0;
+}
+
+// forward: one phase, taps = k x k, source = X
+static void geom_fwd(const eg_conv* c, int dtype, NtParams& p) {
+    const int OH = conv_out_dim(c, c->H), OW = conv_out_dim(c, c->W);
+    p.B = c->B; p.H = c->H; p.W = c->W; p.C = c->Cin;
+    p.lOH = ilog2_exact(OH); p.lOW = ilog2_exact(OW);
+    p.sy = p.sx = c->stride; p.up = c->up;
+    p.N = c->Cout;
+    p.DH = OH; p.DW = OW; p.osy = p.osx = 1;
+    p.M = c->B * OH * OW;
+    NtPhase& f = p.ph[0];
+    f.TH = f.TW = c->k; f.dy0 = f.dx0 = -c->pad; f.dys = f.dxs = 1; f.ooy = f.oox = 0;
+    f.K = c->k * c->k * c->Cin; f.Kpad = round_up(f.K, bk_of(dtype)); f.w_off = 0;
+}
+
+struct BwdAxis { int k0, T, d0; };   // first kernel index, tap count, source offset for tap 0 (then -1 per tap)
+static BwdAxis bwd_axis(const eg_conv* c, int r) {
+    BwdAxis a;
+    a.k0 = (r + c->pad) % c->stride;
+    a.T = a.k0 < c->k ? (c->k - a.k0 + c->stride - 1) / c->stride : 0;
+    a.d0 = (r + c->pad - a.k0) / c->stride;
+    return a;
+}
+
+// backward-data: stride*stride phases; source = dY (lattice == dY's grid), dst = dX interleaved
+static int geom_bwd(const eg_conv* c, int dtype, NtParams& p, int* nphase) {
+    const int OH = conv_out_dim(c, c->H), OW = conv_out_dim(c, c->W);
+    const int s = c->stride;
+    EG_REQUIRE(s == 1 || s == 2, "stride must be 1 or 2");
+    const int XH = c->H << c->up, XW = c->W << c->up;   // dX is produced at the (upsampled) conv-input resolution
+    EG_REQUIRE(XH % s == 0 && XW % s == 0 && XH / s == OH && XW / s == OW,
+               "backward-data needs OH == H/stride (k=%d s=%d p=%d)", c->k, s, c->pad);
+    p.B = c->B; p.H = OH; p.W = OW; p.C = c->Cout;
+    p.lOH = ilog2_exact(OH); p.lOW = ilog2_exact(OW);
+    p.sy = p.sx = 1; p.up = 0;
+    p.N = c->Cin;
+    p.DH = XH; p.DW = XW; p.osy = p.osx = s;
+    p.M = c->B * OH * OW;
+    long long off = 0;
+    int n = 0;
+    for (int ry = 0; ry < s; ++ry)
+        for (int rx = 0; rx < s; ++rx) {
+            const BwdAxis ay = bwd_axis(c, ry), ax = bwd_axis(c, rx);
+            NtPhase& f = p.ph[n++];
+            f.TH = ay.T; f.TW = ax.T; f.dy0 = ay.d0; f.dx0 = ax.d0; f.dys = f.dxs = -1; f.ooy = ry; f.oox = rx;
+            f.K = ay.T * ax.T * c->Cout; f.Kpad = round_up(f.K > 0 ? f.K : 1, bk_of(dtype)); f.w_off = off;
+            off += (long long)c->Cin * f.Kpad;
+        }
+    *nphase = n;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS helpers: rows of 128 bytes, 16-byte chunk c of row r lives at chunk (c ^ ((r>>1)&7))
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T>
+__device__ __forceinline__ void mfma_step(const uint4& a, const uint4& b, f32x4& acc) {
+    if constexpr (std::is_same<T, float>::value) {
+        const float* af = reinterpret_cast<const float*>(&a);
+        const float* bf = reinterpret_cast<const float*>(&b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc, 0, 0, 0);
+    } else {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// igemm_nt
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
+    constexpr int VEC = Elt<T>::VEC;
+    constexpr int BK = 8 * VEC;
+    constexpr int TM = BM / WGM / 16, TN = BN / WGN / 16;
+    constexpr int A_LD = BM / 32;
+    constexpr int B_LD = (BN + 31) / 32;
+    constexpr int STAGE = (BM + BN) * 128;
+    static_assert(WGM * WGN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const NtPhase ph = p.ph[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int chunk = tid & 7, rbase = tid >> 3;
+    const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
+    const int HU = p.H << p.up, WU = p.W << p.up;
+
+    // per-thread A rows
+    int a_pix0[A_LD];   // b*H*W (pixel base of the image) or -1 when the row is out of range
+    int a_y[A_LD], a_x[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        const int m = m0 + rbase + 32 * i;
+        const int b = m >> (p.lOW + p.lOH);
+        a_pix0[i] = (m < p.M) ? b * p.H * p.W : -1;
+        a_y[i] = ((m >> p.lOW) & OHm) * p.sy + ph.dy0;
+        a_x[i] = (m & OWm) * p.sx + ph.dx0;
+    }
+    // tap state of this thread's 16-byte chunk
+    int kc = chunk * VEC, ty = 0, tx = 0;
+    while (kc >= p.C) { kc -= p.C; if (++tx == ph.TW) { tx = 0; ++ty; } }
+
+    const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
+    const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp) + ph.w_off;
+    const int nk = ph.Kpad / BK;
+
+    uint4 ra[A_LD], rb[B_LD];
+    auto gload = [&](int kt) {
+        const bool tap_ok = ty < ph.TH;
+        const int oy = ty * ph.dys, ox = tx * ph.dxs;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int iy = a_y[i] + oy, ix = a_x[i] + ox;
+            const bool ok = tap_ok && a_pix0[i] >= 0 && iy >= 0 && iy < HU && ix >= 0 && ix < WU;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const size_t pix = (size_t)a_pix0[i] + (size_t)((iy >> p.up) * p.W + (ix >> p.up));
+                v = *reinterpret_cast<const uint4*>(src + pix * p.C + kc);
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int r = rbase + 32 * i;
+            const int n = n0 + r;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (r < BN && n < p.N) v = *reinterpret_cast<const uint4*>(wp + (size_t)n * ph.Kpad + (size_t)kt * BK + chunk * VEC);
+            rb[i] = v;
+        }
+        kc += BK;
+        while (kc >= p.C) { kc -= p.C; if (++tx == ph.TW) { tx = 0; ++ty; } }
+    };
+    auto lstore = [&](int stage) {
+        char* sa = smem + stage * STAGE;
+        char* sb = sa + BM * 128;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) *reinterpret_cast<uint4*>(sa + lds_off(rbase + 32 * i, chunk)) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            const int r = rbase + 32 * i;
+            if (r < BN) *reinterpret_cast<uint4*>(sb + lds_off(r, chunk)) = rb[i];
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    if (nk > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+        const char* sa = smem + (kt & 1) * STAGE;
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const uint4*>(sa + lds_off((wm * TM + i) * 16 + frow, ks * 4 + fq));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(sb + lds_off((wn * TN + j) * 16 + frow, ks * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) mfma_step<T>(af[i], bfr[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+    const float inv_sigma = p.sigma ? 1.f / p.sigma[0] : 1.f;
+    const T* __restrict__ mask = reinterpret_cast<const T*>(p.mask);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + (wm * TM + i) * 16 + fq * 4 + r;
+            if (m >= p.M) continue;
+            const int b = m >> (p.lOW + p.lOH);
+            const int y = ((m >> p.lOW) & OHm) * p.osy + ph.ooy;
+            const int x = (m & OWm) * p.osx + ph.oox;
+            const size_t pix = ((size_t)b * p.DH + y) * p.DW + x;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + (wn * TN + j) * 16 + frow;
+                if (n >= p.N) continue;
+                float v = acc[i][j][r] * inv_sigma;
+                if (p.bias) v += p.bias[p.bias_mod ? n % p.bias_mod : n];
+                v = eg_act(v, p.act, p.slope);
+                if (p.out_mode == EG_OUT_NHWC) {
+                    const size_t o = pix * p.N + n;
+                    if (mask) v *= eg_act_grad_from_out(Elt<T>::ld(mask + o), p.mask_act, p.mask_slope);
+                    Elt<T>::st(reinterpret_cast<T*>(p.dst) + o, v);
+                } else {
+                    const size_t o = (((size_t)b * p.N + n) * p.DH + y) * p.DW + x;
+                    if (p.mask) v *= eg_act_grad_from_out(reinterpret_cast<const float*>(p.mask)[o], p.mask_act, p.mask_slope);
+                    reinterpret_cast<float*>(p.dst)[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN>
+static void launch_nt_cfg(const NtParams& p, int nphase, hipStream_t st) {
+    dim3 grid(cdiv(p.M, BM), cdiv(p.N, BN), nphase);
+    const size_t lds = 2 * (BM + BN) * 128;
+    hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, WGM, WGN>), grid, dim3(256), lds, st, p);
+}
+
+template <typename T>
+static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
+    if (p.N <= 16)
+        launch_nt_cfg<T, 128, 16, 4, 1>(p, nphase, st);
+    else if (p.N <= 32)
+        launch_nt_cfg<T, 128, 32, 4, 1>(p, nphase, st);
+    else if (p.N <= 64 || (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * nphase < 192)
+        launch_nt_cfg<T, 128, 64, 2, 2>(p, nphase, st);
+    else
+        launch_nt_cfg<T, 128, 128, 2, 2>(p, nphase, st);
+}
+
+static void fill_epilogue(NtParams& p, const eg_epilogue* ep) {
+    p.bias = ep ? ep->bias : nullptr;
+    p.bias_mod = ep ? ep->bias_mod : 0;
+    p.sigma = ep ? ep->sigma : nullptr;
+    p.act = ep ? ep->act : EG_ACT_NONE;
+    p.slope = ep ? ep->slope : 0.f;
+    p.mask = ep ? ep->mask : nullptr;
+    p.mask_act = ep ? ep->mask_act : EG_ACT_NONE;
+    p.mask_slope = ep ? ep->mask_slope : 0.f;
+    p.out_mode = ep ? ep->out_mode : EG_OUT_NHWC;
+}
+
+extern "C" int eg_conv_fwd(const eg_conv* c, int dtype, const void* X, const void* wp_fwd, void* Y,
+                           const eg_epilogue* ep, eg_stream_t s) {
+    if (int e = check_conv(c, dtype, NEED_CIN)) return e;
+    EG_REQUIRE(X && wp_fwd && Y, "eg_conv_fwd: null pointer");
+    NtParams p;
+    memset(&p, 0, sizeof(p));
+    geom_fwd(c, dtype, p);
+    p.src = X; p.wp = wp_fwd; p.dst = Y;
+    fill_epilogue(p, ep);
+    if (dtype == EG_F32) launch_nt<float>(p, 1, (hipStream_t)s); else launch_nt<bf16_t>(p, 1, (hipStream_t)s);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, const void* wp_bwd, void* dX,
+                                const eg_epilogue* ep, eg_stream_t s) {
+    if (int e = check_conv(c, dtype, NEED_COUT)) return e;
+    EG_REQUIRE(dY && wp_bwd && dX, "eg_conv_bwd_data: null pointer");
+    NtParams p;
+    memset(&p, 0, sizeof(p));
+    int nphase = 0;
+    if (int e = geom_bwd(c, dtype, p, &nphase)) return e;
+    p.src = dY; p.wp = wp_bwd; p.dst = dX;
+    fill_epilogue(p, ep);
+    if (dtype == EG_F32) launch_nt<float>(p, nphase, (hipStream_t)s); else launch_nt<bf16_t>(p, nphase, (hipStream_t)s);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: fp32 master [Cout][Cin][k][k]  ->  K-contiguous dtype-T panels
+// ------------------------------------------------------------------------------------------------
+struct PackParams {
+    const float* w;
+    void* wp;
+    int Nrows;           // rows of the packed panel
+    int Crow;            // channels per tap in a row
+    int TH, TW, kh0, khs, kw0, kws, k;
+    int K, Kpad;
+    long long n_stride, c_stride;   // master strides of the (row, channel) indices
+    long long w_off;
+};
+
+template <typename T>
+__global__ void pack_kernel(const PackParams p) {
+    const long long total = (long long)p.Nrows * p.Kpad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / p.Kpad), kk = (int)(i % p.Kpad);
+        float v = 0.f;
+        if (kk < p.K) {
+            const int t = kk / p.Crow, c = kk % p.Crow;
+            const int ty = t / p.TW, tx = t % p.TW;
+            const int kh = p.kh0 + ty * p.khs, kw = p.kw0 + tx * p.kws;
+            v = p.w[n * p.n_stride + c * p.c_stride + kh * p.k + kw];
+        }
+        Elt<T>::st(reinterpret_cast<T*>(p.wp) + p.w_off + i, v);
+    }
+}
+
+static void launch_pack(const PackParams& p, int dtype, hipStream_t st) {
+    const long long total = (long long)p.Nrows * p.Kpad;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (dtype == EG_F32) hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, p);
+}
+
+extern "C" size_t eg_pack_fwd_elems(const eg_conv* c, int dtype) {
+    return (size_t)c->Cout * round_up(c->k * c->k * c->Cin, bk_of(dtype));
+}
+extern "C" size_t eg_pack_bwd_elems(const eg_conv* c, int dtype) {
+    size_t tot = 0;
+    for (int ry = 0; ry < c->stride; ++ry)
+        for (int rx = 0; rx < c->stride; ++rx) {
+            const int K = bwd_axis(c, ry).T * bwd_axis(c, rx).T * c->Cout;
+            tot += (size_t)c->Cin * round_up(K > 0 ? K : 1, bk_of(dtype));
+        }
+    return tot;
+}
+
+extern "C" int eg_pack_fwd(const eg_conv* c, int dtype, const float* w, void* wp, eg_stream_t s) {
+    EG_REQUIRE(c && w && wp, "eg_pack_fwd: null pointer");
+    PackParams p;
+    memset(&p, 0, sizeof(p));
+    p.w = w; p.wp = wp; p.Nrows = c->Cout; p.Crow = c->Cin;
+    p.TH = p.TW = c->k; p.kh0 = p.kw0 = 0; p.khs = p.kws = 1; p.k = c->k;
+    p.K = c->k * c->k * c->Cin; p.Kpad = round_up(p.K, bk_of(dtype));
+    p.n_stride = (long long)c->Cin * c->k * c->k; p.c_stride = c->k * c->k;
+    launch_pack(p, dtype, (hipStream_t)s);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int eg_pack_bwd(const eg_conv* c, int dtype, const float* w, void* wp, eg_stream_t s) {
+    EG_REQUIRE(c && w && wp, "eg_pack_bwd: null pointer");
+    long long off = 0;
+    for (int ry = 0; ry < c->stride; ++ry)
+        for (int rx = 0; rx < c->stride; ++rx) {
+            const BwdAxis ay = bwd_axis(c, ry), ax = bwd_axis(c, rx);
+            PackParams p;
+            memset(&p, 0, sizeof(p));
+            p.w = w; p.wp = wp; p.Nrows = c->Cin; p.Crow = c->Cout;
+            p.TH = ay.T; p.TW = ax.T > 0 ? ax.T : 1; p.kh0 = ay.k0; p.kw0 = ax.k0; p.khs = p.kws = c->stride; p.k = c->k;
+            p.K = ay.T * ax.T * c->Cout; p.Kpad = round_up(p.K > 0 ? p.K : 1, bk_of(dtype));
+            p.n_stride = c->k * c->k; p.c_stride = (long long)c->Cin * c->k * c->k;
+            p.w_off = off;
+            launch_pack(p, dtype, (hipStream_t)s);
+            off += (long long)c->Cin * p.Kpad;
+        }
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// generic strided pack: wp[n][k] = w[(n / n_div) * s_hi + (n % n_div) * s_lo + k * s_k]  (k < K, else 0)
+template <typename T>
+__global__ void pack_strided_kernel(const float* __restrict__ w, T* __restrict__ wp, int N, int K, int Kpad, int n_div, long long s_hi,
+                                    long long s_lo, long long s_k) {
+    const long long total = (long long)N * Kpad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / Kpad), kk = (int)(i % Kpad);
+        float v = 0.f;
+        if (kk < K) v = w[(n / n_div) * s_hi + (n % n_div) * s_lo + kk * s_k];
+        Elt<T>::st(wp + i, v);
+    }
+}
+
+extern "C" int eg_pack_strided(int dtype, const float* w, void* wp, int N, int K, int Kpad, int n_div, long long s_hi, long long s_lo,
+                               long long s_k, eg_stream_t s) {
+    EG_REQUIRE(w && wp && N > 0 && K > 0 && Kpad >= K && n_div > 0, "eg_pack_strided: bad argument");
+    const long long total = (long long)N * Kpad;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (dtype == EG_F32) hipLaunchKernelGGL(pack_strided_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (float*)wp, N, K, Kpad, n_div, s_hi, s_lo, s_k);
+    else hipLaunchKernelGGL(pack_strided_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)wp, N, K, Kpad, n_div, s_hi, s_lo, s_k);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// igemm_tn : weight-gradient partial slabs
+// ------------------------------------------------------------------------------------------------
+struct TnParams {
+    const void* P;     // [M][N]
+    const void* src;   // [B,H,W,C]
+    float* slab;       // [nsplit][N][ntaps][C]
+    int B, H, W, C, N;
+    int lOH, lOW, M;
+    int TW, ntaps;
+    int sy, sx, dy0, dx0, up;
+    int rows_per_split;
+    int ntn, ntc;
+};
+
+// swizzle of a [32][BW] element tile in units of 16 elements
+__device__ __forceinline__ int tn_fsw(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <typename T, int BNT, int BCT>
+__global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams p) {
+    constexpr int VEC = Elt<T>::VEC;
+    constexpr int TM = BNT / 32, TN = BCT / 32;            // 2x2 waves
+    constexpr int CPR_P = BNT / VEC, CPR_S = BCT / VEC;    // 16-byte chunks per row
+    constexpr int LD_P = 32 * CPR_P / 256 > 0 ? 32 * CPR_P / 256 : 1;
+    constexpr int LD_S = 32 * CPR_S / 256 > 0 ? 32 * CPR_S / 256 : 1;
+    constexpr int MASK_P = BNT / 16 - 1, MASK_S = BCT / 16 - 1;
+    constexpr int STAGE = 32 * (BNT + BCT) * (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tn_i = blockIdx.x / p.ntc, tc_i = blockIdx.x % p.ntc;
+    const int n0 = tn_i * BNT, c0 = tc_i * BCT;
+    const int t = blockIdx.y, ty = t / p.TW, tx = t % p.TW;
+    const int mbeg = blockIdx.z * p.rows_per_split;
+    const int mend = min(p.M, mbeg + p.rows_per_split);
+    const int nk = (mend - mbeg + 31) / 32;
+    const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
+    const int HU = p.H << p.up, WU = p.W << p.up;
+    const T* __restrict__ P = reinterpret_cast<const T*>(p.P);
+    const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
+
+    uint4 rp[LD_P], rs[LD_S];
+    auto gload = [&](int kt) {
+        const int mb = mbeg + kt * 32;
+#pragma unroll
+        for (int i = 0; i < LD_P; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / CPR_P, ch = idx % CPR_P;
+            const int m = mb + row, n = n0 + ch * VEC;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < 32 && m < mend && n < p.N) v = *reinterpret_cast<const uint4*>(P + (size_t)m * p.N + n);
+            rp[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < LD_S; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / CPR_S, ch = idx % CPR_S;
+            const int m = mb + row, c = c0 + ch * VEC;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < 32 && m < mend && c < p.C) {
+                const int b = m >> (p.lOW + p.lOH);
+                const int iy = ((m >> p.lOW) & OHm) * p.sy + p.dy0 + ty;
+                const int ix = (m & OWm) * p.sx + p.dx0 + tx;
+                if (iy >= 0 && iy < HU && ix >= 0 && ix < WU) {
+                    const size_t pix = ((size_t)b * p.H + (iy >> p.up)) * p.W + (ix >> p.up);
+                    v = *reinterpret_cast<const uint4*>(src + pix * p.C + c);
+                }
+            }
+            rs[i] = v;
+        }
+    };
+    auto lstore = [&](int stage) {
+        T* sp = reinterpret_cast<T*>(smem + stage * STAGE);
+        T* ss = sp + 32 * BNT;
+#pragma unroll
+        for (int i = 0; i < LD_P; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / CPR_P, e = (idx % CPR_P) * VEC;
+            if (row < 32) *reinterpret_cast<uint4*>(sp + row * BNT + ((((e >> 4) ^ (tn_fsw(row) & MASK_P)) << 4) | (e & 15))) = rp[i];
+        }
+#pragma unroll
+        for (int i = 0; i < LD_S; ++i) {
+            const int idx = tid + 256 * i;
+            const int row = idx / CPR_S, e = (idx % CPR_S) * VEC;
+            if (row < 32) *reinterpret_cast<uint4*>(ss + row * BCT + ((((e >> 4) ^ (tn_fsw(row) & MASK_S)) << 4) | (e & 15))) = rs[i];
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (nk > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    const int g = lane >> 4, li = lane & 15;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+        const T* sp = reinterpret_cast<const T*>(smem + (kt & 1) * STAGE);
+        const T* ss = sp + 32 * BNT;
+        if constexpr (std::is_same<T, float>::value) {
+#pragma unroll
+            for (int kg = 0; kg < 8; ++kg) {
+                const int row = kg * 4 + g;
+                const int f = tn_fsw(row);
+                float av[TM], bv[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int blk = (wm * TM + i);
+                    av[i] = sp[row * BNT + (((blk ^ (f & MASK_P)) << 4) | li)];
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int blk = (wn * TN + j);
+                    bv[j] = ss[row * BCT + (((blk ^ (f & MASK_S)) << 4) | li)];
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // transposed LDS reads: each 16-lane group g fetches k rows 8g..8g+7 (two 4-row blocks) of a 16-column block
+            const int q = li >> 2, pc = li & 3;
+            uint4 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int blk = (wm * TM + i);
+                s16x4 lo, hi;
+                {
+                    const int row = 8 * g + q;
+                    lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sp + row * BNT + (((blk ^ (tn_fsw(row) & MASK_P)) << 4) | (pc * 4))));
+                }
+                {
+                    const int row = 8 * g + 4 + q;
+                    hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sp + row * BNT + (((blk ^ (tn_fsw(row) & MASK_P)) << 4) | (pc * 4))));
+                }
+                af[i] = make_uint4(((uint32_t)(uint16_t)lo[0]) | ((uint32_t)(uint16_t)lo[1] << 16), ((uint32_t)(uint16_t)lo[2]) | ((uint32_t)(uint16_t)lo[3] << 16),
+                                   ((uint32_t)(uint16_t)hi[0]) | ((uint32_t)(uint16_t)hi[1] << 16), ((uint32_t)(uint16_t)hi[2]) | ((uint32_t)(uint16_t)hi[3] << 16));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int blk = (wn * TN + j);
+                s16x4 lo, hi;
+                {
+                    const int row = 8 * g + q;
+                    lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ss + row * BCT + (((blk ^ (tn_fsw(row) & MASK_S)) << 4) | (pc * 4))));
+                }
+                {
+                    const int row = 8 * g + 4 + q;
+                    hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ss + row * BCT + (((blk ^ (tn_fsw(row) & MASK_S)) << 4) | (pc * 4))));
+                }
+                bfr[j] = make_uint4(((uint32_t)(uint16_t)lo[0]) | ((uint32_t)(uint16_t)lo[1] << 16), ((uint32_t)(uint16_t)lo[2]) | ((uint32_t)(uint16_t)lo[3] << 16),
+                                    ((uint32_t)(uint16_t)hi[0]) | ((uint32_t)(uint16_t)hi[1] << 16), ((uint32_t)(uint16_t)hi[2]) | ((uint32_t)(uint16_t)hi[3] << 16));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    float* slab = p.slab + (size_t)blockIdx.z * p.N * p.ntaps * p.C;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + (wm * TM + i) * 16 + g * 4 + r;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int c = c0 + (wn * TN + j) * 16 + li;
+                if (c < p.C) slab[((size_t)n * p.ntaps + t) * p.C + c] = acc[i][j][r];
+            }
+        }
+}
+
+static void tn_tiles(const eg_conv* c, int* bnt, int* bct) {
+    *bnt = c->Cout >= 128 ? 128 : (c->Cout > 32 ? 64 : 32);
+    *bct = c->Cin >= 128 ? 128 : (c->Cin > 32 ? 64 : 32);
+}
+
+static void tn_plan(const eg_conv* c, int* nsplit, int* rps) {
+    const int OH = conv_out_dim(c, c->H), OW = conv_out_dim(c, c->W);
+    const int M = c->B * OH * OW;
+    int bnt, bct;
+    tn_tiles(c, &bnt, &bct);
+    const long long base = (long long)cdiv(c->Cout, bnt) * cdiv(c->Cin, bct) * c->k * c->k;
+    long long want = base >= 768 ? 1 : (768 + base - 1) / base;
+    long long cap = M / 256 > 0 ? M / 256 : 1;
+    if (want > cap) want = cap;
+    if (want > 64) want = 64;
+    int r = round_up((int)((M + want - 1) / want), 32);
+    *rps = r;
+    *nsplit = cdiv(M, r);
+}
+
+extern "C" size_t eg_conv_wgrad_ws_bytes(const eg_conv* c, int dtype) {
+    (void)dtype;
+    int ns, rps;
+    tn_plan(c, &ns, &rps);
+    return (size_t)ns * c->Cout * c->k * c->k * c->Cin * sizeof(float);
+}
+
+template <typename T, int BNT, int BCT>
+static void launch_tn_cfg(TnParams& p, int nsplit, hipStream_t st) {
+    p.ntn = cdiv(p.N, BNT); p.ntc = cdiv(p.C, BCT);
+    dim3 grid(p.ntn * p.ntc, p.ntaps, nsplit);
+    const size_t lds = 2 * 32 * (BNT + BCT) * sizeof(T);
+    hipLaunchKernelGGL((igemm_tn_kernel<T, BNT, BCT>), grid, dim3(256), lds, st, p);
+}
+
+template <typename T>
+static void launch_tn(TnParams& p, int bnt, int bct, int nsplit, hipStream_t st) {
+#define EG_TN_CASE(a, b) if (bnt == a && bct == b) { launch_tn_cfg<T, a, b>(p, nsplit, st); return; }
+    EG_TN_CASE(128, 128) EG_TN_CASE(128, 64) EG_TN_CASE(128, 32)
+    EG_TN_CASE(64, 128) EG_TN_CASE(64, 64) EG_TN_CASE(64, 32)
+    EG_TN_CASE(32, 128) EG_TN_CASE(32, 64) EG_TN_CASE(32, 32)
+#undef EG_TN_CASE
+}
+
+extern "C" int eg_conv_wgrad(const eg_conv* c, int dtype, const void* X, const void* dY, float* slab, int* nsplit_out,
+                             eg_stream_t s) {
+    if (int e = check_conv(c, dtype, NEED_CIN | NEED_COUT)) return e;
+    EG_REQUIRE(X && dY && slab && nsplit_out, "eg_conv_wgrad: null pointer");
+    const int OH = conv_out_dim(c, c->H), OW = conv_out_dim(c, c->W);
+    TnParams p;
+    memset(&p, 0, sizeof(p));
+    p.P = dY; p.src = X; p.slab = slab;
+    p.B = c->B; p.H = c->H; p.W = c->W; p.C = c->Cin; p.N = c->Cout;
+    p.lOH = ilog2_exact(OH); p.lOW = ilog2_exact(OW); p.M = c->B * OH * OW;
+    p.TW = c->k; p.ntaps = c->k * c->k;
+    p.sy = p.sx = c->stride; p.dy0 = p.dx0 = -c->pad; p.up = c->up;
+    int ns, rps, bnt, bct;
+    tn_plan(c, &ns, &rps);
+    tn_tiles(c, &bnt, &bct);
+    p.rows_per_split = rps;
+    if (dtype == EG_F32) launch_tn<float>(p, bnt, bct, ns, (hipStream_t)s); else launch_tn<bf16_t>(p, bnt, bct, ns, (hipStream_t)s);
+    *nsplit_out = ns;
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// slab reduction into the master-layout gradient (+ spectral-norm correction)
+// ------------------------------------------------------------------------------------------------
+#define EG_SN_NPART 1024
+
+// one thread per (n, c): sums the splits for all taps and writes master[n][c][0..T)
+template <bool SN>
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int NS, int N, int C, int T,
+                                    float* __restrict__ out, int accumulate, const float* __restrict__ w_orig,
+                                    float* __restrict__ partials) {
+    __shared__ float sm[16];
+    const long long NC = (long long)N * C;
+    const size_t split_stride = (size_t)NS * T * C;
+    float dot = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < NC; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / C), c = (int)(i % C);
+        for (int t = 0; t < T; ++t) {
+            const size_t si = ((size_t)n * T + t) * C + c;
+            float a = 0.f;
+            for (int z = 0; z < nsplit; ++z) a += slab[z * split_stride + si];
+            const size_t oi = ((size_t)n * C + c) * T + t;
+            if (SN) {
+                out[oi] = a;
+                dot += a * w_orig[oi];
+            } else {
+                out[oi] = accumulate ? out[oi] + a : a;
+            }
+        }
+    }
+    if (SN) {
+        const float tot = block_sum(dot, sm);
+        if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+    }
+}
+
+__global__ void sn_grad_apply_kernel(const float* __restrict__ gtmp, const float* __restrict__ partials, int npart,
+                                     const float* __restrict__ sigma, const float* __restrict__ u, const float* __restrict__ v,
+                                     long long total, int Kdim, float* __restrict__ grad) {
+    __shared__ float sm[16];
+    float d = 0.f;
+    for (int i = threadIdx.x; i < npart; i += blockDim.x) d += partials[i];
+    const float dot = block_sum(d, sm);
+    const float sg = sigma[0];
+    const float inv = 1.f / sg, coef = dot / (sg * sg);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / Kdim), kk = (int)(i % Kdim);
+        grad[i] += gtmp[i] * inv - coef * u[n] * v[kk];
+    }
+}
+
+extern "C" int eg_wgrad_reduce(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad, int accumulate, eg_stream_t s) {
+    EG_REQUIRE(slab && grad && nsplit > 0 && n_rows <= n_slab, "eg_wgrad_reduce: bad argument");
+    const long long NC = (long long)n_rows * C;
+    const int blocks = (int)((NC + 255) / 256 > 2048 ? 2048 : (NC + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T, grad, accumulate,
+                       (const float*)nullptr, (float*)nullptr);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int eg_sn_partials(void) { return EG_SN_NPART; }
+
+extern "C" int eg_wgrad_reduce_sn(const eg_conv* c, const float* slab, int nsplit, const float* w_orig, const float* sigma,
+                                  const float* u, const float* v, float* gtmp, float* partials, float* grad, eg_stream_t s) {
+    EG_REQUIRE(c && slab && w_orig && sigma && u && v && gtmp && partials && grad && nsplit > 0, "eg_wgrad_reduce_sn: bad argument");
+    const long long NC = (long long)c->Cout * c->Cin;
+    const int blocks = (int)((NC + 255) / 256 > EG_SN_NPART ? EG_SN_NPART : (NC + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)s, slab, nsplit, c->Cout, c->Cout, c->Cin,
+                       c->k * c->k, gtmp, 0, w_orig, partials);
+    const long long total = NC * c->k * c->k;
+    const int blocks2 = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    hipLaunchKernelGGL(sn_grad_apply_kernel, dim3(blocks2), dim3(256), 0, (hipStream_t)s, gtmp, partials, blocks, sigma, u, v, total,
+                       c->Cin * c->k * c->k, grad);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bias gradient: column sums of a [rows][N] tensor (two deterministic stages)
+// ------------------------------------------------------------------------------------------------
+#define EG_BG_RPB 512   // rows per block
+
+template <typename T>
+__global__ void colsum_partial_kernel(const T* __restrict__ x, int rows, int N, float* __restrict__ partials) {
+    __shared__ float sm[4][64];
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * EG_BG_RPB, r1 = min(rows, r0 + EG_BG_RPB);
+    float a = 0.f;
+    if (col < N)
+        for (int r = r0 + rl; r < r1; r += 4) a += Elt<T>::ld(x + (size_t)r * N + col);
+    sm[rl][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (rl == 0 && col < N) partials[(size_t)blockIdx.y * N + col] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ partials, int nrb, int N, int nb, float* __restrict__ gb) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nb) return;
+    float a = 0.f;
+    for (int n = j; n < N; n += nb)
+        for (int r = 0; r < nrb; ++r) a += partials[(size_t)r * N + n];
+    gb[j] += a;
+}
+
+extern "C" size_t eg_bias_grad_ws_floats(int rows, int N) { return (size_t)cdiv(rows, EG_BG_RPB) * N; }
+
+extern "C" int eg_bias_grad(int dtype, const void* dY, int rows, int N, int bias_mod, float* partials, float* gb, eg_stream_t s) {
+    EG_REQUIRE(dY && partials && gb && rows > 0 && N > 0, "eg_bias_grad: bad argument");
+    const int nrb = cdiv(rows, EG_BG_RPB);
+    dim3 grid(cdiv(N, 64), nrb);
+    if (dtype == EG_F32) hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)dY, rows, N, partials);
+    else hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)dY, rows, N, partials);
+    const int nb = bias_mod > 0 ? bias_mod : N;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, (hipStream_t)s, partials, nrb, N, nb, gb);
+    EG_LAUNCH_CHECK();
+    return 0;
+}

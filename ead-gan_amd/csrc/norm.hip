@@ -1,0 +1,201 @@
+// BatchNorm2d (training mode) over NHWC activations viewed as [M = B*H*W][C].
+// replaces nn.BatchNorm2d forward/backward: celebA/EAD-GAN_celebA.py:79,83,87; MNIST/EAD-GAN_rpqmnxy.py:80,83,87,145
+// (eps is a parameter: the MNIST nets pass 0.8); dSprites/rp.py:130-138.
+// Statistics are deterministic: per-row-block (count, mean, M2) partials combined with Chan's formula in fp64.
+#include "eg_common.h"
+
+#define BN_RPB 256   // rows per block in the partial kernels
+
+template <typename T>
+__global__ void bn_stats_partial_kernel(const T* __restrict__ x, int M, int C, float* __restrict__ partial) {
+    __shared__ float sm[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * BN_RPB, r1 = min(M, r0 + BN_RPB);
+    const int cnt = r1 - r0;
+    float s = 0.f;
+    if (col < C)
+        for (int r = r0 + rl; r < r1; r += 4) s += Elt<T>::ld(x + (size_t)r * C + col);
+    sm[rl][cl] = s;
+    __syncthreads();
+    const float mean = (sm[0][cl] + sm[1][cl] + sm[2][cl] + sm[3][cl]) / (float)cnt;
+    __syncthreads();
+    float q = 0.f;
+    if (col < C)
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const float d = Elt<T>::ld(x + (size_t)r * C + col) - mean;
+            q += d * d;
+        }
+    sm[rl][cl] = q;
+    __syncthreads();
+    if (rl == 0 && col < C) {
+        float* o = partial + (size_t)blockIdx.y * 3 * C;
+        o[col] = (float)cnt;
+        o[C + col] = mean;
+        o[2 * C + col] = sm[0][cl] + sm[1][cl] + sm[2][cl] + sm[3][cl];
+    }
+}
+
+__global__ void bn_stats_final_kernel(const float* __restrict__ partial, int nrb, int C, int M, float eps, float momentum,
+                                      float* running_mean, float* running_var, long long* nbt, float* save_mean, float* save_invstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && nbt) nbt[0] += 1;
+    if (c >= C) return;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int r = 0; r < nrb; ++r) {
+        const float* o = partial + (size_t)r * 3 * C;
+        const double nb = o[c], mb = o[C + c], qb = o[2 * C + c];
+        const double tot = n + nb, delta = mb - mean;
+        mean += delta * nb / tot;
+        m2 += qb + delta * delta * n * nb / tot;
+        n = tot;
+    }
+    const double var = m2 / (double)M;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        const double unb = M > 1 ? m2 / (double)(M - 1) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, size_t total, int C, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd, int act,
+                                float slope) {
+    constexpr int VEC = Elt<T>::VEC;
+    const size_t nchunk = total / VEC;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunk; i += (size_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)((i * VEC) % C);
+        uint4 v = *reinterpret_cast<const uint4*>(x + i * VEC);
+        T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = c0 + j;
+            float f = (Elt<T>::ld(e + j) - mean[c]) * invstd[c] * gamma[c] + beta[c];
+            Elt<T>::st(e + j, eg_act(f, act, slope));
+        }
+        *reinterpret_cast<uint4*>(y + i * VEC) = v;
+    }
+}
+
+extern "C" size_t eg_bn_ws_floats(int M, int C) { return (size_t)cdiv(M, BN_RPB) * 3 * C; }
+
+extern "C" int eg_bn_fwd_train(int dtype, const void* x, void* y, int M, int C, const float* gamma, const float* beta, float eps,
+                               float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
+                               float* save_mean, float* save_invstd, float* ws, int act, float slope, eg_stream_t s) {
+    EG_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && ws && M > 0 && C > 0, "eg_bn_fwd_train: bad argument");
+    EG_REQUIRE(C % (dtype == EG_F32 ? 4 : 8) == 0, "eg_bn_fwd_train: C must be a multiple of the 16-byte vector width");
+    const int nrb = cdiv(M, BN_RPB);
+    dim3 g1(cdiv(C, 64), nrb);
+    hipStream_t st = (hipStream_t)s;
+    if (dtype == EG_F32) hipLaunchKernelGGL(bn_stats_partial_kernel<float>, g1, dim3(256), 0, st, (const float*)x, M, C, ws);
+    else hipLaunchKernelGGL(bn_stats_partial_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)x, M, C, ws);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, ws, nrb, C, M, eps, momentum, running_mean, running_var,
+                       num_batches_tracked, save_mean, save_invstd);
+    const size_t total = (size_t)M * C;
+    const size_t nchunk = total / (dtype == EG_F32 ? 4 : 8);
+    const int blocks = (int)((nchunk + 255) / 256 > 4096 ? 4096 : (nchunk + 255) / 256);
+    if (dtype == EG_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, total, C, gamma, beta, save_mean, save_invstd, act, slope);
+    else hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, total, C, gamma, beta, save_mean, save_invstd, act, slope);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- backward -----------------------------------------------------------------------------------
+__device__ __forceinline__ float pre_act_grad(float y, int act, float slope) {
+    switch (act) {
+        case EG_ACT_LRELU: return y > 0.f ? 1.f : slope;
+        case EG_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        default: return 1.f;
+    }
+}
+
+template <typename T>
+__global__ void bn_bwd_partial_kernel(const T* __restrict__ z, const T* __restrict__ da, int M, int C, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                      int act, float slope, float* __restrict__ partial) {
+    __shared__ float sm[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const int r0 = blockIdx.y * BN_RPB, r1 = min(M, r0 + BN_RPB);
+    float s1 = 0.f, s2 = 0.f;
+    if (col < C) {
+        const float mu = mean[col], is = invstd[col], g = gamma[col], b = beta[col];
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const size_t o = (size_t)r * C + col;
+            const float xh = (Elt<T>::ld(z + o) - mu) * is;
+            const float dy = Elt<T>::ld(da + o) * pre_act_grad(xh * g + b, act, slope);
+            s1 += dy;
+            s2 += dy * xh;
+        }
+    }
+    sm[0][rl][cl] = s1;
+    sm[1][rl][cl] = s2;
+    __syncthreads();
+    if (rl == 0 && col < C) {
+        float* o = partial + (size_t)blockIdx.y * 2 * C;
+        o[col] = sm[0][0][cl] + sm[0][1][cl] + sm[0][2][cl] + sm[0][3][cl];
+        o[C + col] = sm[1][0][cl] + sm[1][1][cl] + sm[1][2][cl] + sm[1][3][cl];
+    }
+}
+
+__global__ void bn_bwd_final_kernel(const float* __restrict__ partial, int nrb, int C, float* sums, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < nrb; ++r) {
+        s1 += partial[(size_t)r * 2 * C + c];
+        s2 += partial[(size_t)r * 2 * C + C + c];
+    }
+    sums[c] = s1;
+    sums[C + c] = s2;
+    if (dbeta) dbeta[c] += s1;
+    if (dgamma) dgamma[c] += s2;
+}
+
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ z, const T* __restrict__ da, T* __restrict__ dz, size_t total, int C, int M,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ sums, int act, float slope) {
+    constexpr int VEC = Elt<T>::VEC;
+    const size_t nchunk = total / VEC;
+    const float invM = 1.f / (float)M;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunk; i += (size_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)((i * VEC) % C);
+        uint4 vz = *reinterpret_cast<const uint4*>(z + i * VEC);
+        uint4 vd = *reinterpret_cast<const uint4*>(da + i * VEC);
+        const T* ez = reinterpret_cast<const T*>(&vz);
+        T* ed = reinterpret_cast<T*>(&vd);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = c0 + j;
+            const float is = invstd[c], g = gamma[c];
+            const float xh = (Elt<T>::ld(ez + j) - mean[c]) * is;
+            const float dy = Elt<T>::ld(ed + j) * pre_act_grad(xh * g + beta[c], act, slope);
+            Elt<T>::st(ed + j, g * is * (dy - sums[c] * invM - xh * sums[C + c] * invM));
+        }
+        *reinterpret_cast<uint4*>(dz + i * VEC) = vd;
+    }
+}
+
+// ws: >= max(eg_bn_ws_floats(M,C), ...) floats; sums: 2*C floats
+extern "C" int eg_bn_bwd(int dtype, const void* z, const void* da, void* dz, int M, int C, const float* gamma, const float* beta,
+                         const float* save_mean, const float* save_invstd, int act, float slope, float* dgamma, float* dbeta,
+                         float* sums, float* ws, eg_stream_t s) {
+    EG_REQUIRE(z && da && dz && gamma && beta && save_mean && save_invstd && sums && ws, "eg_bn_bwd: null pointer");
+    const int nrb = cdiv(M, BN_RPB);
+    dim3 g1(cdiv(C, 64), nrb);
+    hipStream_t st = (hipStream_t)s;
+    if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_partial_kernel<float>, g1, dim3(256), 0, st, (const float*)z, (const float*)da, M, C, gamma, beta, save_mean, save_invstd, act, slope, ws);
+    else hipLaunchKernelGGL(bn_bwd_partial_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)da, M, C, gamma, beta, save_mean, save_invstd, act, slope, ws);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, ws, nrb, C, sums, dgamma, dbeta);
+    const size_t total = (size_t)M * C;
+    const size_t nchunk = total / (dtype == EG_F32 ? 4 : 8);
+    const int blocks = (int)((nchunk + 255) / 256 > 4096 ? 4096 : (nchunk + 255) / 256);
+    if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)z, (const float*)da, (float*)dz, total, C, M, gamma, beta, save_mean, save_invstd, sums, act, slope);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)da, (bf16_t*)dz, total, C, M, gamma, beta, save_mean, save_invstd, sums, act, slope);
+    EG_LAUNCH_CHECK();
+    return 0;
+}

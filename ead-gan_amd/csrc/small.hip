@@ -1,0 +1,382 @@
+// Skinny ends of the networks, where the GEMM view has K or N of 1..48 and the work is HBM/LDS bound:
+//   * image-side convolution (NCHW fp32 image with 1..4 channels  ->  NHWC dtype-T features) and its
+//     weight gradient:  first Discriminator/Encoder conv (celebA/EAD-GAN_celebA.py:110, dSprites/rp.py:95,
+//     MNIST/EAD-GAN_rpqmnxy.py:107,143) and the input-gradient of the Generator's last ConvTranspose (:90);
+//   * small-N dense heads (celebA/EAD-GAN_celebA.py:122 1024x4x4 -> 19; MNIST/dSprites Linear heads).
+// These use VALU FMAs with LDS-staged operands; MFMA tiles would idle >80 % of their lanes here.
+#include "eg_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// image-side convolution forward
+// ------------------------------------------------------------------------------------------------
+struct ImgConvP {
+    const float* img;    // [B][CI][H][W]
+    const float* w;      // master [N][CI][k][k] fp32
+    void* out;           // [B][OH][OW][N] dtype T
+    const float* bias;
+    const float* sigma;
+    const void* mask;    // same layout/dtype as out (activation output) or null
+    int B, CI, H, W, N, k, stride, pad, OH, OW;
+    int act; float slope; int mask_act; float mask_slope;
+    int rows_per_block;
+};
+
+template <typename T, int CPT>
+__global__ __launch_bounds__(256) void conv_img_fwd_kernel(const ImgConvP p) {
+    extern __shared__ __attribute__((aligned(16))) float sm_f[];
+    const int NT = p.CI * p.k * p.k;
+    float* wl = sm_f;                       // [NT][N]
+    float* il = sm_f + NT * p.N;            // [CI][k][WP] one strip of input rows
+    const int WP = p.W + 2 * p.pad;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < NT * p.N; i += 256) {
+        const int n = i / NT, t = i % NT;
+        wl[t * p.N + n] = p.w[i];
+    }
+    const int groups = 256 / p.OW;
+    const int ox = tid % p.OW, cg = tid / p.OW;
+    const int nb = cg * CPT;
+    const int b = blockIdx.y;
+    const float inv_sigma = p.sigma ? 1.f / p.sigma[0] : 1.f;
+    const T* __restrict__ mask = reinterpret_cast<const T*>(p.mask);
+    T* __restrict__ out = reinterpret_cast<T*>(p.out);
+    for (int ry = 0; ry < p.rows_per_block; ++ry) {
+        const int oy = blockIdx.x * p.rows_per_block + ry;
+        if (oy >= p.OH) break;
+        __syncthreads();
+        for (int i = tid; i < p.CI * p.k * WP; i += 256) {
+            const int xx = i % WP, r = (i / WP) % p.k, ci = i / (WP * p.k);
+            const int iy = oy * p.stride - p.pad + r, ix = xx - p.pad;
+            float v = 0.f;
+            if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) v = p.img[(((size_t)b * p.CI + ci) * p.H + iy) * p.W + ix];
+            il[i] = v;
+        }
+        __syncthreads();
+        if (cg < groups && nb < p.N) {
+            float acc[CPT];
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
+            for (int ci = 0; ci < p.CI; ++ci)
+                for (int kh = 0; kh < p.k; ++kh)
+                    for (int kw = 0; kw < p.k; ++kw) {
+                        const float xv = il[(ci * p.k + kh) * WP + ox * p.stride + kw];
+                        const float* wr = wl + ((ci * p.k + kh) * p.k + kw) * p.N + nb;
+#pragma unroll
+                        for (int j = 0; j < CPT; ++j) acc[j] += xv * wr[j];
+                    }
+            const size_t o = (((size_t)b * p.OH + oy) * p.OW + ox) * p.N + nb;
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                float v = acc[j] * inv_sigma;
+                if (p.bias) v += p.bias[nb + j];
+                v = eg_act(v, p.act, p.slope);
+                if (mask) v *= eg_act_grad_from_out(Elt<T>::ld(mask + o + j), p.mask_act, p.mask_slope);
+                Elt<T>::st(out + o + j, v);
+            }
+        }
+    }
+}
+
+/* image conv forward: out[B,OH,OW,N] = act(conv(img, w)/sigma + bias) [* act'(mask)] */
+extern "C" int eg_conv_img_fwd(int dtype, const float* img, const float* w_master, void* out, int B, int CI, int H, int W, int N, int k,
+                               int stride, int pad, const eg_epilogue* ep, eg_stream_t s) {
+    EG_REQUIRE(img && w_master && out && CI >= 1 && CI <= 4, "eg_conv_img_fwd: bad argument");
+    ImgConvP p;
+    memset(&p, 0, sizeof(p));
+    p.img = img; p.w = w_master; p.out = out;
+    p.B = B; p.CI = CI; p.H = H; p.W = W; p.N = N; p.k = k; p.stride = stride; p.pad = pad;
+    p.OH = (H + 2 * pad - k) / stride + 1; p.OW = (W + 2 * pad - k) / stride + 1;
+    EG_REQUIRE(p.OW <= 256 && 256 % p.OW == 0, "eg_conv_img_fwd: OW must divide 256");
+    if (ep) { p.bias = ep->bias; p.sigma = ep->sigma; p.act = ep->act; p.slope = ep->slope; p.mask = ep->mask; p.mask_act = ep->mask_act; p.mask_slope = ep->mask_slope; }
+    const int groups = 256 / p.OW;
+    EG_REQUIRE(N % groups == 0 || N < groups, "eg_conv_img_fwd: N=%d not divisible by %d thread groups", N, groups);
+    const int cpt = N >= groups ? N / groups : 1;
+    p.rows_per_block = p.OH >= 4 ? 4 : p.OH;
+    dim3 grid(cdiv(p.OH, p.rows_per_block), B);
+    const size_t lds = (size_t)(CI * k * k * N + CI * k * (W + 2 * pad)) * sizeof(float);
+    hipStream_t st = (hipStream_t)s;
+#define EG_CASE(T_, C_) hipLaunchKernelGGL((conv_img_fwd_kernel<T_, C_>), grid, dim3(256), lds, st, p)
+#define EG_DISPATCH(C_) do { if (dtype == EG_F32) EG_CASE(float, C_); else EG_CASE(bf16_t, C_); } while (0)
+    switch (cpt) {
+        case 1: EG_DISPATCH(1); break;
+        case 2: EG_DISPATCH(2); break;
+        case 4: EG_DISPATCH(4); break;
+        case 8: EG_DISPATCH(8); break;
+        case 16: EG_DISPATCH(16); break;
+        default: EG_FAIL(-1, "eg_conv_img_fwd: unsupported channels-per-thread %d", cpt);
+    }
+#undef EG_DISPATCH
+#undef EG_CASE
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// image-side weight gradient: slab[b][n][ci][kh][kw] = sum_{oy,ox} dz[b,oy,ox,n] * img[b,ci,oy*s-p+kh,ox*s-p+kw]
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MAXT>
+__global__ __launch_bounds__(256) void conv_img_wgrad_kernel(const T* __restrict__ dz, const float* __restrict__ img, float* __restrict__ slab,
+                                                             int CI, int H, int W, int N, int k, int stride, int pad, int OH, int OW) {
+    extern __shared__ __attribute__((aligned(16))) float il[];   // [CI][H+2p][W+2p]
+    const int HP = H + 2 * pad, WP = W + 2 * pad;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < CI * HP * WP; i += 256) {
+        const int xx = i % WP, yy = (i / WP) % HP, ci = i / (WP * HP);
+        const int iy = yy - pad, ix = xx - pad;
+        il[i] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? img[(((size_t)b * CI + ci) * H + iy) * W + ix] : 0.f;
+    }
+    __syncthreads();
+    const int NT = CI * k * k;
+    const int G = 256 / N;                 // tap groups (N <= 256, N divides 256)
+    const int n = tid % N, tg = tid / N;
+    int toff[MAXT];
+    float acc[MAXT];
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+        const int t = tg + j * G;
+        acc[j] = 0.f;
+        if (t < NT) {
+            const int kw = t % k, kh = (t / k) % k, ci = t / (k * k);
+            toff[j] = (ci * HP + kh) * WP + kw;
+        } else
+            toff[j] = -1;
+    }
+    if (tg < G) {
+        const T* dzb = dz + (size_t)b * OH * OW * N + n;
+        for (int oy = 0; oy < OH; ++oy)
+            for (int ox = 0; ox < OW; ++ox) {
+                const float g = Elt<T>::ld(dzb + (size_t)(oy * OW + ox) * N);
+                const int base = oy * stride * WP + ox * stride;
+#pragma unroll
+                for (int j = 0; j < MAXT; ++j)
+                    if (toff[j] >= 0) acc[j] += g * il[base + toff[j]];
+            }
+        float* o = slab + ((size_t)b * N + n) * NT;
+#pragma unroll
+        for (int j = 0; j < MAXT; ++j) {
+            const int t = tg + j * G;
+            if (t < NT) o[t] = acc[j];
+        }
+    }
+}
+
+extern "C" size_t eg_conv_img_wgrad_ws_bytes(int B, int CI, int N, int k) { return (size_t)B * N * CI * k * k * sizeof(float); }
+
+extern "C" int eg_conv_img_wgrad(int dtype, const void* dz, const float* img, float* slab, int B, int CI, int H, int W, int N, int k,
+                                 int stride, int pad, eg_stream_t s) {
+    EG_REQUIRE(dz && img && slab && N <= 256 && 256 % N == 0, "eg_conv_img_wgrad: N must divide 256");
+    const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+    const int NT = CI * k * k, G = 256 / N;
+    const int maxt = cdiv(NT, G);
+    const size_t lds = (size_t)CI * (H + 2 * pad) * (W + 2 * pad) * sizeof(float);
+    EG_REQUIRE(lds <= 64 * 1024, "eg_conv_img_wgrad: image does not fit LDS");
+    hipStream_t st = (hipStream_t)s;
+#define EG_CASE(T_, M_) hipLaunchKernelGGL((conv_img_wgrad_kernel<T_, M_>), dim3(B), dim3(256), lds, st, (const T_*)dz, img, slab, CI, H, W, N, k, stride, pad, OH, OW)
+#define EG_DISPATCH(M_) do { if (dtype == EG_F32) EG_CASE(float, M_); else EG_CASE(bf16_t, M_); } while (0)
+    if (maxt <= 1) EG_DISPATCH(1);
+    else if (maxt <= 2) EG_DISPATCH(2);
+    else if (maxt <= 3) EG_DISPATCH(3);
+    else if (maxt <= 6) EG_DISPATCH(6);
+    else if (maxt <= 12) EG_DISPATCH(12);
+    else if (maxt <= 24) EG_DISPATCH(24);
+    else EG_FAIL(-1, "eg_conv_img_wgrad: too many taps per thread (%d)", maxt);
+#undef EG_DISPATCH
+#undef EG_CASE
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// flat slab reduction (master order already): out (+)= sum_z slab[z][i]; SN variant writes gtmp + <G,W> partials
+template <bool SN>
+__global__ void flat_reduce_kernel(const float* __restrict__ slab, int nslab, size_t total, float* __restrict__ out, int accumulate,
+                                   const float* __restrict__ w_orig, float* __restrict__ partials) {
+    __shared__ float sm[16];
+    float dot = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int z = 0; z < nslab; ++z) a += slab[(size_t)z * total + i];
+        if (SN) { out[i] = a; dot += a * w_orig[i]; }
+        else out[i] = accumulate ? out[i] + a : a;
+    }
+    if (SN) {
+        const float tot = block_sum(dot, sm);
+        if (threadIdx.x == 0) partials[blockIdx.x] = tot;
+    }
+}
+
+__global__ void sn_grad_apply_kernel2(const float* __restrict__ gtmp, const float* __restrict__ partials, int npart,
+                                      const float* __restrict__ sigma, const float* __restrict__ u, const float* __restrict__ v,
+                                      long long total, int Kdim, float* __restrict__ grad) {
+    __shared__ float sm[16];
+    float d = 0.f;
+    for (int i = threadIdx.x; i < npart; i += blockDim.x) d += partials[i];
+    const float dot = block_sum(d, sm);
+    const float sg = sigma[0];
+    const float inv = 1.f / sg, coef = dot / (sg * sg);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / Kdim), kk = (int)(i % Kdim);
+        grad[i] += gtmp[i] * inv - coef * u[n] * v[kk];
+    }
+}
+
+// per-channel sum of an NCHW fp32 tensor with few channels: gb[c] += sum_{b,hw} x[b][c][hw]
+__global__ void bias_grad_nchw_kernel(const float* __restrict__ x, int B, int C, int HW, float* __restrict__ gb) {
+    __shared__ float sm[16];
+    const int c = blockIdx.x;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* p = x + ((size_t)b * C + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) a += p[i];
+    }
+    const float tot = block_sum(a, sm);
+    if (threadIdx.x == 0) gb[c] += tot;
+}
+extern "C" int eg_bias_grad_nchw(const float* x, int B, int C, int HW, float* gb, eg_stream_t s) {
+    EG_REQUIRE(x && gb, "eg_bias_grad_nchw: null pointer");
+    hipLaunchKernelGGL(bias_grad_nchw_kernel, dim3(C), dim3(1024), 0, (hipStream_t)s, x, B, C, HW, gb);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+/* grad (+)= sum_z slab[z]  over `total` floats in master order */
+extern "C" int eg_flat_reduce(const float* slab, int nslab, size_t total, float* grad, int accumulate, eg_stream_t s) {
+    EG_REQUIRE(slab && grad && nslab > 0, "eg_flat_reduce: bad argument");
+    const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+    hipLaunchKernelGGL(flat_reduce_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)s, slab, nslab, total, grad, accumulate, (const float*)nullptr, (float*)nullptr);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+/* spectral-norm variant: rows = Cout, Kdim = elements per row; partials >= 1024 floats */
+extern "C" int eg_flat_reduce_sn(const float* slab, int nslab, int rows, int Kdim, const float* w_orig, const float* sigma, const float* u,
+                                 const float* v, float* gtmp, float* partials, float* grad, eg_stream_t s) {
+    EG_REQUIRE(slab && w_orig && sigma && u && v && gtmp && partials && grad && nslab > 0, "eg_flat_reduce_sn: bad argument");
+    const size_t total = (size_t)rows * Kdim;
+    const int blocks = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+    hipLaunchKernelGGL(flat_reduce_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)s, slab, nslab, total, gtmp, 0, w_orig, partials);
+    hipLaunchKernelGGL(sn_grad_apply_kernel2, dim3(blocks), dim3(256), 0, (hipStream_t)s, gtmp, partials, blocks, sigma, u, v, (long long)total, Kdim, grad);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small-N dense head:  y[b][n] = sum_k x[b][k] * Wp[n][k] (+ bias[n]);  x dtype T [B][K], Wp dtype T [N][Kpad]
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void dense_small_fwd_kernel(const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ bias,
+                                                              float* __restrict__ y, int K, int Kpad, int N) {
+    constexpr int VEC = Elt<T>::VEC;
+    __shared__ float sm[16];
+    const int b = blockIdx.x;
+    const T* xr = x + (size_t)b * K;
+    for (int n = 0; n < N; ++n) {
+        const T* wr = wp + (size_t)n * Kpad;
+        float a = 0.f;
+        for (int k0 = threadIdx.x * VEC; k0 < K; k0 += 256 * VEC) {
+            const uint4 xv = *reinterpret_cast<const uint4*>(xr + k0);
+            const uint4 wv = *reinterpret_cast<const uint4*>(wr + k0);
+            const T* xe = reinterpret_cast<const T*>(&xv);
+            const T* we = reinterpret_cast<const T*>(&wv);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) a += Elt<T>::ld(xe + j) * Elt<T>::ld(we + j);
+        }
+        const float tot = block_sum(a, sm);
+        if (threadIdx.x == 0) y[(size_t)b * N + n] = tot + (bias ? bias[n] : 0.f);
+    }
+}
+
+// dx[b][k] = (sum_n dy[b][n] * Wp[n][k]) * act'(mask[b][k])
+template <typename T>
+__global__ __launch_bounds__(256) void dense_small_bwd_kernel(const float* __restrict__ dy, const T* __restrict__ wp, const T* __restrict__ mask,
+                                                              T* __restrict__ dx, int K, int Kpad, int N, int mask_act, float mask_slope) {
+    constexpr int VEC = Elt<T>::VEC;
+    __shared__ float dl[64];
+    const int b = blockIdx.x;
+    if (threadIdx.x < N) dl[threadIdx.x] = dy[(size_t)b * N + threadIdx.x];
+    __syncthreads();
+    for (int k0 = threadIdx.x * VEC; k0 < K; k0 += 256 * VEC) {
+        float a[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) a[j] = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const uint4 wv = *reinterpret_cast<const uint4*>(wp + (size_t)n * Kpad + k0);
+            const T* we = reinterpret_cast<const T*>(&wv);
+            const float g = dl[n];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) a[j] += g * Elt<T>::ld(we + j);
+        }
+        uint4 ov;
+        T* oe = reinterpret_cast<T*>(&ov);
+        if (mask) {
+            const uint4 mv = *reinterpret_cast<const uint4*>(mask + (size_t)b * K + k0);
+            const T* me = reinterpret_cast<const T*>(&mv);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) a[j] *= eg_act_grad_from_out(Elt<T>::ld(me + j), mask_act, mask_slope);
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) Elt<T>::st(oe + j, a[j]);
+        *reinterpret_cast<uint4*>(dx + (size_t)b * K + k0) = ov;
+    }
+}
+
+// gw_master[(n*Cin + ci)*T + t] += sum_b dy[b][n] * x[b][k],  k = t*Cin + ci
+template <typename T>
+__global__ __launch_bounds__(256) void dense_small_wgrad_kernel(const float* __restrict__ dy, const T* __restrict__ x, float* __restrict__ gw,
+                                                                int B, int K, int N, int Cin, int Ttaps) {
+    extern __shared__ float dl[];   // [B][N]
+    for (int i = threadIdx.x; i < B * N; i += 256) dl[i] = dy[i];
+    __syncthreads();
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    float acc[32];
+#pragma unroll
+    for (int n = 0; n < 32; ++n) acc[n] = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float xv = Elt<T>::ld(x + (size_t)b * K + k);
+#pragma unroll
+        for (int n = 0; n < 32; ++n)
+            if (n < N) acc[n] += xv * dl[b * N + n];
+    }
+    const int t = k / Cin, ci = k % Cin;
+#pragma unroll
+    for (int n = 0; n < 32; ++n)
+        if (n < N) gw[((size_t)n * Cin + ci) * Ttaps + t] += acc[n];
+}
+
+extern "C" int eg_dense_small_fwd(int dtype, const void* x, const void* wp, const float* bias, float* y, int B, int K, int Kpad, int N,
+                                  eg_stream_t s) {
+    EG_REQUIRE(x && wp && y && K % (dtype == EG_F32 ? 4 : 8) == 0, "eg_dense_small_fwd: bad argument");
+    if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_fwd_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)s, (const float*)x, (const float*)wp, bias, y, K, Kpad, N);
+    else hipLaunchKernelGGL(dense_small_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)wp, bias, y, K, Kpad, N);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int eg_dense_small_bwd(int dtype, const float* dy, const void* wp, const void* mask, void* dx, int B, int K, int Kpad, int N,
+                                  int mask_act, float mask_slope, eg_stream_t s) {
+    EG_REQUIRE(dy && wp && dx && N <= 64 && K % (dtype == EG_F32 ? 4 : 8) == 0, "eg_dense_small_bwd: bad argument");
+    if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_bwd_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)s, dy, (const float*)wp, (const float*)mask, (float*)dx, K, Kpad, N, mask_act, mask_slope);
+    else hipLaunchKernelGGL(dense_small_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)s, dy, (const bf16_t*)wp, (const bf16_t*)mask, (bf16_t*)dx, K, Kpad, N, mask_act, mask_slope);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+/* gw (master [N][Cin][taps], accumulate) and gb[n] += sum_b dy[b][n] */
+__global__ void dense_small_bgrad_kernel(const float* dy, float* gb, int B, int N) {
+    const int n = threadIdx.x;
+    if (n >= N) return;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += dy[(size_t)b * N + n];
+    gb[n] += a;
+}
+
+extern "C" int eg_dense_small_wgrad(int dtype, const float* dy, const void* x, float* gw, float* gb, int B, int K, int N, int Cin, int taps,
+                                    eg_stream_t s) {
+    EG_REQUIRE(dy && x && gw && N <= 32 && (size_t)B * N * 4 <= 64 * 1024 && Cin * taps == K, "eg_dense_small_wgrad: bad argument (N<=32)");
+    const size_t lds = (size_t)B * N * sizeof(float);
+    if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_wgrad_kernel<float>, dim3(cdiv(K, 256)), dim3(256), lds, (hipStream_t)s, dy, (const float*)x, gw, B, K, N, Cin, taps);
+    else hipLaunchKernelGGL(dense_small_wgrad_kernel<bf16_t>, dim3(cdiv(K, 256)), dim3(256), lds, (hipStream_t)s, dy, (const bf16_t*)x, gw, B, K, N, Cin, taps);
+    if (gb) hipLaunchKernelGGL(dense_small_bgrad_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, dy, gb, B, N);
+    EG_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,108 @@
+"""Host-side building blocks shared by the per-dataset models: flat parameter arenas, the shared device
+workspace, and conv-layer records (geometry + packed weight panels) over the C ABI in :mod:`ops`."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .ops import EG_BF16, EG_F32
+
+
+def parse_dtype(dtype) -> int:
+    if dtype in (EG_F32, "f32", "fp32", "float32", torch.float32):
+        return EG_F32
+    if dtype in (EG_BF16, "bf16", "bfloat16", torch.bfloat16):
+        return EG_BF16
+    raise ValueError(f"unsupported compute dtype {dtype!r} (use 'f32' or 'bf16')")
+
+
+class Arena:
+    """All parameters of a module re-homed into ONE flat fp32 tensor (reference ``.parameters()`` order)
+    with a matching flat gradient tensor: one fused Adam launch per optimizer, one all-reduce per pass."""
+
+    def __init__(self, module: torch.nn.Module):
+        params = list(module.parameters())
+        dev = params[0].device
+        n = sum(p.numel() for p in params)
+        self.flat = torch.empty(n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.slices = {}
+        off = 0
+        for name, p in module.named_parameters():
+            k = p.numel()
+            self.flat[off:off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off:off + k].view(p.shape)
+            p.grad = self.grad[off:off + k].view(p.shape)
+            self.slices[name] = (off, k)
+            off += k
+        self.numel = n
+
+    def grad_of(self, name, arena_grad=None):
+        off, k = self.slices[name]
+        return (self.grad if arena_grad is None else arena_grad)[off:off + k]
+
+
+class Workspace:
+    """Scratch shared by every engine on a device (calls are stream-ordered, so one copy suffices).
+    Grown only while engines are being built -- never inside a training step."""
+
+    _per_device = {}
+
+    def __init__(self, device):
+        self.device = device
+        self.slab = torch.empty(0, device=device, dtype=torch.float32)
+        self.gtmp = torch.empty(0, device=device, dtype=torch.float32)
+        self.small = torch.empty(0, device=device, dtype=torch.float32)
+        self.partials = torch.empty(max(2048, ops.sn_partials()), device=device, dtype=torch.float32)
+        self.sums = torch.empty(0, device=device, dtype=torch.float32)
+
+    @classmethod
+    def get(cls, device) -> "Workspace":
+        key = (device.type, device.index)
+        if key not in cls._per_device:
+            cls._per_device[key] = cls(device)
+        return cls._per_device[key]
+
+    def _grow(self, name, floats):
+        t = getattr(self, name)
+        if t.numel() < floats:
+            setattr(self, name, torch.empty(int(floats), device=self.device, dtype=torch.float32))
+
+    def need_slab(self, nbytes):
+        self._grow("slab", (nbytes + 3) // 4)
+
+    def need_gtmp(self, floats):
+        self._grow("gtmp", floats)
+
+    def need_small(self, floats):      # bn / sn / bias-grad partial buffers
+        self._grow("small", floats)
+
+    def need_sums(self, floats):
+        self._grow("sums", floats)
+
+
+class ConvRec:
+    """One conv-view layer at a fixed batch size: geometry, packed panels, workspace reservations."""
+
+    def __init__(self, dtype, B, H, W, Cin, Cout, k, stride, pad, up=0, device=None, want_fwd=True, want_bwd=True,
+                 want_wgrad=True, ws: Workspace | None = None):
+        self.dtype = dtype
+        self.c = ops.make_conv(B, H, W, Cin, Cout, k, stride, pad, up)
+        self.B, self.H, self.W, self.Cin, self.Cout, self.k = B, H, W, Cin, Cout, k
+        self.OH = ((H << up) + 2 * pad - k) // stride + 1
+        self.OW = ((W << up) + 2 * pad - k) // stride + 1
+        tdt = ops.torch_dtype(dtype)
+        self.wp_fwd = torch.empty(ops.pack_fwd_elems(self.c, dtype), device=device, dtype=tdt) if want_fwd else None
+        self.wp_bwd = torch.empty(ops.pack_bwd_elems(self.c, dtype), device=device, dtype=tdt) if want_bwd else None
+        self.Kpad_fwd = ops.round_up(k * k * Cin, ops.bk(dtype))
+        if ws is not None:
+            if want_wgrad:
+                ws.need_slab(ops.conv_wgrad_ws_bytes(self.c, dtype))
+                ws.need_gtmp(Cout * Cin * k * k)
+            ws.need_small(ops.bias_grad_ws_floats(B * max(self.OH * self.OW, (H << up) * (W << up)), max(Cin, Cout)))
+
+    def pack(self, w_master):
+        if self.wp_fwd is not None:
+            ops.pack_fwd(self.c, self.dtype, w_master, self.wp_fwd)
+        if self.wp_bwd is not None:
+            ops.pack_bwd(self.c, self.dtype, w_master, self.wp_bwd)

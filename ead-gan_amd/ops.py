@@ -1,0 +1,222 @@
+"""Thin torch-tensor front end of the C ABI (include/eadgan_hip.h).
+
+Every function enqueues hand-written HIP kernels on torch's current stream and returns immediately.
+torch is used for device memory and streams only.  No function here has a CPU or eager fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, EG_BF16, EG_F32, OUT_NCHW_F32,
+                   OUT_NHWC, EgConv, EgEpilogue, lib)
+
+__all__ = ["EG_F32", "EG_BF16", "ACT_NONE", "ACT_LRELU", "ACT_RELU", "ACT_TANH", "ACT_SIGMOID", "OUT_NHWC",
+           "OUT_NCHW_F32"]
+
+
+def torch_dtype(dtype: int):
+    return torch.float32 if dtype == EG_F32 else torch.bfloat16
+
+
+def vec(dtype: int) -> int:
+    return 4 if dtype == EG_F32 else 8
+
+
+def bk(dtype: int) -> int:
+    return 32 if dtype == EG_F32 else 64
+
+
+def round_up(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def make_conv(B, H, W, Cin, Cout, k, stride, pad, up=0) -> EgConv:
+    return EgConv(B, H, W, Cin, Cout, k, stride, pad, up)
+
+
+def epilogue(bias=None, bias_mod=0, sigma=None, act=ACT_NONE, slope=0.0, mask=None, mask_act=ACT_NONE,
+             mask_slope=0.0, out_mode=OUT_NHWC) -> EgEpilogue:
+    return EgEpilogue(_p(bias), bias_mod, _p(sigma), act, slope, _p(mask), mask_act, mask_slope, out_mode)
+
+
+# ---- implicit-GEMM family ------------------------------------------------------------------------
+def pack_fwd_elems(c, dtype):
+    return lib().query("eg_pack_fwd_elems", ctypes.byref(c), dtype)
+
+
+def pack_bwd_elems(c, dtype):
+    return lib().query("eg_pack_bwd_elems", ctypes.byref(c), dtype)
+
+
+def pack_fwd(c, dtype, w_master, wp):
+    lib().call("eg_pack_fwd", ctypes.byref(c), dtype, _p(w_master), _p(wp), _stream())
+
+
+def pack_bwd(c, dtype, w_master, wp):
+    lib().call("eg_pack_bwd", ctypes.byref(c), dtype, _p(w_master), _p(wp), _stream())
+
+
+def pack_strided(dtype, w, wp, N, K, Kpad, n_div, s_hi, s_lo, s_k):
+    lib().call("eg_pack_strided", dtype, _p(w), _p(wp), N, K, Kpad, n_div, s_hi, s_lo, s_k, _stream())
+
+
+def conv_fwd(c, dtype, X, wp, Y, ep=None):
+    lib().call("eg_conv_fwd", ctypes.byref(c), dtype, _p(X), _p(wp), _p(Y), ctypes.byref(ep) if ep is not None else None, _stream())
+
+
+def conv_bwd_data(c, dtype, dY, wp, dX, ep=None):
+    lib().call("eg_conv_bwd_data", ctypes.byref(c), dtype, _p(dY), _p(wp), _p(dX), ctypes.byref(ep) if ep is not None else None, _stream())
+
+
+def conv_wgrad_ws_bytes(c, dtype):
+    return lib().query("eg_conv_wgrad_ws_bytes", ctypes.byref(c), dtype)
+
+
+def conv_wgrad(c, dtype, X, dY, slab) -> int:
+    ns = ctypes.c_int(0)
+    lib().call("eg_conv_wgrad", ctypes.byref(c), dtype, _p(X), _p(dY), _p(slab), ctypes.addressof(ns), _stream())
+    return ns.value
+
+
+def wgrad_reduce(slab, nsplit, n_slab, n_rows, C, T, grad, accumulate=True):
+    lib().call("eg_wgrad_reduce", _p(slab), nsplit, n_slab, n_rows, C, T, _p(grad), int(accumulate), _stream())
+
+
+def sn_partials():
+    return lib().query("eg_sn_partials")
+
+
+def wgrad_reduce_sn(c, slab, nsplit, w_orig, sigma, u, v, gtmp, partials, grad):
+    lib().call("eg_wgrad_reduce_sn", ctypes.byref(c), _p(slab), nsplit, _p(w_orig), _p(sigma), _p(u), _p(v), _p(gtmp), _p(partials), _p(grad), _stream())
+
+
+def bias_grad_ws_floats(rows, N):
+    return lib().query("eg_bias_grad_ws_floats", rows, N)
+
+
+def bias_grad(dtype, dY, rows, N, partials, gb, bias_mod=0):
+    lib().call("eg_bias_grad", dtype, _p(dY), rows, N, bias_mod, _p(partials), _p(gb), _stream())
+
+
+# ---- image side / heads ----------------------------------------------------------------------------
+def conv_img_fwd(dtype, img, w_master, out, B, CI, H, W, N, k, stride, pad, ep=None):
+    lib().call("eg_conv_img_fwd", dtype, _p(img), _p(w_master), _p(out), B, CI, H, W, N, k, stride, pad,
+               ctypes.byref(ep) if ep is not None else None, _stream())
+
+
+def conv_img_wgrad_ws_bytes(B, CI, N, k):
+    return lib().query("eg_conv_img_wgrad_ws_bytes", B, CI, N, k)
+
+
+def conv_img_wgrad(dtype, dz, img, slab, B, CI, H, W, N, k, stride, pad):
+    lib().call("eg_conv_img_wgrad", dtype, _p(dz), _p(img), _p(slab), B, CI, H, W, N, k, stride, pad, _stream())
+
+
+def flat_reduce(slab, nslab, total, grad, accumulate=True):
+    lib().call("eg_flat_reduce", _p(slab), nslab, total, _p(grad), int(accumulate), _stream())
+
+
+def flat_reduce_sn(slab, nslab, rows, Kdim, w_orig, sigma, u, v, gtmp, partials, grad):
+    lib().call("eg_flat_reduce_sn", _p(slab), nslab, rows, Kdim, _p(w_orig), _p(sigma), _p(u), _p(v), _p(gtmp), _p(partials), _p(grad), _stream())
+
+
+def bias_grad_nchw(x, B, C, HW, gb):
+    lib().call("eg_bias_grad_nchw", _p(x), B, C, HW, _p(gb), _stream())
+
+
+def dense_small_fwd(dtype, x, wp, bias, y, B, K, Kpad, N):
+    lib().call("eg_dense_small_fwd", dtype, _p(x), _p(wp), _p(bias), _p(y), B, K, Kpad, N, _stream())
+
+
+def dense_small_bwd(dtype, dy, wp, mask, dx, B, K, Kpad, N, mask_act=ACT_NONE, mask_slope=0.0):
+    lib().call("eg_dense_small_bwd", dtype, _p(dy), _p(wp), _p(mask), _p(dx), B, K, Kpad, N, mask_act, mask_slope, _stream())
+
+
+def dense_small_wgrad(dtype, dy, x, gw, gb, B, K, N, Cin, taps):
+    lib().call("eg_dense_small_wgrad", dtype, _p(dy), _p(x), _p(gw), _p(gb), B, K, N, Cin, taps, _stream())
+
+
+# ---- norm / spectral norm / optimiser -----------------------------------------------------------------
+def bn_ws_floats(M, C):
+    return lib().query("eg_bn_ws_floats", M, C)
+
+
+def bn_fwd_train(dtype, x, y, M, C, gamma, beta, eps, momentum, rmean, rvar, nbt, save_mean, save_invstd, ws, act=ACT_NONE, slope=0.0):
+    lib().call("eg_bn_fwd_train", dtype, _p(x), _p(y), M, C, _p(gamma), _p(beta), eps, momentum, _p(rmean), _p(rvar), _p(nbt),
+               _p(save_mean), _p(save_invstd), _p(ws), act, slope, _stream())
+
+
+def bn_bwd(dtype, z, da, dz, M, C, gamma, beta, save_mean, save_invstd, act, slope, dgamma, dbeta, sums, ws):
+    lib().call("eg_bn_bwd", dtype, _p(z), _p(da), _p(dz), M, C, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd), act, slope,
+               _p(dgamma), _p(dbeta), _p(sums), _p(ws), _stream())
+
+
+def sn_ws_floats(R, Kd):
+    return lib().query("eg_sn_ws_floats", R, Kd)
+
+
+def sn_power_iter(w_orig, R, Kd, u, v, sigma, u_snap, v_snap, ws, training=True, eps=1e-12):
+    lib().call("eg_sn_power_iter", _p(w_orig), R, Kd, _p(u), _p(v), _p(sigma), _p(u_snap), _p(v_snap), _p(ws), int(training), eps, _stream())
+
+
+def adam_step(p, g, m, v, n, lr, b1, b2, eps, step, tick=True):
+    lib().call("eg_adam_step", _p(p), _p(g), _p(m), _p(v), n, lr, b1, b2, eps, _p(step), int(tick), _stream())
+
+
+def fill_f32(t, val=0.0):
+    lib().call("eg_fill_f32", _p(t), t.numel(), val, _stream())
+
+
+# ---- utilities ------------------------------------------------------------------------------------------
+def concat_cast(dtype, a, b, c, out, B, Cpad):
+    wa = a.shape[1]
+    wb = b.shape[1] if b is not None else 0
+    wc = c.shape[1] if c is not None else 0
+    lib().call("eg_concat_cast", dtype, _p(a), wa, _p(b), wb, _p(c), wc, B, Cpad, _p(out), _stream())
+
+
+def act_grad_mul_f32(g, a, out, act, slope=0.0):
+    lib().call("eg_act_grad_mul_f32", _p(g), _p(a), _p(out), g.numel(), act, slope, _stream())
+
+
+def nchw_to_nhwc(dtype, x, y, B, C, HW, Cpad):
+    lib().call("eg_nchw_to_nhwc", dtype, _p(x), _p(y), B, C, HW, Cpad, _stream())
+
+
+def nhwc_to_nchw(dtype, x, y, B, C, HW, Cpad):
+    lib().call("eg_nhwc_to_nchw", dtype, _p(x), _p(y), B, C, HW, Cpad, _stream())
+
+
+# ---- affine / warp / losses --------------------------------------------------------------------------------
+def theta_rpqxy(code, ldc, B, theta):
+    lib().call("eg_theta_rpqxy", _p(code), ldc, B, _p(theta), _stream())
+
+
+def warp_affine(img, theta, out, B, C, H, W):
+    lib().call("eg_warp_affine", _p(img), _p(theta), _p(out), B, C, H, W, _stream())
+
+
+def loss_bce_sigmoid(o, ld, col, B, target, scale, loss, dout, zero_rows=True):
+    lib().call("eg_loss_bce_sigmoid", _p(o), ld, col, B, target, scale, _p(loss), _p(dout), int(zero_rows), _stream())
+
+
+def loss_mse(o, ld, col0, n, B, tgt, ldt, tconst, scale, loss, dout, zero_rows=True):
+    lib().call("eg_loss_mse", _p(o), ld, col0, n, B, _p(tgt), ldt, tconst, scale, _p(loss), _p(dout), int(zero_rows), _stream())
+
+
+def loss_ce_softmaxed(o, ld, c0, n, B, labels, scale, loss, dout):
+    lib().call("eg_loss_ce_softmaxed", _p(o), ld, c0, n, B, _p(labels), scale, _p(loss), _p(dout), _stream())
+
+
+def loss_affine_rpqxy(o_real, o_trans, ld, c0, B, code, ldc, scale, loss, d_real, d_trans, pred_out=None):
+    lib().call("eg_loss_affine_rpqxy", _p(o_real), _p(o_trans), ld, c0, B, _p(code), ldc, scale, _p(loss), _p(d_real), _p(d_trans), _p(pred_out), _stream())

@@ -1,0 +1,165 @@
+/* libeadgan_hip.so -- C ABI of the MI355X-native EAD-GAN training hot path (gfx950 / CDNA4).
+ *
+ * The reference (letao1991/EAD-GAN) is pure PyTorch: it has no FFI of its own.  Its hot path calls the
+ * torch operators listed per entry point below (file:line relative to the reference root); each entry
+ * point here is the hand-written HIP replacement that the Python host layer (ead-gan_amd/) binds with
+ * ctypes.  INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (tensor.data_ptr()); nothing is allocated,
+ *     freed or retained by the library; workspaces are passed in explicitly;
+ *   - every call is an asynchronous enqueue on `stream` (hipStream_t passed as void*), no device sync,
+ *     graph-capturable;
+ *   - return value: 0 ok, <0 argument error, >0 hipError_t; eg_last_error() gives the text;
+ *   - activations are NHWC ("pixel-major") in dtype T (EG_F32 or EG_BF16); images at the module boundary
+ *     are NCHW fp32 like the reference's tensors; master weights / gradients / optimizer state are fp32
+ *     in the reference's own layouts ([Cout][Cin][kh][kw] for Conv2d, [Cin][Cout][kh][kw] for
+ *     ConvTranspose2d);
+ *   - "conv view": a ConvTranspose2d(Ci->Co,k,s,p) layer is described as the Conv2d(Co->Ci,k,s,p) whose
+ *     backward-data it is; its forward is eg_conv_bwd_data, its input gradient eg_conv_fwd.
+ */
+#ifndef EADGAN_HIP_H
+#define EADGAN_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* eg_stream_t;
+
+enum { EG_F32 = 0, EG_BF16 = 1 };
+enum { EG_ACT_NONE = 0, EG_ACT_LRELU = 1, EG_ACT_RELU = 2, EG_ACT_TANH = 3, EG_ACT_SIGMOID = 4 };
+enum { EG_OUT_NHWC = 0, EG_OUT_NCHW_F32 = 1 };
+
+int eg_version(void);
+const char* eg_last_error(void);
+
+/* One square 2-D convolution in conv view.  X is [B,H,W,Cin] (NHWC); if up==1 the conv reads the
+ * nearest-2x-upsampled X (nn.Upsample fused, MNIST/EAD-GAN_rpqmnxy.py:81,85).  Y is [B,OH,OW,Cout],
+ * OH = ((H<<up) + 2*pad - k)/stride + 1.  All spatial extents must be powers of two. */
+typedef struct eg_conv {
+    int B, H, W, Cin, Cout, k, stride, pad, up;
+} eg_conv;
+
+/* Fused epilogue of the implicit-GEMM kernels:  v = acc [/ *sigma] [+ bias[n % bias_mod]] ;
+ * v = act(v) ; [v *= act'(mask)] ; store.  `mask` holds the activation OUTPUT of the layer whose
+ * gradient is being formed (same dtype and layout as dst), so LeakyReLU/ReLU backward never needs a
+ * separate pass. */
+typedef struct eg_epilogue {
+    const float* bias;
+    int bias_mod;
+    const float* sigma;
+    int act;
+    float slope;
+    const void* mask;
+    int mask_act;
+    float mask_slope;
+    int out_mode;
+} eg_epilogue;
+
+/* --- implicit-GEMM convolution family (MFMA) ---------------------------------------------------
+ * replaces torch.nn.functional.conv2d / conv_transpose2d / linear and their autograd backward:
+ *   celebA/EAD-GAN_celebA.py:76-90,110-122   dSprites/rp.py:95-110,129-146
+ *   MNIST/EAD-GAN_rpqmnxy.py:77-90,107-124,143-163 */
+size_t eg_pack_fwd_elems(const eg_conv* c, int dtype);                 /* elements of Wp_fwd */
+size_t eg_pack_bwd_elems(const eg_conv* c, int dtype);                 /* elements of Wp_bwd */
+int eg_pack_fwd(const eg_conv* c, int dtype, const float* w_master, void* wp, eg_stream_t s);
+int eg_pack_bwd(const eg_conv* c, int dtype, const float* w_master, void* wp, eg_stream_t s);
+/* Y = conv(X, W) */
+int eg_conv_fwd(const eg_conv* c, int dtype, const void* X, const void* wp_fwd, void* Y,
+                const eg_epilogue* ep, eg_stream_t s);
+/* dX = conv^T(dY, W)  (== ConvTranspose2d forward); dX has spatial dims (H<<up, W<<up) */
+int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, const void* wp_bwd, void* dX,
+                     const eg_epilogue* ep, eg_stream_t s);
+/* dW partial slabs: slab[split][Cout][k*k][Cin] fp32.  Returns the split count through *nsplit. */
+size_t eg_conv_wgrad_ws_bytes(const eg_conv* c, int dtype);
+int eg_conv_wgrad(const eg_conv* c, int dtype, const void* X, const void* dY, float* slab, int* nsplit,
+                  eg_stream_t s);
+/* grad[n][c][t] (+)= sum_split slab[split][n][t][c]  for n < n_rows (slab rows: n_slab >= n_rows);
+ * C = gathered channels, T = taps.  Master layouts [Cout][Cin][k][k] / [Cin_T][Cout_T][k][k] are both [n][c][t]. */
+int eg_wgrad_reduce(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad,
+                    int accumulate, eg_stream_t s);
+/* spectral-norm variant (torch.nn.utils.spectral_norm backward, celebA/EAD-GAN_celebA.py:110-120):
+ * G = sum slab ;  grad += G/sigma - (<G,W_orig>/sigma^2) u v^T.  gtmp: Cout*Cin*k*k floats,
+ * partials: >= eg_sn_partials() floats. */
+int eg_sn_partials(void);
+int eg_wgrad_reduce_sn(const eg_conv* c, const float* slab, int nsplit, const float* w_orig,
+                       const float* sigma, const float* u, const float* v, float* gtmp, float* partials,
+                       float* grad, eg_stream_t s);
+/* per-output-channel bias gradient: gb[n % bias_mod] += sum_rows dY[row][n]  (dY is [rows][N] dtype T) */
+size_t eg_bias_grad_ws_floats(int rows, int N);
+int eg_bias_grad(int dtype, const void* dY, int rows, int N, int bias_mod, float* partials, float* gb,
+                 eg_stream_t s);
+/* wp[n][k] = w[(n / n_div) * s_hi + (n % n_div) * s_lo + k * s_k], zero for K <= k < Kpad
+ * (ConvTranspose2d on a 1x1 input as a GEMM: celebA/EAD-GAN_celebA.py:76; view-permuted Linear outputs) */
+int eg_pack_strided(int dtype, const float* w, void* wp, int N, int K, int Kpad, int n_div, long long s_hi,
+                    long long s_lo, long long s_k, eg_stream_t s);
+
+/* --- image-side (1..4 channel, NCHW fp32) convolution and its weight gradient ---------------------
+ * first Discriminator/Encoder conv (celebA/EAD-GAN_celebA.py:110, dSprites/rp.py:95, MNIST/EAD-GAN_rpqmnxy.py:107)
+ * and input gradient / weight gradient of the Generator's last ConvTranspose2d (celebA/EAD-GAN_celebA.py:90) */
+int eg_conv_img_fwd(int dtype, const float* img, const float* w_master, void* out, int B, int CI, int H, int W,
+                    int N, int k, int stride, int pad, const eg_epilogue* ep, eg_stream_t s);
+size_t eg_conv_img_wgrad_ws_bytes(int B, int CI, int N, int k);
+int eg_conv_img_wgrad(int dtype, const void* dz, const float* img, float* slab, int B, int CI, int H, int W,
+                      int N, int k, int stride, int pad, eg_stream_t s);
+int eg_flat_reduce(const float* slab, int nslab, size_t total, float* grad, int accumulate, eg_stream_t s);
+int eg_flat_reduce_sn(const float* slab, int nslab, int rows, int Kdim, const float* w_orig, const float* sigma,
+                      const float* u, const float* v, float* gtmp, float* partials, float* grad, eg_stream_t s);
+int eg_bias_grad_nchw(const float* x, int B, int C, int HW, float* gb, eg_stream_t s);
+
+/* --- small-N dense heads (celebA/EAD-GAN_celebA.py:122; MNIST/EAD-GAN_rpqmnxy.py:124,161-163; dSprites/rp.py:109-110,180-183)
+ * y[b][n] = sum_k x[b][k] Wp[n][k] + bias[n];  x dtype T [B][K]; Wp dtype T [N][Kpad] (eg_pack_fwd order);  y fp32 */
+int eg_dense_small_fwd(int dtype, const void* x, const void* wp, const float* bias, float* y, int B, int K,
+                       int Kpad, int N, eg_stream_t s);
+int eg_dense_small_bwd(int dtype, const float* dy, const void* wp, const void* mask, void* dx, int B, int K,
+                       int Kpad, int N, int mask_act, float mask_slope, eg_stream_t s);
+int eg_dense_small_wgrad(int dtype, const float* dy, const void* x, float* gw, float* gb, int B, int K, int N,
+                         int Cin, int taps, eg_stream_t s);
+
+/* --- BatchNorm2d, training mode (celebA/EAD-GAN_celebA.py:79,83,87; MNIST/EAD-GAN_rpqmnxy.py:80,83,87,145) ----
+ * x,y: [M][C] dtype T; updates running stats (momentum, unbiased var) and num_batches_tracked; fused activation */
+size_t eg_bn_ws_floats(int M, int C);
+int eg_bn_fwd_train(int dtype, const void* x, void* y, int M, int C, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
+                    float* save_mean, float* save_invstd, float* ws, int act, float slope, eg_stream_t s);
+/* dz from da (gradient w.r.t. the activation output); dgamma/dbeta accumulate; sums: 2*C floats scratch */
+int eg_bn_bwd(int dtype, const void* z, const void* da, void* dz, int M, int C, const float* gamma, const float* beta,
+              const float* save_mean, const float* save_invstd, int act, float slope, float* dgamma, float* dbeta,
+              float* sums, float* ws, eg_stream_t s);
+
+/* --- spectral norm power iteration (torch.nn.utils.spectral_norm, celebA/EAD-GAN_celebA.py:110-120) -------- */
+size_t eg_sn_ws_floats(int R, int Kd);
+int eg_sn_power_iter(const float* w_orig, int R, int Kd, float* u, float* v, float* sigma, float* u_snap,
+                     float* v_snap, float* ws, int training, float eps, eg_stream_t s);
+
+/* --- Adam (torch.optim.Adam, celebA/EAD-GAN_celebA.py:211-217) over a flat fp32 arena ----------------------- */
+int eg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                 int* step, int tick, eg_stream_t s);
+int eg_fill_f32(float* p, size_t n, float val, eg_stream_t s);
+
+/* --- utility: generator input concat+cast, elementwise activation gradient, layout conversion -------------- */
+int eg_concat_cast(int dtype, const float* a, int wa, const float* b, int wb, const float* c, int wc, int B,
+                   int Cpad, void* out, eg_stream_t s);
+int eg_act_grad_mul_f32(const float* g, const float* a, float* out, size_t n, int act, float slope, eg_stream_t s);
+int eg_nchw_to_nhwc(int dtype, const float* x, void* y, int B, int C, int HW, int Cpad, eg_stream_t s);
+int eg_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int HW, int Cpad, eg_stream_t s);
+
+/* --- affine codes, warp and loss heads ---------------------------------------------------------------------
+ * eg_theta_rpqxy : celebA/utils_rpqxy.py:59-80 (rows 0,1 of R*Z*T) ;  eg_warp_affine : transformation_2D,
+ * celebA/EAD-GAN_celebA.py:146-152 ;  losses : celebA/EAD-GAN_celebA.py:161-169,342,355-362,383-395 */
+int eg_theta_rpqxy(const float* code, int ldc, int B, float* theta, eg_stream_t s);
+int eg_warp_affine(const float* img, const float* theta, float* out, int B, int C, int H, int W, eg_stream_t s);
+int eg_loss_bce_sigmoid(const float* o, int ld, int col, int B, float target, float scale, float* loss, float* dout,
+                        int zero_rows, eg_stream_t s);
+int eg_loss_mse(const float* o, int ld, int col0, int n, int B, const float* tgt, int ldt, float tconst, float scale,
+                float* loss, float* dout, int zero_rows, eg_stream_t s);
+int eg_loss_ce_softmaxed(const float* o, int ld, int c0, int n, int B, const long long* labels, float scale,
+                         float* loss, float* dout, eg_stream_t s);
+int eg_loss_affine_rpqxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc,
+                         float scale, float* loss, float* d_real, float* d_trans, float* pred_out, eg_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EADGAN_HIP_H */

@@ -1,0 +1,163 @@
+"""CelebA hot path on the MI355X vs the CPU oracle (oracle/celeba_oracle.py, pinned to the reference by
+tests/golden/celeba_b4_s3.npz): network forward/backward, the fused train step, hipGraph replay."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN
+from oracle import celeba_oracle as co
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+eg = None
+
+
+def setup_module(module):
+    global eg
+    eg = importlib.import_module("ead-gan_amd")
+    torch.set_num_threads(16)
+
+
+def build_pair(seed, dtype):
+    orc = co.CelebAOracle(seed=seed)
+    G = eg.celeba.Generator(dtype=dtype).to(DEV)
+    D = eg.celeba.Discriminator(dtype=dtype).to(DEV)
+    assert list(G.state_dict().keys()) == list(orc.G.keys())
+    assert list(D.state_dict().keys()) == list(orc.D.keys())
+    G.load_state_dict({k: v.detach() for k, v in orc.G.items()})
+    D.load_state_dict({k: v.detach() for k, v in orc.D.items()})
+    return orc, G, D
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu().flatten(), b.detach().float().cpu().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def test_state_dict_is_reference_compatible():
+    orc, G, D = build_pair(0, "f32")
+    for k, v in orc.D.items():
+        assert D.state_dict()[k].shape == v.shape, k
+    for k, v in orc.G.items():
+        assert G.state_dict()[k].shape == v.shape, k
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("bf16", 3e-2)])
+def test_generator_forward_backward(dtype, tol):
+    B = 4
+    orc, G, D = build_pair(1, dtype)
+    rng = np.random.RandomState(5)
+    z, code, labels = co.draw_step_inputs(rng, B)
+    onehot = F.one_hot(labels, 10).float()
+    want = co.generator_forward(orc.G, z, onehot, code)
+    got = G(z.to(DEV), onehot.to(DEV), code.to(DEV))
+    assert got.shape == (B, 3, 64, 64)
+    assert rel_err(got, want) < tol
+    w = torch.randn(want.shape, generator=torch.Generator().manual_seed(3))
+    (want * w).sum().backward()
+    (got * w.to(DEV)).sum().backward()
+    for k, p in G.named_parameters():
+        ref = orc.G[k].grad
+        if ref.abs().mean() < 1e-7:          # conv biases in front of BatchNorm: zero gradient up to rounding noise
+            continue
+        assert rel_err(p.grad, ref) < tol * 20, k
+    # BatchNorm running statistics follow the reference (momentum 0.1, unbiased variance)
+    for k in ("conv_blocks.2.running_mean", "conv_blocks.5.running_var", "conv_blocks.8.running_mean"):
+        assert rel_err(G.state_dict()[k], orc.G[k]) < max(tol, 1e-4), k
+    assert int(G.state_dict()["conv_blocks.2.num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-5), ("bf16", 3e-2)])
+def test_discriminator_forward_backward(dtype, tol):
+    B = 4
+    orc, G, D = build_pair(2, dtype)
+    img = co.synthetic_real(B, seed=9).requires_grad_(True)
+    imgd = img.detach().to(DEV).requires_grad_(True)
+    cat, cont, val = co.discriminator_forward(orc.D, img)
+    gcat, gcont, gval = D(imgd)
+    assert rel_err(gcat, cat) < tol and rel_err(gcont, cont) < tol * 5 and rel_err(gval, val) < tol
+    # spectral-norm buffers advanced by exactly one power iteration
+    for i in range(4):
+        assert rel_err(D.state_dict()[f"main.{2 * i}.weight_u"], orc.D[f"main.{2 * i}.weight_u"]) < 1e-4
+        assert rel_err(D.state_dict()[f"main.{2 * i}.weight_v"], orc.D[f"main.{2 * i}.weight_v"]) < 1e-4
+    g = torch.Generator().manual_seed(4)
+    w1, w2, w3 = torch.randn(cat.shape, generator=g), torch.randn(cont.shape, generator=g), torch.randn(val.shape, generator=g)
+    ((cat * w1).sum() + (cont * w2).sum() + (val * w3).sum()).backward()
+    ((gcat * w1.to(DEV)).sum() + (gcont * w2.to(DEV)).sum() + (gval * w3.to(DEV)).sum()).backward()
+    assert rel_err(imgd.grad, img.grad) < tol * 20
+    for k, p in D.named_parameters():
+        assert rel_err(p.grad, orc.D[k].grad) < tol * 20, k
+
+
+def run_steps(dtype, B, steps, seed=0, capture=False):
+    orc, G, D = build_pair(seed, dtype)
+    tr = eg.celeba.CelebATrainer(G, D, B, dtype=dtype)
+    rng = np.random.RandomState(seed)
+    real = co.synthetic_real(B * steps, seed=1234).view(steps, B, 3, 64, 64)
+    got, want = [], []
+    for i in range(steps):
+        z, code, labels = co.draw_step_inputs(rng, B)
+        got.append(tr.train_step(real[i].to(DEV), z.to(DEV), code.to(DEV), labels.to(DEV)))
+        want.append(orc.train_step(real[i], z, code, labels))
+    return orc, G, D, tr, got, want
+
+
+def test_train_step_fp32_parity():
+    """fp32 tolerance: step 0 losses 2e-5 abs; info-step gradients 1e-3 relative (L2); later steps looser because
+    Adam's first updates amplify rounding noise (see tests/test_oracle_golden.py)."""
+    orc, G, D, tr, got, want = run_steps("f32", 8, 2)
+    for k in ("g_loss", "d_loss", "info_loss"):
+        assert abs(got[0][k] - want[0][k]) < 2e-5, (k, got[0][k], want[0][k])
+        assert abs(got[1][k] - want[1][k]) < 2e-3, (k, got[1][k], want[1][k])
+
+
+def test_train_step_gradients_fp32():
+    orc, G, D, tr, got, want = run_steps("f32", 8, 1, seed=3)
+    for mod, ref in ((G, orc.G), (D, orc.D)):
+        for k, p in mod.named_parameters():
+            r = ref[k].grad
+            if r.abs().mean() < 1e-7:
+                continue
+            assert rel_err(p.grad, r) < 2e-3, k
+
+
+def test_train_step_bf16_tracks_oracle():
+    """bf16 MFMA inputs, fp32 accumulate/master weights: losses within 3e-2 of the fp32 oracle over 3 steps."""
+    orc, G, D, tr, got, want = run_steps("bf16", 8, 3)
+    for i in range(3):
+        for k in ("g_loss", "d_loss", "info_loss"):
+            assert abs(got[i][k] - want[i][k]) < 3e-2 * max(1.0, abs(want[i][k])), (i, k, got[i][k], want[i][k])
+
+
+def test_matches_reference_golden_losses():
+    gold = np.load(os.path.join(GOLDEN, "celeba_b4_s3.npz"))
+    B, steps, seed = int(gold["B"]), int(gold["steps"]), int(gold["seed"])
+    orc, G, D, tr, got, want = run_steps("f32", B, steps, seed=seed)
+    for i, tol in enumerate((2e-5, 1e-3, 1e-2)):
+        for k in ("g_loss", "d_loss", "info_loss"):
+            assert abs(got[i][k] - gold[k][i]) < tol, (i, k, got[i][k], gold[k][i])
+
+
+def test_graph_replay_equals_eager():
+    """the captured hipGraph must reproduce the eager launch sequence bit for bit (deterministic kernels)."""
+    B = 4
+    losses = []
+    for capture in (False, True):
+        orc, G, D = build_pair(7, "bf16")
+        tr = eg.celeba.CelebATrainer(G, D, B, dtype="bf16")
+        rng = np.random.RandomState(1)
+        real = co.synthetic_real(B, seed=5).to(DEV)
+        out = []
+        for i in range(3):
+            z, code, labels = co.draw_step_inputs(rng, B)
+            tr.load_inputs(real, z.to(DEV), code.to(DEV), labels.to(DEV))
+            if capture and i == 1:
+                tr.capture()          # step 0 ran eagerly: kernels are loaded, capture records without executing
+            out.append(tr.step_resident().clone())
+        torch.cuda.synchronize()
+        losses.append(torch.stack(out).cpu())
+    assert torch.equal(losses[0], losses[1]), (losses[0], losses[1])

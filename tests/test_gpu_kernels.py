@@ -1,0 +1,331 @@
+"""Per-kernel parity: hand-written HIP kernels (through the C ABI) vs torch-CPU fp32 on the same seeded inputs.
+fp32 kernels use the exact-fp32 MFMA -> tight tolerances; bf16 kernels round inputs to bf16 (fp32 accumulate)
+-> tolerances scale with sqrt(K) * 2^-8."""
+import importlib
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+eg = None
+ops = None
+
+
+def setup_module(module):
+    global eg, ops
+    eg = importlib.import_module("ead-gan_amd")
+    ops = eg.ops
+
+
+DEV = "cuda"
+DTYPES = [0, 1]
+
+
+def tol(dtype, K):
+    return (2e-5, 2e-5) if dtype == 0 else (3e-2, 2e-2 * math.sqrt(max(K, 1)) / 8)
+
+
+def nhwc(x, dtype):
+    """NCHW fp32 CPU -> NHWC device tensor in compute dtype"""
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV).to(ops.torch_dtype(dtype))
+
+
+def nchw(y):
+    return y.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rq(x, dtype):
+    """round a CPU fp32 tensor through the compute dtype (what the kernel sees)"""
+    return x if dtype == 0 else x.to(torch.bfloat16).float()
+
+
+CONV_CASES = [
+    # B, H, Cin, Cout, k, s, p, up
+    (2, 16, 32, 48, 4, 2, 1, 0),
+    (3, 8, 64, 160, 4, 2, 1, 0),
+    (2, 8, 16, 24, 3, 1, 1, 1),
+    (2, 16, 16, 32, 3, 2, 1, 0),
+    (5, 1, 24, 40, 1, 1, 0, 0),
+    (4, 4, 128, 19 + 5, 4, 1, 0, 0),
+    (1, 32, 8, 8, 4, 2, 1, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd(case, dtype):
+    B, H, Cin, Cout, k, s, p, up = case
+    g = torch.Generator().manual_seed(1)
+    x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    c = ops.make_conv(B, H, H, Cin, Cout, k, s, p, up)
+    wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
+    ops.pack_fwd(c, dtype, w.to(DEV), wp)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    want = F.leaky_relu(F.conv2d(xin, rq(w, dtype), b, s, p), 0.2)
+    OH = want.shape[-1]
+    y = torch.empty(B, OH, OH, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
+    bias = b.to(DEV)
+    ops.conv_fwd(c, dtype, nhwc(x, dtype), wp, y, ops.epilogue(bias=bias, act=ops.ACT_LRELU, slope=0.2))
+    torch.cuda.synchronize()
+    rt, at = tol(dtype, Cin * k * k)
+    torch.testing.assert_close(nchw(y), want, rtol=rt, atol=at)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES[:4] + [(2, 16, 3, 32, 4, 2, 1, 0)])
+def test_conv_bwd_data(case, dtype):
+    """dX = conv_transpose2d(dY, W) incl. sigma scaling, activation-gradient mask and NCHW fp32 output."""
+    B, H, Cin, Cout, k, s, p, up = case
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.1
+    OH = ((H << up) + 2 * p - k) // s + 1
+    dy = rq(torch.randn(B, Cout, OH, OH, generator=g), dtype)
+    c = ops.make_conv(B, H, H, Cin, Cout, k, s, p, up)
+    wp = torch.empty(ops.pack_bwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
+    ops.pack_bwd(c, dtype, w.to(DEV), wp)
+    XH = H << up
+    want = F.conv_transpose2d(dy, rq(w, dtype), None, s, p, output_padding=XH - ((OH - 1) * s - 2 * p + k))
+    sigma = torch.tensor([1.7], device=DEV)
+    rt, at = tol(dtype, Cout * k * k / (s * s))
+    if Cin % ops.vec(dtype) == 0:
+        a = rq(torch.randn(B, Cin, XH, XH, generator=g), dtype)
+        dx = torch.empty(B, XH, XH, Cin, device=DEV, dtype=ops.torch_dtype(dtype))
+        ops.conv_bwd_data(c, dtype, nhwc(dy, dtype), wp, dx,
+                          ops.epilogue(sigma=sigma, mask=nhwc(a, dtype), mask_act=ops.ACT_LRELU, mask_slope=0.1))
+        torch.cuda.synchronize()
+        torch.testing.assert_close(nchw(dx), want / 1.7 * torch.where(a > 0, 1.0, 0.1), rtol=rt, atol=at)
+    out = torch.empty(B, Cin, XH, XH, device=DEV, dtype=torch.float32)
+    b = torch.randn(Cin, generator=g)
+    ops.conv_bwd_data(c, dtype, nhwc(dy, dtype), wp, out, ops.epilogue(bias=b.to(DEV), act=ops.ACT_TANH, out_mode=ops.OUT_NCHW_F32))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.cpu(), torch.tanh(want + b[None, :, None, None]), rtol=rt, atol=at)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES[:5] + [(4, 32, 16, 32, 4, 2, 1, 0), (8, 16, 128, 256, 4, 2, 1, 0)])
+def test_conv_wgrad(case, dtype):
+    B, H, Cin, Cout, k, s, p, up = case
+    g = torch.Generator().manual_seed(3)
+    x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) * 0.1).requires_grad_(True)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    y = F.conv2d(xin, w, None, s, p)
+    dy = rq(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    c = ops.make_conv(B, H, H, Cin, Cout, k, s, p, up)
+    slab = torch.empty(ops.conv_wgrad_ws_bytes(c, dtype) // 4, device=DEV)
+    ns = ops.conv_wgrad(c, dtype, nhwc(x, dtype), nhwc(dy, dtype), slab)
+    grad = torch.ones(Cout, Cin, k, k, device=DEV)
+    ops.wgrad_reduce(slab, ns, Cout, Cout, Cin, k * k, grad, accumulate=True)
+    torch.cuda.synchronize()
+    rt, at = tol(dtype, B * y.shape[-1] ** 2)
+    torch.testing.assert_close(grad.cpu() - 1.0, w.grad, rtol=rt, atol=at * 4)
+    # spectral-norm reduction: grad += G/sigma - <G,W>/sigma^2 u v^T
+    u = F.normalize(torch.randn(Cout, generator=g), dim=0)
+    v = F.normalize(torch.randn(Cin * k * k, generator=g), dim=0)
+    sig = torch.tensor([1.3])
+    gtmp = torch.empty(Cout * Cin * k * k, device=DEV)
+    part = torch.empty(4096, device=DEV)
+    grad2 = torch.zeros(Cout, Cin, k, k, device=DEV)
+    ops.wgrad_reduce_sn(c, slab, ns, w.detach().to(DEV), sig.to(DEV), u.to(DEV), v.to(DEV), gtmp, part, grad2)
+    torch.cuda.synchronize()
+    G = w.grad
+    want = G / 1.3 - (G * w.detach()).sum() / 1.3 ** 2 * torch.outer(u, v).view_as(G)
+    torch.testing.assert_close(grad2.cpu(), want, rtol=rt * 2, atol=at * 8)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 8, 64, 1e-5, 2), (3, 16, 24, 0.8, 1), (4, 4, 128, 1e-5, 0)])
+def test_batchnorm(shape, dtype):
+    B, H, C, eps, act = shape
+    g = torch.Generator().manual_seed(4)
+    x = rq(torch.randn(B, C, H, H, generator=g) * 2 + 0.5, dtype).requires_grad_(True)
+    bn = torch.nn.BatchNorm2d(C, eps)
+    with torch.no_grad():
+        bn.weight.normal_(1, 0.2, generator=g)
+        bn.bias.normal_(0, 0.2, generator=g)
+    fact = {0: lambda t: t, 1: lambda t: F.leaky_relu(t, 0.2), 2: F.relu}[act]
+    y = fact(bn(x))
+    da = rq(torch.randn(y.shape, generator=g), dtype)
+    y.backward(da)
+    M = B * H * H
+    tdt = ops.torch_dtype(dtype)
+    ws = torch.empty(max(ops.bn_ws_floats(M, C), 1), device=DEV)
+    gam, bet = bn.weight.detach().to(DEV), bn.bias.detach().to(DEV)
+    rm, rv, nbt = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+    sm, si = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    xd = nhwc(x.detach(), dtype)
+    yd = torch.empty_like(xd)
+    ops.bn_fwd_train(dtype, xd, yd, M, C, gam, bet, eps, 0.1, rm, rv, nbt, sm, si, ws, act, 0.2)
+    torch.cuda.synchronize()
+    rt, at = (1e-5, 2e-5) if dtype == 0 else (2e-2, 2e-2)
+    torch.testing.assert_close(nchw(yd), y.detach(), rtol=rt, atol=at)
+    torch.testing.assert_close(rm.cpu(), bn.running_mean, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rv.cpu(), bn.running_var, rtol=1e-5, atol=1e-5)
+    assert int(nbt) == 1
+    dz = torch.empty_like(xd)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    sums = torch.empty(2 * C, device=DEV)
+    ops.bn_bwd(dtype, xd, nhwc(da, dtype), dz, M, C, gam, bet, sm, si, act, 0.2, dg, db, sums, ws)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(nchw(dz), x.grad, rtol=rt * 5, atol=at * 2)
+    torch.testing.assert_close(dg.cpu(), bn.weight.grad, rtol=rt * 5, atol=at * 10)
+    torch.testing.assert_close(db.cpu(), bn.bias.grad, rtol=rt * 5, atol=at * 10)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(3, 3, 64, 128, 4, 2, 1), (2, 1, 32, 16, 3, 2, 1), (2, 1, 64, 32, 4, 2, 1), (2, 1, 32, 64, 3, 1, 1)])
+def test_conv_img(case, dtype):
+    B, CI, H, N, k, s, p = case
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(B, CI, H, H, generator=g)
+    w = (torch.randn(N, CI, k, k, generator=g) * 0.2).requires_grad_(True)
+    b = torch.randn(N, generator=g)
+    want = F.leaky_relu(F.conv2d(img, w, None, s, p) / 1.5 + b[None, :, None, None], 0.1)
+    OH = want.shape[-1]
+    out = torch.empty(B, OH, OH, N, device=DEV, dtype=ops.torch_dtype(dtype))
+    sig = torch.tensor([1.5], device=DEV)
+    ops.conv_img_fwd(dtype, img.to(DEV), w.detach().to(DEV), out, B, CI, H, H, N, k, s, p,
+                     ops.epilogue(bias=b.to(DEV), sigma=sig, act=ops.ACT_LRELU, slope=0.1))
+    torch.cuda.synchronize()
+    rt, at = (1e-5, 1e-5) if dtype == 0 else (1e-2, 1e-2)
+    torch.testing.assert_close(nchw(out), want.detach(), rtol=rt, atol=at)
+    # weight gradient
+    dz = rq(torch.randn(B, N, OH, OH, generator=g), dtype)
+    F.conv2d(img, w, None, s, p).backward(dz)
+    slab = torch.empty(ops.conv_img_wgrad_ws_bytes(B, CI, N, k) // 4, device=DEV)
+    ops.conv_img_wgrad(dtype, nhwc(dz, dtype), img.to(DEV), slab, B, CI, H, H, N, k, s, p)
+    grad = torch.zeros(N, CI, k, k, device=DEV)
+    ops.flat_reduce(slab, B, grad.numel(), grad)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(grad.cpu(), w.grad, rtol=1e-4, atol=2e-4 * math.sqrt(B * OH * OH))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dense_small(dtype):
+    B, C, T, N = 6, 64, 16, 19
+    K = C * T
+    g = torch.Generator().manual_seed(6)
+    x = rq(torch.randn(B, C, 4, 4, generator=g), dtype).requires_grad_(True)        # NCHW reference
+    w = (torch.randn(N, C, 4, 4, generator=g) * 0.05).requires_grad_(True)
+    b = torch.randn(N, generator=g).requires_grad_(True)
+    a = F.leaky_relu(x, 0.1)
+    dy = torch.randn(B, N, generator=g)
+    y = F.conv2d(a, rq(w.detach(), dtype), b.detach()).squeeze()        # forward / input gradient see the rounded weights
+    y.backward(dy)
+    F.conv2d(rq(a.detach(), dtype), w, b).squeeze().backward(dy)           # weight / bias gradient
+    c = ops.make_conv(B, 4, 4, C, N, 4, 1, 0)
+    wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
+    ops.pack_fwd(c, dtype, w.detach().to(DEV), wp)
+    Kpad = ops.round_up(K, ops.bk(dtype))
+    ad = nhwc(rq(a.detach(), dtype), dtype)
+    yd = torch.empty(B, N, device=DEV)
+    ops.dense_small_fwd(dtype, ad, wp, b.detach().to(DEV), yd, B, K, Kpad, N)
+    torch.cuda.synchronize()
+    rt, at = (1e-5, 2e-5) if dtype == 0 else (2e-2, 5e-2)
+    torch.testing.assert_close(yd.cpu(), y.detach(), rtol=rt, atol=at)
+    dx = torch.empty_like(ad)
+    ops.dense_small_bwd(dtype, dy.to(DEV), wp, ad, dx, B, K, Kpad, N, ops.ACT_LRELU, 0.1)
+    gw, gb = torch.zeros(N, C, 4, 4, device=DEV), torch.zeros(N, device=DEV)
+    ops.dense_small_wgrad(dtype, dy.to(DEV), ad, gw, gb, B, K, N, C, T)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(nchw(dx), x.grad, rtol=rt, atol=at)
+    torch.testing.assert_close(gw.cpu(), w.grad, rtol=rt, atol=at)
+    torch.testing.assert_close(gb.cpu(), b.grad, rtol=1e-5, atol=1e-5)
+
+
+def test_spectral_norm_power_iteration():
+    g = torch.Generator().manual_seed(7)
+    for R, Kd in [(128, 48), (256, 2048), (1024, 8192), (16, 9)]:
+        conv = torch.nn.Linear(Kd, R, bias=False)
+        m = torch.nn.utils.spectral_norm(conv)
+        w, u, v = m.weight_orig.detach().clone(), m.weight_u.clone(), m.weight_v.clone()
+        ud, vd, sd = u.to(DEV), v.to(DEV), torch.empty(1, device=DEV)
+        us, vs = torch.empty_like(ud), torch.empty_like(vd)
+        ws = torch.empty(ops.sn_ws_floats(R, Kd), device=DEV)
+        for it in range(3):
+            m.train()
+            _ = m(torch.zeros(1, Kd))         # one power iteration (training-mode forward)
+            ops.sn_power_iter(w.to(DEV), R, Kd, ud, vd, sd, us, vs, ws, True, 1e-12)
+            torch.cuda.synchronize()
+            sigma_ref = torch.dot(m.weight_u, torch.mv(w, m.weight_v))
+            torch.testing.assert_close(ud.cpu(), m.weight_u, rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(vd.cpu(), m.weight_v, rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(us.cpu(), m.weight_u, rtol=1e-4, atol=1e-5)
+            torch.testing.assert_close(sd.cpu()[0], sigma_ref, rtol=1e-5, atol=1e-6)
+
+
+def test_adam_matches_torch():
+    g = torch.Generator().manual_seed(8)
+    n = 10007
+    p = torch.randn(n, generator=g).requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=2e-4, betas=(0.5, 0.999))
+    pd, m, v = p.detach().clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for it in range(5):
+        gr = torch.randn(n, generator=g) * (10.0 ** (it - 3))
+        p.grad = gr.clone()
+        opt.step()
+        ops.adam_step(pd, gr.to(DEV), m, v, n, 2e-4, 0.5, 0.999, 1e-8, step, True)
+    torch.cuda.synchronize()
+    assert int(step) == 5
+    torch.testing.assert_close(pd.cpu(), p.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_warp_and_theta_match_golden():
+    import os
+    from conftest import GOLDEN
+    from oracle import celeba_oracle as co
+    gold = np.load(os.path.join(GOLDEN, "celeba_affine.npz"))
+    code = torch.tensor(gold["code"]).to(DEV)
+    A = eg.celeba.get_matrix(code[:, :5].contiguous())
+    np.testing.assert_allclose(A.cpu().numpy(), gold["A"], rtol=2e-6, atol=2e-7)
+    img = co.synthetic_real(4, seed=int(gold["img_seed"])).to(DEV)
+    warped = eg.celeba.transformation_2D()(img, A[:4, 0:2])
+    np.testing.assert_allclose(warped.cpu().numpy(), gold["warped"], rtol=1e-4, atol=2e-5)
+
+
+def test_affine_regularizer_matches_golden():
+    import os
+    from conftest import GOLDEN
+    gold = np.load(os.path.join(GOLDEN, "celeba_affine.npz"))
+    rc = torch.tensor(gold["real_code"], device=DEV, requires_grad=True)
+    tc = torch.tensor(gold["trans_code"], device=DEV, requires_grad=True)
+    pred = eg.celeba.affine_regularzier(rc, tc)
+    np.testing.assert_allclose(pred.detach().cpu().numpy(), gold["pred"], rtol=2e-4, atol=2e-5)
+    (pred * torch.tensor(gold["w"], device=DEV)).sum().backward()
+    np.testing.assert_allclose(rc.grad.cpu().numpy()[:, :5], gold["d_real"][:, :5], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(tc.grad.cpu().numpy()[:, :5], gold["d_trans"][:, :5], rtol=2e-3, atol=2e-4)
+    assert float(rc.grad[:, 5:].abs().max()) == 0.0
+
+
+def test_loss_heads():
+    g = torch.Generator().manual_seed(9)
+    B = 37
+    o = (torch.randn(B, 19, generator=g) * 2).requires_grad_(True)
+    code = torch.rand(B, 8, generator=g) * 2 - 1
+    labels = torch.randint(0, 10, (B,), generator=g)
+    od = o.detach().to(DEV)
+    loss = torch.zeros(4, device=DEV)
+    dout = torch.full((B, 19), 7.0, device=DEV)
+    # BCE(sigmoid(o0), 1) * 0.5
+    l = 0.5 * F.binary_cross_entropy(torch.sigmoid(o[:, 0]), torch.ones(B))
+    (gr,) = torch.autograd.grad(l, o)
+    ops.loss_bce_sigmoid(od, 19, 0, B, 1.0, 0.5, loss[0:1], dout)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(loss[0].cpu(), l.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dout.cpu(), gr, rtol=1e-4, atol=1e-7)
+    # info loss: CE(softmax(o[9:19])) + MSE(o[1:9], code)
+    l = F.cross_entropy(F.softmax(o[:, 9:19], dim=1), labels) + F.mse_loss(o[:, 1:9], code)
+    (gr,) = torch.autograd.grad(l, o)
+    ops.loss_mse(od, 19, 1, 8, B, code.to(DEV), 8, 0.0, 1.0, loss[1:2], dout)
+    ops.loss_ce_softmaxed(od, 19, 9, 10, B, labels.to(DEV), 1.0, loss[1:2], dout)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(loss[1].cpu(), l.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dout.cpu(), gr, rtol=1e-4, atol=1e-7)
