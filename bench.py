@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Headline benchmark: imgs/sec of one full EAD-GAN CelebA train iteration (G adversarial step + D step + info/affine
+step, three Adams; celebA/EAD-GAN_celebA.py:299-401) at 64x64, batch 128 per GPU, bf16 MFMA compute with fp32 master
+weights, synthetic data, on N MI355X of one node (weak scaling, RCCL all-reduce of the gradient arenas).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     : dominant kernel (by time) of the step, algorithmic FLOPs per launch / measured launch duration
+                 (HIP events on the launch stream, in this process) against the dense bf16 MFMA peak;
+  cpu_baseline : the CPU oracle (oracle/celeba_oracle.py, a port pinned to the reference) timed on the host cores
+                 on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+GFLOP_PER_IMG = 18.80          # algorithmic FLOPs per image per iteration, dead work excluded
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="images per GPU per step (BASELINE config: 128)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying one hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def roofline_pass(eg, trainer, dtype):
+    """Replays every implicit-GEMM launch of one iteration, each bracketed by HIP events on the launch stream, and
+    returns the per-kernel table + the dominant kernel's roofline object."""
+    ops = eg.ops
+    ops.RECORDER = []
+    trainer._step_body()
+    torch.cuda.synchronize()
+    rec, ops.RECORDER = ops.RECORDER, None
+    REP = 5
+    table = {}
+    for label, flops, fn in rec:
+        fn()                                            # warm
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(REP):
+            fn()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / REP
+        t = table.setdefault(label, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        t["launches"] += 1
+        t["ms"] += ms
+        t["flops"] += flops
+    if not table:
+        return None, table
+    dom = max(table, key=lambda k: table[k]["ms"])
+    d = table[dom]
+    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+    achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": None, "launches_per_step": d["launches"],
+            "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3)}
+    return roof, table
+
+
+def cpu_baseline(B, steps):
+    from oracle import celeba_oracle as co          # the checker, timed as the reported CPU baseline
+    torch.set_num_threads(min(16, os.cpu_count() or 1))   # the GPU box's CPU share for one GPU is 16 cores
+    orc = co.CelebAOracle(seed=0)
+    rng = np.random.RandomState(0)
+    real = co.synthetic_real(B, seed=1)
+    times = []
+    for i in range(steps + 1):
+        z, code, labels = co.draw_step_inputs(rng, B)
+        t0 = time.perf_counter()
+        orc.train_step(real, z, code, labels)
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))
+    return {"value": round(B / t, 2), "unit": "imgs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} timed iterations of the same workload (B={B}, fp32, torch-CPU oracle) after 1 warm-up; median"}
+
+
+def main():
+    a = parse()
+    eg = importlib.import_module("ead-gan_amd")
+    rank, world, local = eg.dp.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B = a.batch
+
+    torch.manual_seed(0)                                 # identical replicas on every rank
+    G = eg.celeba.Generator(dtype=a.dtype).to(dev)
+    D = eg.celeba.Discriminator(dtype=a.dtype).to(dev)
+    allreduce = eg.dp.GradAllReduce(world) if world > 1 else None
+    tr = eg.celeba.CelebATrainer(G, D, B, dtype=a.dtype, allreduce=allreduce)
+
+    # synthetic inputs resident in HBM before the timed region: per-rank shard of the global batch
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    real = torch.rand((B, 3, 64, 64), device=dev, generator=g) * 2 - 1
+    z = torch.randn((B, 200), device=dev, generator=g)
+    code = torch.rand((B, 8), device=dev, generator=g) * 2 - 1
+    labels = torch.randint(0, 10, (B,), device=dev, generator=g)
+    tr.load_inputs(real, z, code, labels)
+
+    use_graph = (not a.no_graph) and world == 1
+    tr.step_resident()                                   # first eager iteration: loads kernels, sizes workspaces
+    if use_graph:
+        tr.capture()
+    for _ in range(max(a.warmup - 1, 0)):
+        tr.step_resident()
+    eg.dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.step_resident()
+    torch.cuda.synchronize()
+    eg.dp.barrier()
+    dt = time.perf_counter() - t0
+    dt = eg.dp.max_over_ranks(dt, dev)
+    losses = tr.losses.tolist()
+
+    roof = table = None
+    if not a.no_roofline and rank == 0:
+        roof, table = roofline_pass(eg, tr, a.dtype)
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(B, a.cpu_steps)
+
+    if rank == 0:
+        ips = B * world * a.steps / dt
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        out = {
+            "metric": "imgs/sec per G+D+E train step, CelebA 64x64 bs=128",
+            "value": round(ips, 1), "unit": "imgs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"EAD-GAN CelebA 64x64x3 full train iteration (G adv + D + info/affine, 3 Adams), batch {B}/GPU, "
+                                   f"{'hipGraph replay' if use_graph else 'eager launches'}, data-parallel x{world}",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "whole_step_mfma_frac": round(ips / world * GFLOP_PER_IMG / 1e3 / peak, 4),
+            "roofline": roof, "cpu_baseline": cpu,
+            "final_losses": {"g": round(losses[0], 4), "d": round(losses[1], 4), "info": round(losses[2], 4)},
+        }
+        if table:
+            out["kernel_table"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in table.items()}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

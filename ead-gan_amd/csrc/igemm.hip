@@ -293,6 +293,14 @@ static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
         launch_nt_cfg<T, 128, 128, 2, 2>(p, nphase, st);
 }
 
+/* which igemm_nt instantiation a (M, N, nphase) problem is dispatched to: returns BM*1000 + BN */
+extern "C" int eg_igemm_nt_tile(int M, int N, int nphase) {
+    if (N <= 16) return 128 * 1000 + 16;
+    if (N <= 32) return 128 * 1000 + 32;
+    if (N <= 64 || (long long)cdiv(M, 128) * cdiv(N, 128) * nphase < 192) return 128 * 1000 + 64;
+    return 128 * 1000 + 128;
+}
+
 static void fill_epilogue(NtParams& p, const eg_epilogue* ep) {
     p.bias = ep ? ep->bias : nullptr;
     p.bias_mod = ep ? ep->bias_mod : 0;

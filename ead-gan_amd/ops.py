@@ -70,12 +70,41 @@ def pack_strided(dtype, w, wp, N, K, Kpad, n_div, s_hi, s_lo, s_k):
     lib().call("eg_pack_strided", dtype, _p(w), _p(wp), N, K, Kpad, n_div, s_hi, s_lo, s_k, _stream())
 
 
+# Optional launch recorder (bench.py's roofline pass): when set to a list, every implicit-GEMM launch appends
+# (kernel label, algorithmic FLOPs, replay closure).  Never set on the training path.
+RECORDER = None
+
+
+def _out_hw(c):
+    return ((c.H << c.up) + 2 * c.pad - c.k) // c.stride + 1, ((c.W << c.up) + 2 * c.pad - c.k) // c.stride + 1
+
+
+def _record(kind, c, dtype, fn):
+    oh, ow = _out_hw(c)
+    M = c.B * oh * ow
+    flops = 2.0 * M * c.Cout * c.Cin * c.k * c.k
+    tname = "float" if dtype == EG_F32 else "bf16"
+    if kind == "tn":
+        label = f"igemm_tn_kernel<{tname}>"
+    else:
+        N, nph = (c.Cout, 1) if kind == "fwd" else (c.Cin, c.stride * c.stride)
+        tile = lib().query("eg_igemm_nt_tile", M, N, nph)
+        label = f"igemm_nt_kernel<{tname},{tile // 1000},{tile % 1000}>"
+    RECORDER.append((label, flops, fn))
+
+
 def conv_fwd(c, dtype, X, wp, Y, ep=None):
-    lib().call("eg_conv_fwd", ctypes.byref(c), dtype, _p(X), _p(wp), _p(Y), ctypes.byref(ep) if ep is not None else None, _stream())
+    args = ("eg_conv_fwd", ctypes.byref(c), dtype, _p(X), _p(wp), _p(Y), ctypes.byref(ep) if ep is not None else None)
+    lib().call(*args, _stream())
+    if RECORDER is not None:
+        _record("fwd", c, dtype, lambda keep=(c, ep, X, wp, Y): lib().call(*args, _stream()))
 
 
 def conv_bwd_data(c, dtype, dY, wp, dX, ep=None):
-    lib().call("eg_conv_bwd_data", ctypes.byref(c), dtype, _p(dY), _p(wp), _p(dX), ctypes.byref(ep) if ep is not None else None, _stream())
+    args = ("eg_conv_bwd_data", ctypes.byref(c), dtype, _p(dY), _p(wp), _p(dX), ctypes.byref(ep) if ep is not None else None)
+    lib().call(*args, _stream())
+    if RECORDER is not None:
+        _record("bwd", c, dtype, lambda keep=(c, ep, dY, wp, dX): lib().call(*args, _stream()))
 
 
 def conv_wgrad_ws_bytes(c, dtype):
@@ -84,7 +113,10 @@ def conv_wgrad_ws_bytes(c, dtype):
 
 def conv_wgrad(c, dtype, X, dY, slab) -> int:
     ns = ctypes.c_int(0)
-    lib().call("eg_conv_wgrad", ctypes.byref(c), dtype, _p(X), _p(dY), _p(slab), ctypes.addressof(ns), _stream())
+    args = ("eg_conv_wgrad", ctypes.byref(c), dtype, _p(X), _p(dY), _p(slab), ctypes.addressof(ns))
+    lib().call(*args, _stream())
+    if RECORDER is not None:
+        _record("tn", c, dtype, lambda keep=(c, ns, X, dY, slab): lib().call(*args, _stream()))
     return ns.value
 
 

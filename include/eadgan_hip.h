@@ -71,6 +71,8 @@ int eg_conv_fwd(const eg_conv* c, int dtype, const void* X, const void* wp_fwd, 
 /* dX = conv^T(dY, W)  (== ConvTranspose2d forward); dX has spatial dims (H<<up, W<<up) */
 int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, const void* wp_bwd, void* dX,
                      const eg_epilogue* ep, eg_stream_t s);
+/* tile (BM*1000+BN) of the igemm_nt instantiation a problem is dispatched to (profiling labels only) */
+int eg_igemm_nt_tile(int M, int N, int nphase);
 /* dW partial slabs: slab[split][Cout][k*k][Cin] fp32.  Returns the split count through *nsplit. */
 size_t eg_conv_wgrad_ws_bytes(const eg_conv* c, int dtype);
 int eg_conv_wgrad(const eg_conv* c, int dtype, const void* X, const void* dY, float* slab, int* nsplit,

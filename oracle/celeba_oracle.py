@@ -202,14 +202,14 @@ def affine_regularzier(real_code, trans_code):
 class CelebAOracle:
     """Holds G/D state + the three Adams (:211-217: lr 1e-3 / 2e-4 / 2e-4, betas (.5,.999))."""
 
-    def __init__(self, seed=0, G=None, D=None):
+    def __init__(self, seed=0, G=None, D=None, lrs=(1e-3, 2e-4, 2e-4)):
         if G is None:
             G, D = init_state(seed)
         self.G, self.D = G, D
         gp, dp = trainable(G), trainable(D)
-        self.opt_G = torch.optim.Adam(gp, lr=1e-3, betas=(0.5, 0.999))
-        self.opt_D = torch.optim.Adam(dp, lr=2e-4, betas=(0.5, 0.999))
-        self.opt_info = torch.optim.Adam(gp + dp, lr=2e-4, betas=(0.5, 0.999))
+        self.opt_G = torch.optim.Adam(gp, lr=lrs[0], betas=(0.5, 0.999))
+        self.opt_D = torch.optim.Adam(dp, lr=lrs[1], betas=(0.5, 0.999))
+        self.opt_info = torch.optim.Adam(gp + dp, lr=lrs[2], betas=(0.5, 0.999))
 
     def train_step(self, real_imgs, z, code, labels):
         """One loop body, EAD-GAN_celebA.py:299-401.  ``labels`` int64 [B]; returns dict of floats."""
