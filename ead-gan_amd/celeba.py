@@ -62,7 +62,11 @@ class _GenEngine:
         # L1..L3: ConvTranspose2d(k4,s2,p1) in conv view (Cout_cv = ConvT in-channels)
         self.mid = [ConvRec(dtype, B, s * 2 ** (i + 1), s * 2 ** (i + 1), W[i + 1], W[i], 4, 2, 1, device=dev, ws=ws) for i in range(3)]
         self.l4 = ConvRec(dtype, B, s * 16, s * 16, gen.channels, W[3], 4, 2, 1, device=dev, want_fwd=False, want_wgrad=False, ws=ws)
-        ws.need_slab(ops.conv_img_wgrad_ws_bytes(B, gen.channels, W[3], 4))
+        # the same layer seen from the image side as a 1x1 conv over im2col patches (K = C*16): input/weight gradients on MFMA
+        self.kp = gen.channels * 16
+        self.l4p = ConvRec(dtype, B, s * 8, s * 8, self.kp, W[3], 1, 1, 0, device=dev, want_bwd=False, ws=ws)
+        self.patches = torch.empty(B * (s * 8) ** 2, self.kp, device=dev, dtype=tdt)
+        ws.need_small(B * gen.channels)
         # activations
         e = lambda *shape, dt=tdt: torch.empty(shape, device=dev, dtype=dt)
         self.inp = e(B, self.cpad)
@@ -93,6 +97,7 @@ class _GenEngine:
         for i, idx in enumerate((1, 4, 7)):
             self.mid[i].pack(self._p(idx, "weight"))
         self.l4.pack(self._p(10, "weight"))
+        ops.pack_strided(dt, self._p(10, "weight"), self.l4p.wp_fwd, G_WIDTHS[3], self.kp, self.l4p.Kpad_fwd, 1, self.kp, 0, 1)
 
     def forward(self, noise, labels, code):
         dt, B, W = self.dtype, self.B, G_WIDTHS
@@ -116,14 +121,13 @@ class _GenEngine:
         dt, B, W, ws, gen = self.dtype, self.B, G_WIDTHS, self.ws, self.gen
         gof = lambda name: gen.arena.grad_of(name, grad)
         C, S = gen.channels, self.img.shape[-1]
-        # tanh
-        ops.act_grad_mul_f32(dimg, self.img, self.dimg_z, ACT_TANH)
-        # L4 = ConvTranspose2d(128 -> C): weight grad / bias grad / input grad through the image-side kernels
-        w4 = self._p(10, "weight")
-        ops.conv_img_wgrad(dt, self.a[2], self.dimg_z, ws.slab, B, C, S, S, W[3], 4, 2, 1)
-        ops.flat_reduce(ws.slab, B, w4.numel(), gof("conv_blocks.10.weight"))
-        ops.bias_grad_nchw(self.dimg_z, B, C, S * S, gof("conv_blocks.10.bias"))
-        ops.conv_img_fwd(dt, self.dimg_z, w4, self.da[2], B, C, S, S, W[3], 4, 2, 1, None)
+        # tanh backward fused with the bias gradient of the last ConvTranspose2d
+        ops.act_grad_mul_bias_nchw(dimg, self.img, self.dimg_z, B, C, S * S, ACT_TANH, 0.0, ws.small, gof("conv_blocks.10.bias"))
+        # L4 = ConvTranspose2d(128 -> C): weight / input gradients as 1x1-conv GEMMs over im2col patches of d(img)
+        ops.im2col_img(dt, self.dimg_z, self.patches, B, C, S, S, 4, 2, 1, self.kp)
+        ns = ops.conv_wgrad(self.l4p.c, dt, self.patches, self.a[2], ws.slab)
+        ops.wgrad_reduce(ws.slab, ns, W[3], W[3], self.kp, 1, gof("conv_blocks.10.weight"))
+        ops.conv_fwd(self.l4p.c, dt, self.patches, self.l4p.wp_fwd, self.da[2], None)
         # L3..L1
         for i, idx in ((2, 7), (1, 4), (0, 1)):
             r = self.mid[i]
@@ -245,6 +249,7 @@ class _DTape:
         tdt = ops.torch_dtype(dtype)
         W = D_WIDTHS
         self.img = None
+        self.patches = torch.empty(B * (S // 2) ** 2, C * 16, device=dev, dtype=tdt)      # im2col of the input image
         self.a = [torch.empty(B, S >> (i + 1), S >> (i + 1), W[i], device=dev, dtype=tdt) for i in range(4)]
         self.out = torch.empty(B, 19, device=dev, dtype=torch.float32)
         kd = [C * 16] + [W[i] * 16 for i in range(3)]
@@ -264,9 +269,12 @@ class _DiscEngine:
         self.C, self.S = C, S
         self.nout = disc.n_out
         self.l1 = ConvRec(dtype, B, S, S, C, W[0], 4, 2, 1, device=dev, want_fwd=False, want_wgrad=False, ws=ws)
+        self.kp = C * 16
+        self.l1p = ConvRec(dtype, B, S // 2, S // 2, self.kp, W[0], 1, 1, 0, device=dev, want_bwd=False, ws=ws)   # image side as 1x1 conv over patches
+        self.headw = ConvRec(dtype, B, 1, 1, 16 * W[3], 32, 1, 1, 0, device=dev, want_fwd=False, want_bwd=False, ws=ws)   # head weight gradient (TN GEMM)
+        self.dout_t = torch.empty(B, 32, device=dev, dtype=ops.torch_dtype(dtype))
         self.mid = [ConvRec(dtype, B, S >> (i + 1), S >> (i + 1), W[i], W[i + 1], 4, 2, 1, device=dev, ws=ws) for i in range(3)]
         self.head = ConvRec(dtype, B, 4, 4, W[3], self.nout, 4, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
-        ws.need_slab(ops.conv_img_wgrad_ws_bytes(B, C, W[0], 4))
         ws.need_gtmp(W[0] * C * 16)
         for i in range(4):
             ws.need_small(ops.sn_ws_floats(W[i], (C if i == 0 else W[i - 1]) * 16))
@@ -281,6 +289,7 @@ class _DiscEngine:
 
     def repack(self):
         self.l1.pack(self._m(0).weight_orig)
+        ops.pack_strided(self.dtype, self._m(0).weight_orig, self.l1p.wp_fwd, D_WIDTHS[0], self.kp, self.l1p.Kpad_fwd, 1, self.kp, 0, 1)
         for i in range(3):
             self.mid[i].pack(self._m(i + 1).weight_orig)
         self.head.pack(self._m(4).weight)
@@ -298,7 +307,8 @@ class _DiscEngine:
                 tp.u[i].copy_(m.weight_u)
                 tp.v[i].copy_(m.weight_v)
         ep = lambda i: ops.epilogue(bias=self._m(i).bias, sigma=tp.sigma[i], act=ACT_LRELU, slope=LRELU_SLOPE)
-        ops.conv_img_fwd(dt, img, self._m(0).weight_orig, tp.a[0], B, self.C, self.S, self.S, W[0], 4, 2, 1, ep(0))
+        ops.im2col_img(dt, img, tp.patches, B, self.C, self.S, self.S, 4, 2, 1, self.kp)
+        ops.conv_fwd(self.l1p.c, dt, tp.patches, self.l1p.wp_fwd, tp.a[0], ep(0))
         for i in range(3):
             r = self.mid[i]
             ops.conv_fwd(r.c, dt, tp.a[i], r.wp_fwd, tp.a[i + 1], ep(i + 1))
@@ -313,7 +323,10 @@ class _DiscEngine:
         gof = lambda name: disc.arena.grad_of(name, grad)
         K = 16 * W[3]
         if need_wgrad:
-            ops.dense_small_wgrad(dt, dout, tp.a[3], gof("main.8.weight"), gof("main.8.bias"), B, K, self.nout, W[3], 16)
+            ops.cast_pad(dt, dout, self.dout_t, B, self.nout, 32)
+            ns = ops.conv_wgrad(self.headw.c, dt, tp.a[3], self.dout_t, ws.slab)
+            ops.wgrad_reduce(ws.slab, ns, 32, self.nout, W[3], 16, gof("main.8.weight"))
+            ops.dense_small_bgrad(dout, gof("main.8.bias"), B, self.nout)
         ops.dense_small_bwd(dt, dout, self.head.wp_fwd, tp.a[3], self.dz[3], B, K, self.head.Kpad_fwd, self.nout, ACT_LRELU, LRELU_SLOPE)
         for i in (3, 2, 1):
             r = self.mid[i - 1]
@@ -328,9 +341,9 @@ class _DiscEngine:
                               ops.epilogue(sigma=tp.sigma[i], mask=tp.a[i - 1], mask_act=ACT_LRELU, mask_slope=LRELU_SLOPE))
         m = self._m(0)
         if need_wgrad:
-            ops.conv_img_wgrad(dt, self.dz[0], tp.img, ws.slab, B, self.C, self.S, self.S, W[0], 4, 2, 1)
-            ops.flat_reduce_sn(ws.slab, B, W[0], self.C * 16, m.weight_orig, tp.sigma[0], tp.u[0], tp.v[0], ws.gtmp, ws.partials,
-                               gof("main.0.weight_orig"))
+            ns = ops.conv_wgrad(self.l1p.c, dt, tp.patches, self.dz[0], ws.slab)
+            ops.wgrad_reduce_sn(self.l1p.c, ws.slab, ns, m.weight_orig, tp.sigma[0], tp.u[0], tp.v[0], ws.gtmp, ws.partials,
+                                gof("main.0.weight_orig"))
             ops.bias_grad(dt, self.dz[0], B * (self.S // 2) ** 2, W[0], ws.small, gof("main.0.bias"))
         if need_dimg:
             ops.conv_bwd_data(self.l1.c, dt, self.dz[0], self.l1.wp_bwd, self.dimg, ops.epilogue(sigma=tp.sigma[0], out_mode=OUT_NCHW_F32))

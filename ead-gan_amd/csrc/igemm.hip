@@ -345,38 +345,41 @@ extern "C" int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, con
 // ------------------------------------------------------------------------------------------------
 // weight packing: fp32 master [Cout][Cin][k][k]  ->  K-contiguous dtype-T panels
 // ------------------------------------------------------------------------------------------------
+struct PackPhase { int TH, TW, kh0, kw0, K, Kpad; long long w_off; };
 struct PackParams {
     const float* w;
     void* wp;
     int Nrows;           // rows of the packed panel
     int Crow;            // channels per tap in a row
-    int TH, TW, kh0, khs, kw0, kws, k;
-    int K, Kpad;
+    int khs, kws, k;
     long long n_stride, c_stride;   // master strides of the (row, channel) indices
-    long long w_off;
+    int nphase;
+    PackPhase ph[4];
 };
 
 template <typename T>
 __global__ void pack_kernel(const PackParams p) {
-    const long long total = (long long)p.Nrows * p.Kpad;
+    const PackPhase ph = p.ph[blockIdx.y];
+    const long long total = (long long)p.Nrows * ph.Kpad;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int n = (int)(i / p.Kpad), kk = (int)(i % p.Kpad);
+        const int n = (int)(i / ph.Kpad), kk = (int)(i % ph.Kpad);
         float v = 0.f;
-        if (kk < p.K) {
+        if (kk < ph.K) {
             const int t = kk / p.Crow, c = kk % p.Crow;
-            const int ty = t / p.TW, tx = t % p.TW;
-            const int kh = p.kh0 + ty * p.khs, kw = p.kw0 + tx * p.kws;
+            const int ty = t / ph.TW, tx = t % ph.TW;
+            const int kh = ph.kh0 + ty * p.khs, kw = ph.kw0 + tx * p.kws;
             v = p.w[n * p.n_stride + c * p.c_stride + kh * p.k + kw];
         }
-        Elt<T>::st(reinterpret_cast<T*>(p.wp) + p.w_off + i, v);
+        Elt<T>::st(reinterpret_cast<T*>(p.wp) + ph.w_off + i, v);
     }
 }
 
 static void launch_pack(const PackParams& p, int dtype, hipStream_t st) {
-    const long long total = (long long)p.Nrows * p.Kpad;
-    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    if (dtype == EG_F32) hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, p);
+    long long total = 0;
+    for (int i = 0; i < p.nphase; ++i) total = total > (long long)p.Nrows * p.ph[i].Kpad ? total : (long long)p.Nrows * p.ph[i].Kpad;
+    const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    if (dtype == EG_F32) hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks, p.nphase), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks, p.nphase), dim3(256), 0, st, p);
 }
 
 extern "C" size_t eg_pack_fwd_elems(const eg_conv* c, int dtype) {
@@ -397,30 +400,35 @@ extern "C" int eg_pack_fwd(const eg_conv* c, int dtype, const float* w, void* wp
     PackParams p;
     memset(&p, 0, sizeof(p));
     p.w = w; p.wp = wp; p.Nrows = c->Cout; p.Crow = c->Cin;
-    p.TH = p.TW = c->k; p.kh0 = p.kw0 = 0; p.khs = p.kws = 1; p.k = c->k;
-    p.K = c->k * c->k * c->Cin; p.Kpad = round_up(p.K, bk_of(dtype));
+    p.khs = p.kws = 1; p.k = c->k;
     p.n_stride = (long long)c->Cin * c->k * c->k; p.c_stride = c->k * c->k;
+    p.nphase = 1;
+    p.ph[0].TH = p.ph[0].TW = c->k; p.ph[0].kh0 = p.ph[0].kw0 = 0;
+    p.ph[0].K = c->k * c->k * c->Cin; p.ph[0].Kpad = round_up(p.ph[0].K, bk_of(dtype)); p.ph[0].w_off = 0;
     launch_pack(p, dtype, (hipStream_t)s);
     EG_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int eg_pack_bwd(const eg_conv* c, int dtype, const float* w, void* wp, eg_stream_t s) {
-    EG_REQUIRE(c && w && wp, "eg_pack_bwd: null pointer");
+    EG_REQUIRE(c && w && wp && c->stride <= 2, "eg_pack_bwd: bad argument");
+    PackParams p;
+    memset(&p, 0, sizeof(p));
+    p.w = w; p.wp = wp; p.Nrows = c->Cin; p.Crow = c->Cout;
+    p.khs = p.kws = c->stride; p.k = c->k;
+    p.n_stride = c->k * c->k; p.c_stride = (long long)c->Cin * c->k * c->k;
     long long off = 0;
+    int n = 0;
     for (int ry = 0; ry < c->stride; ++ry)
         for (int rx = 0; rx < c->stride; ++rx) {
             const BwdAxis ay = bwd_axis(c, ry), ax = bwd_axis(c, rx);
-            PackParams p;
-            memset(&p, 0, sizeof(p));
-            p.w = w; p.wp = wp; p.Nrows = c->Cin; p.Crow = c->Cout;
-            p.TH = ay.T; p.TW = ax.T > 0 ? ax.T : 1; p.kh0 = ay.k0; p.kw0 = ax.k0; p.khs = p.kws = c->stride; p.k = c->k;
-            p.K = ay.T * ax.T * c->Cout; p.Kpad = round_up(p.K > 0 ? p.K : 1, bk_of(dtype));
-            p.n_stride = c->k * c->k; p.c_stride = (long long)c->Cin * c->k * c->k;
-            p.w_off = off;
-            launch_pack(p, dtype, (hipStream_t)s);
-            off += (long long)c->Cin * p.Kpad;
+            PackPhase& f = p.ph[n++];
+            f.TH = ay.T; f.TW = ax.T > 0 ? ax.T : 1; f.kh0 = ay.k0; f.kw0 = ax.k0;
+            f.K = ay.T * ax.T * c->Cout; f.Kpad = round_up(f.K > 0 ? f.K : 1, bk_of(dtype)); f.w_off = off;
+            off += (long long)c->Cin * f.Kpad;
         }
+    p.nphase = n;
+    launch_pack(p, dtype, (hipStream_t)s);
     EG_LAUNCH_CHECK();
     return 0;
 }
@@ -648,7 +656,7 @@ static void tn_plan(const eg_conv* c, int* nsplit, int* rps) {
     long long want = base >= 768 ? 1 : (768 + base - 1) / base;
     long long cap = M / 256 > 0 ? M / 256 : 1;
     if (want > cap) want = cap;
-    if (want > 64) want = 64;
+    if (want > 128) want = 128;
     int r = round_up((int)((M + want - 1) / want), 32);
     *rps = r;
     *nsplit = cdiv(M, r);
@@ -780,40 +788,69 @@ extern "C" int eg_wgrad_reduce_sn(const eg_conv* c, const float* slab, int nspli
 // ------------------------------------------------------------------------------------------------
 // bias gradient: column sums of a [rows][N] tensor (two deterministic stages)
 // ------------------------------------------------------------------------------------------------
-#define EG_BG_RPB 512   // rows per block
+#define EG_BG_RPB 256   // rows per block
 
+// block = 256 threads = (N/VEC chunk columns) x (row lanes); 16-byte loads; LDS combine of the row lanes
 template <typename T>
-__global__ void colsum_partial_kernel(const T* __restrict__ x, int rows, int N, float* __restrict__ partials) {
-    __shared__ float sm[4][64];
-    const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int rows, int N, float* __restrict__ partials) {
+    constexpr int VEC = Elt<T>::VEC;
+    __shared__ float sm[256 * VEC];
+    const int cpr = N / VEC;                       // chunks per row (host guarantees cpr <= 256 and 256 % cpr == 0 via tiling in x)
+    const int ccols = cpr < 256 ? cpr : 256;
+    const int lanes = 256 / ccols;
+    const int cj = threadIdx.x % ccols, rl = threadIdx.x / ccols;
+    const int chunk = blockIdx.x * ccols + cj;
     const int r0 = blockIdx.y * EG_BG_RPB, r1 = min(rows, r0 + EG_BG_RPB);
-    float a = 0.f;
-    if (col < N)
-        for (int r = r0 + rl; r < r1; r += 4) a += Elt<T>::ld(x + (size_t)r * N + col);
-    sm[rl][threadIdx.x & 63] = a;
+    float a[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) a[j] = 0.f;
+    if (chunk < cpr)
+        for (int r = r0 + rl; r < r1; r += lanes) {
+            const uint4 v = *reinterpret_cast<const uint4*>(x + (size_t)r * N + (size_t)chunk * VEC);
+            const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) a[j] += Elt<T>::ld(e + j);
+        }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sm[threadIdx.x * VEC + j] = a[j];
     __syncthreads();
-    if (rl == 0 && col < N) partials[(size_t)blockIdx.y * N + col] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    if (rl == 0 && chunk < cpr) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float t = 0.f;
+            for (int l = 0; l < lanes; ++l) t += sm[(l * ccols + cj) * VEC + j];
+            partials[(size_t)blockIdx.y * N + (size_t)chunk * VEC + j] = t;
+        }
+    }
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ partials, int nrb, int N, int nb, float* __restrict__ gb) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+// gb[j] += scale * sum_{n == j mod nb} sum_r partials[r][n]; one wave per output j
+__global__ void colsum_final_kernel(const float* __restrict__ partials, int nrb, int N, int nb, const float* __restrict__ scale, float* __restrict__ gb) {
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (j >= nb) return;
     float a = 0.f;
     for (int n = j; n < N; n += nb)
-        for (int r = 0; r < nrb; ++r) a += partials[(size_t)r * N + n];
-    gb[j] += a;
+        for (int r = lane; r < nrb; r += 64) a += partials[(size_t)r * N + n];
+    a = wave_sum(a);
+    if (lane == 0) gb[j] += a * (scale ? scale[0] : 1.f);
 }
 
 extern "C" size_t eg_bias_grad_ws_floats(int rows, int N) { return (size_t)cdiv(rows, EG_BG_RPB) * N; }
 
 extern "C" int eg_bias_grad(int dtype, const void* dY, int rows, int N, int bias_mod, float* partials, float* gb, eg_stream_t s) {
     EG_REQUIRE(dY && partials && gb && rows > 0 && N > 0, "eg_bias_grad: bad argument");
+    const int vecw = dtype == EG_F32 ? 4 : 8;
+    EG_REQUIRE(N % vecw == 0, "eg_bias_grad: N must be a multiple of the 16-byte vector width");
+    const int cpr = N / vecw;
+    const int ccols = cpr < 256 ? cpr : 256;
+    EG_REQUIRE(256 % ccols == 0, "eg_bias_grad: N/vec must divide 256 or be a multiple of it");
     const int nrb = cdiv(rows, EG_BG_RPB);
-    dim3 grid(cdiv(N, 64), nrb);
+    dim3 grid(cdiv(cpr, ccols), nrb);
     if (dtype == EG_F32) hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)dY, rows, N, partials);
     else hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)dY, rows, N, partials);
     const int nb = bias_mod > 0 ? bias_mod : N;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(nb, 256)), dim3(256), 0, (hipStream_t)s, partials, nrb, N, nb, gb);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(nb, 4)), dim3(256), 0, (hipStream_t)s, partials, nrb, N, nb, (const float*)nullptr, gb);
     EG_LAUNCH_CHECK();
     return 0;
 }

@@ -36,13 +36,15 @@ __global__ void bn_stats_partial_kernel(const T* __restrict__ x, int M, int C, f
     }
 }
 
+// one wave per channel: lanes combine row-block partials (Chan) in fp64, then a shuffle tree merges the lanes
 __global__ void bn_stats_final_kernel(const float* __restrict__ partial, int nrb, int C, int M, float eps, float momentum,
                                       float* running_mean, float* running_var, long long* nbt, float* save_mean, float* save_invstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && nbt) nbt[0] += 1;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
     if (c >= C) return;
     double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (int r = 0; r < nrb; ++r) {
+    for (int r = lane; r < nrb; r += 64) {
         const float* o = partial + (size_t)r * 3 * C;
         const double nb = o[c], mb = o[C + c], qb = o[2 * C + c];
         const double tot = n + nb, delta = mb - mean;
@@ -50,6 +52,19 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ partial, int nrb
         m2 += qb + delta * delta * n * nb / tot;
         n = tot;
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double n2 = __shfl_xor(n, o, 64), mean2 = __shfl_xor(mean, o, 64), m22 = __shfl_xor(m2, o, 64);
+        const double tot = n + n2;
+        if (tot > 0.0) {
+            const double delta = mean2 - mean;
+            const double nm = mean + delta * n2 / tot;
+            m2 = m2 + m22 + delta * delta * n * n2 / tot;
+            mean = nm;
+            n = tot;
+        }
+    }
+    if (lane != 0) return;
     const double var = m2 / (double)M;
     save_mean[c] = (float)mean;
     save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -92,7 +107,7 @@ extern "C" int eg_bn_fwd_train(int dtype, const void* x, void* y, int M, int C, 
     hipStream_t st = (hipStream_t)s;
     if (dtype == EG_F32) hipLaunchKernelGGL(bn_stats_partial_kernel<float>, g1, dim3(256), 0, st, (const float*)x, M, C, ws);
     else hipLaunchKernelGGL(bn_stats_partial_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)x, M, C, ws);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, ws, nrb, C, M, eps, momentum, running_mean, running_var,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, ws, nrb, C, M, eps, momentum, running_mean, running_var,
                        num_batches_tracked, save_mean, save_invstd);
     const size_t total = (size_t)M * C;
     const size_t nchunk = total / (dtype == EG_F32 ? 4 : 8);
@@ -142,13 +157,17 @@ __global__ void bn_bwd_partial_kernel(const T* __restrict__ z, const T* __restri
 }
 
 __global__ void bn_bwd_final_kernel(const float* __restrict__ partial, int nrb, int C, float* sums, float* dgamma, float* dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (c >= C) return;
     float s1 = 0.f, s2 = 0.f;
-    for (int r = 0; r < nrb; ++r) {
+    for (int r = lane; r < nrb; r += 64) {
         s1 += partial[(size_t)r * 2 * C + c];
         s2 += partial[(size_t)r * 2 * C + C + c];
     }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane != 0) return;
     sums[c] = s1;
     sums[C + c] = s2;
     if (dbeta) dbeta[c] += s1;
@@ -190,7 +209,7 @@ extern "C" int eg_bn_bwd(int dtype, const void* z, const void* da, void* dz, int
     hipStream_t st = (hipStream_t)s;
     if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_partial_kernel<float>, g1, dim3(256), 0, st, (const float*)z, (const float*)da, M, C, gamma, beta, save_mean, save_invstd, act, slope, ws);
     else hipLaunchKernelGGL(bn_bwd_partial_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)da, M, C, gamma, beta, save_mean, save_invstd, act, slope, ws);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 128)), dim3(128), 0, st, ws, nrb, C, sums, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, ws, nrb, C, sums, dgamma, dbeta);
     const size_t total = (size_t)M * C;
     const size_t nchunk = total / (dtype == EG_F32 ? 4 : 8);
     const int blocks = (int)((nchunk + 255) / 256 > 4096 ? 4096 : (nchunk + 255) / 256);

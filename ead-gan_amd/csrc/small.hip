@@ -219,6 +219,36 @@ __global__ void sn_grad_apply_kernel2(const float* __restrict__ gtmp, const floa
     }
 }
 
+// out = g * act'(a) on NCHW fp32 tensors, plus partial[b*C+c] = sum_hw out  (bias gradient of the layer that produced a)
+__global__ void act_grad_mul_rowsum_kernel(const float* __restrict__ g, const float* __restrict__ a, float* __restrict__ out, int HW, int act,
+                                           float slope, float* __restrict__ partial) {
+    __shared__ float sm[16];
+    const size_t base = (size_t)blockIdx.x * HW;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+        const float v = g[base + i] * eg_act_grad_from_out(a[base + i], act, slope);
+        out[base + i] = v;
+        acc += v;
+    }
+    const float tot = block_sum(acc, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+__global__ void rowsum_final_kernel(const float* __restrict__ partial, int B, int C, float* __restrict__ gb) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int b = 0; b < B; ++b) a += partial[b * C + c];
+    gb[c] += a;
+}
+extern "C" int eg_act_grad_mul_bias_nchw(const float* g, const float* a, float* out, int B, int C, int HW, int act, float slope, float* partial,
+                                         float* gb, eg_stream_t s) {
+    EG_REQUIRE(g && a && out && partial && gb && C <= 64, "eg_act_grad_mul_bias_nchw: bad argument");
+    hipLaunchKernelGGL(act_grad_mul_rowsum_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)s, g, a, out, HW, act, slope, partial);
+    hipLaunchKernelGGL(rowsum_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partial, B, C, gb);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
 // per-channel sum of an NCHW fp32 tensor with few channels: gb[c] += sum_{b,hw} x[b][c][hw]
 __global__ void bias_grad_nchw_kernel(const float* __restrict__ x, int B, int C, int HW, float* __restrict__ gb) {
     __shared__ float sm[16];
@@ -260,29 +290,103 @@ extern "C" int eg_flat_reduce_sn(const float* slab, int nslab, int rows, int Kdi
 }
 
 // ------------------------------------------------------------------------------------------------
+// im2col of a 1..4 channel NCHW fp32 image into K-contiguous patch rows [B*OH*OW][Kp] (dtype T), patch index
+// t = (ci*k + kh)*k + kw == the master weight order, so the first/last image-side layers run on the MFMA kernels
+// as 1x1 convolutions with K = CI*k*k (48 for CelebA) instead of scalar FMAs.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void im2col_img_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int CI, int H, int W, int k, int stride, int pad,
+                                  int OH, int OW, int K, int Kp) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int cpr = Kp / VEC;
+    const size_t total = (size_t)B * OH * OW * cpr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % cpr);
+        const size_t m = i / cpr;
+        const int ox = (int)(m % OW), oy = (int)((m / OW) % OH), b = (int)(m / ((size_t)OW * OH));
+        uint4 v;
+        T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const int t = j * VEC + q;
+            float f = 0.f;
+            if (t < K) {
+                const int kw = t % k, kh = (t / k) % k, ci = t / (k * k);
+                const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) f = img[(((size_t)b * CI + ci) * H + iy) * W + ix];
+            }
+            Elt<T>::st(e + q, f);
+        }
+        *reinterpret_cast<uint4*>(out + i * VEC) = v;
+    }
+}
+
+extern "C" int eg_im2col_img(int dtype, const float* img, void* out, int B, int CI, int H, int W, int k, int stride, int pad, int Kp,
+                             eg_stream_t s) {
+    EG_REQUIRE(img && out && Kp >= CI * k * k && Kp % (dtype == EG_F32 ? 4 : 8) == 0, "eg_im2col_img: bad argument");
+    const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+    const size_t total = (size_t)B * OH * OW * (Kp / (dtype == EG_F32 ? 4 : 8));
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    if (dtype == EG_F32) hipLaunchKernelGGL(im2col_img_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, img, (float*)out, B, CI, H, W, k, stride, pad, OH, OW, CI * k * k, Kp);
+    else hipLaunchKernelGGL(im2col_img_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, img, (bf16_t*)out, B, CI, H, W, k, stride, pad, OH, OW, CI * k * k, Kp);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// dst[r][0:n] = cast(src[r][0:n]), dst[r][n:npad] = 0   (fp32 head gradients -> MFMA operand)
+template <typename T>
+__global__ void cast_pad_kernel(const float* __restrict__ src, T* __restrict__ dst, int rows, int n, int npad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * npad) return;
+    const int r = i / npad, c = i % npad;
+    Elt<T>::st(dst + i, c < n ? src[(size_t)r * n + c] : 0.f);
+}
+extern "C" int eg_cast_pad(int dtype, const float* src, void* dst, int rows, int n, int npad, eg_stream_t s) {
+    EG_REQUIRE(src && dst && npad >= n, "eg_cast_pad: bad argument");
+    if (dtype == EG_F32) hipLaunchKernelGGL(cast_pad_kernel<float>, dim3(cdiv(rows * npad, 256)), dim3(256), 0, (hipStream_t)s, src, (float*)dst, rows, n, npad);
+    else hipLaunchKernelGGL(cast_pad_kernel<bf16_t>, dim3(cdiv(rows * npad, 256)), dim3(256), 0, (hipStream_t)s, src, (bf16_t*)dst, rows, n, npad);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // small-N dense head:  y[b][n] = sum_k x[b][k] * Wp[n][k] (+ bias[n]);  x dtype T [B][K], Wp dtype T [N][Kpad]
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void dense_small_fwd_kernel(const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ bias,
                                                               float* __restrict__ y, int K, int Kpad, int N) {
     constexpr int VEC = Elt<T>::VEC;
-    __shared__ float sm[16];
-    const int b = blockIdx.x;
+    __shared__ float part[4][64];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const T* xr = x + (size_t)b * K;
-    for (int n = 0; n < N; ++n) {
-        const T* wr = wp + (size_t)n * Kpad;
-        float a = 0.f;
+    for (int n0 = 0; n0 < N; n0 += 8) {          // 8 outputs per sweep over x: x chunks are re-read from L1/L2, W streamed once
+        float a[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) a[q] = 0.f;
         for (int k0 = threadIdx.x * VEC; k0 < K; k0 += 256 * VEC) {
             const uint4 xv = *reinterpret_cast<const uint4*>(xr + k0);
-            const uint4 wv = *reinterpret_cast<const uint4*>(wr + k0);
             const T* xe = reinterpret_cast<const T*>(&xv);
-            const T* we = reinterpret_cast<const T*>(&wv);
+            float xf[VEC];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) a += Elt<T>::ld(xe + j) * Elt<T>::ld(we + j);
+            for (int j = 0; j < VEC; ++j) xf[j] = Elt<T>::ld(xe + j);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (n0 + q < N) {
+                    const uint4 wv = *reinterpret_cast<const uint4*>(wp + (size_t)(n0 + q) * Kpad + k0);
+                    const T* we = reinterpret_cast<const T*>(&wv);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) a[q] += xf[j] * Elt<T>::ld(we + j);
+                }
+            }
         }
-        const float tot = block_sum(a, sm);
-        if (threadIdx.x == 0) y[(size_t)b * N + n] = tot + (bias ? bias[n] : 0.f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float w = wave_sum(a[q]);
+            if (lane == 0) part[wave][n0 + q < 64 ? n0 + q : 63] = w;
+        }
     }
+    __syncthreads();
+    if (threadIdx.x < N) y[(size_t)b * N + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x] + (bias ? bias[threadIdx.x] : 0.f);
 }
 
 // dx[b][k] = (sum_n dy[b][n] * Wp[n][k]) * act'(mask[b][k])
@@ -345,7 +449,7 @@ __global__ __launch_bounds__(256) void dense_small_wgrad_kernel(const float* __r
 
 extern "C" int eg_dense_small_fwd(int dtype, const void* x, const void* wp, const float* bias, float* y, int B, int K, int Kpad, int N,
                                   eg_stream_t s) {
-    EG_REQUIRE(x && wp && y && K % (dtype == EG_F32 ? 4 : 8) == 0, "eg_dense_small_fwd: bad argument");
+    EG_REQUIRE(x && wp && y && N <= 64 && K % (dtype == EG_F32 ? 4 : 8) == 0, "eg_dense_small_fwd: bad argument (N<=64)");
     if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_fwd_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)s, (const float*)x, (const float*)wp, bias, y, K, Kpad, N);
     else hipLaunchKernelGGL(dense_small_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)wp, bias, y, K, Kpad, N);
     EG_LAUNCH_CHECK();
@@ -368,6 +472,13 @@ __global__ void dense_small_bgrad_kernel(const float* dy, float* gb, int B, int 
     float a = 0.f;
     for (int b = 0; b < B; ++b) a += dy[(size_t)b * N + n];
     gb[n] += a;
+}
+
+extern "C" int eg_dense_small_bgrad(const float* dy, float* gb, int B, int N, eg_stream_t s) {
+    EG_REQUIRE(dy && gb && N <= 64, "eg_dense_small_bgrad: bad argument");
+    hipLaunchKernelGGL(dense_small_bgrad_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, dy, gb, B, N);
+    EG_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int eg_dense_small_wgrad(int dtype, const float* dy, const void* x, float* gw, float* gb, int B, int K, int N, int Cin, int taps,

@@ -4,11 +4,12 @@
 // celebA/EAD-GAN_celebA.py:211-217).  W is never divided by sigma in memory: consumers scale in their epilogue.
 #include "eg_common.h"
 
-#define SN_RB 32   // rows per block in the W^T u partial kernel
+#define SN_NRB 8   // row blocks in the W^T u partial kernel
 
 __global__ void sn_wtu_partial_kernel(const float* __restrict__ W, const float* __restrict__ u, int R, int Kd, float* __restrict__ partial) {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    const int r0 = blockIdx.y * SN_RB, r1 = min(R, r0 + SN_RB);
+    const int rb = (R + SN_NRB - 1) / SN_NRB;
+    const int r0 = blockIdx.y * rb, r1 = min(R, r0 + rb);
     if (k >= Kd) return;
     float a = 0.f;
     for (int r = r0; r < r1; ++r) a += W[(size_t)r * Kd + k] * u[r];
@@ -68,7 +69,7 @@ __global__ void sn_sigma_only_kernel(const float* __restrict__ s, const float* _
     if (threadIdx.x == 0) sigma[0] = sg;
 }
 
-extern "C" size_t eg_sn_ws_floats(int R, int Kd) { return (size_t)cdiv(R, SN_RB) * Kd + R; }
+extern "C" size_t eg_sn_ws_floats(int R, int Kd) { return (size_t)SN_NRB * Kd + R; }
 
 /* one power iteration in place on u[R], v[Kd]; writes sigma[0] and (optionally) snapshots of the updated u,v that the
  * backward of THIS forward must use (torch clones them).  training==0: u,v untouched, sigma only. */
@@ -76,7 +77,7 @@ extern "C" int eg_sn_power_iter(const float* w_orig, int R, int Kd, float* u, fl
                                 int training, float eps, eg_stream_t s) {
     EG_REQUIRE(w_orig && u && v && sigma && ws && R > 0 && Kd > 0, "eg_sn_power_iter: bad argument");
     hipStream_t st = (hipStream_t)s;
-    const int nrb = cdiv(R, SN_RB);
+    const int nrb = SN_NRB;
     float* partial = ws;
     float* sv = ws + (size_t)nrb * Kd;
     if (training) {

@@ -154,6 +154,22 @@ def conv_img_wgrad(dtype, dz, img, slab, B, CI, H, W, N, k, stride, pad):
     lib().call("eg_conv_img_wgrad", dtype, _p(dz), _p(img), _p(slab), B, CI, H, W, N, k, stride, pad, _stream())
 
 
+def im2col_img(dtype, img, out, B, CI, H, W, k, stride, pad, Kp):
+    lib().call("eg_im2col_img", dtype, _p(img), _p(out), B, CI, H, W, k, stride, pad, Kp, _stream())
+
+
+def cast_pad(dtype, src, dst, rows, n, npad):
+    lib().call("eg_cast_pad", dtype, _p(src), _p(dst), rows, n, npad, _stream())
+
+
+def act_grad_mul_bias_nchw(g, a, out, B, C, HW, act, slope, partial, gb):
+    lib().call("eg_act_grad_mul_bias_nchw", _p(g), _p(a), _p(out), B, C, HW, act, slope, _p(partial), _p(gb), _stream())
+
+
+def dense_small_bgrad(dy, gb, B, N):
+    lib().call("eg_dense_small_bgrad", _p(dy), _p(gb), B, N, _stream())
+
+
 def flat_reduce(slab, nslab, total, grad, accumulate=True):
     lib().call("eg_flat_reduce", _p(slab), nslab, total, _p(grad), int(accumulate), _stream())
 

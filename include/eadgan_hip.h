@@ -105,6 +105,14 @@ int eg_conv_img_fwd(int dtype, const float* img, const float* w_master, void* ou
 size_t eg_conv_img_wgrad_ws_bytes(int B, int CI, int N, int k);
 int eg_conv_img_wgrad(int dtype, const void* dz, const float* img, float* slab, int B, int CI, int H, int W,
                       int N, int k, int stride, int pad, eg_stream_t s);
+/* patch rows [B*OH*OW][Kp] (dtype T, K = CI*k*k in master weight order, zero padded to Kp): lets the image-side layers
+ * run on the MFMA kernels as 1x1 convolutions over Kp channels */
+int eg_im2col_img(int dtype, const float* img, void* out, int B, int CI, int H, int W, int k, int stride, int pad, int Kp,
+                  eg_stream_t s);
+int eg_cast_pad(int dtype, const float* src, void* dst, int rows, int n, int npad, eg_stream_t s);
+/* out = g * act'(a) over an NCHW fp32 tensor and gb[c] += sum_{b,hw} out  (partial: B*C floats) */
+int eg_act_grad_mul_bias_nchw(const float* g, const float* a, float* out, int B, int C, int HW, int act, float slope,
+                              float* partial, float* gb, eg_stream_t s);
 int eg_flat_reduce(const float* slab, int nslab, size_t total, float* grad, int accumulate, eg_stream_t s);
 int eg_flat_reduce_sn(const float* slab, int nslab, int rows, int Kdim, const float* w_orig, const float* sigma,
                       const float* u, const float* v, float* gtmp, float* partials, float* grad, eg_stream_t s);
@@ -118,6 +126,7 @@ int eg_dense_small_bwd(int dtype, const float* dy, const void* wp, const void* m
                        int Kpad, int N, int mask_act, float mask_slope, eg_stream_t s);
 int eg_dense_small_wgrad(int dtype, const float* dy, const void* x, float* gw, float* gb, int B, int K, int N,
                          int Cin, int taps, eg_stream_t s);
+int eg_dense_small_bgrad(const float* dy, float* gb, int B, int N, eg_stream_t s);   /* gb[n] += sum_b dy[b][n] */
 
 /* --- BatchNorm2d, training mode (celebA/EAD-GAN_celebA.py:79,83,87; MNIST/EAD-GAN_rpqmnxy.py:80,83,87,145) ----
  * x,y: [M][C] dtype T; updates running stats (momentum, unbiased var) and num_batches_tracked; fused activation */

@@ -329,3 +329,58 @@ def test_loss_heads():
     torch.cuda.synchronize()
     torch.testing.assert_close(loss[1].cpu(), l.detach(), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(dout.cpu(), gr, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_image_side_layers_via_im2col(dtype):
+    """first D conv / last G ConvTranspose gradients as 1x1-conv GEMMs over im2col patches (MFMA path)."""
+    B, CI, H, N, k, s, p = 3, 3, 64, 128, 4, 2, 1
+    g = torch.Generator().manual_seed(11)
+    img = torch.randn(B, CI, H, H, generator=g)
+    w = (torch.randn(N, CI, k, k, generator=g) * 0.2).requires_grad_(True)
+    b = torch.randn(N, generator=g)
+    OH = H // 2
+    Kp = CI * k * k
+    tdt = ops.torch_dtype(dtype)
+    patches = torch.empty(B * OH * OH, Kp, device=DEV, dtype=tdt)
+    ops.im2col_img(dtype, img.to(DEV), patches, B, CI, H, H, k, s, p, Kp)
+    want_p = F.unfold(img, k, padding=p, stride=s).transpose(1, 2).reshape(B * OH * OH, Kp)
+    torch.testing.assert_close(patches.float().cpu(), rq(want_p, dtype), rtol=0, atol=0)
+    c = ops.make_conv(B, OH, OH, Kp, N, 1, 1, 0)
+    Kpad = ops.round_up(Kp, ops.bk(dtype))
+    wp = torch.empty(N * Kpad, device=DEV, dtype=tdt)
+    ops.pack_strided(dtype, w.detach().to(DEV), wp, N, Kp, Kpad, 1, Kp, 0, 1)
+    y = torch.empty(B, OH, OH, N, device=DEV, dtype=tdt)
+    ops.conv_fwd(c, dtype, patches, wp, y, ops.epilogue(bias=b.to(DEV), act=ops.ACT_LRELU, slope=0.1))
+    want = F.leaky_relu(F.conv2d(rq(img, dtype), rq(w.detach(), dtype), b, s, p), 0.1)
+    rt, at = tol(dtype, Kp)
+    torch.testing.assert_close(nchw(y), want, rtol=rt, atol=at)
+    dz = rq(torch.randn(B, N, OH, OH, generator=g), dtype)
+    F.conv2d(rq(img, dtype), w, None, s, p).backward(dz)
+    slab = torch.empty(ops.conv_wgrad_ws_bytes(c, dtype) // 4, device=DEV)
+    ns = ops.conv_wgrad(c, dtype, patches, nhwc(dz, dtype), slab)
+    grad = torch.zeros(N, CI, k, k, device=DEV)
+    ops.wgrad_reduce(slab, ns, N, N, Kp, 1, grad)
+    torch.cuda.synchronize()
+    rt, at = tol(dtype, B * OH * OH)
+    torch.testing.assert_close(grad.cpu(), w.grad, rtol=rt, atol=at * 4)
+
+
+def test_tanh_backward_with_bias_gradient_and_cast_pad():
+    g = torch.Generator().manual_seed(12)
+    B, C, HW = 5, 3, 4096
+    a = torch.tanh(torch.randn(B, C, HW, generator=g))
+    gr = torch.randn(B, C, HW, generator=g)
+    out = torch.empty(B, C, HW, device=DEV)
+    part = torch.empty(B * C, device=DEV)
+    gb = torch.ones(C, device=DEV)
+    ops.act_grad_mul_bias_nchw(gr.to(DEV), a.to(DEV), out, B, C, HW, ops.ACT_TANH, 0.0, part, gb)
+    want = gr * (1 - a * a)
+    torch.testing.assert_close(out.cpu(), want, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(gb.cpu() - 1, want.sum(dim=(0, 2)), rtol=1e-4, atol=1e-3)
+    src = torch.randn(7, 19, generator=g)
+    for dtype in DTYPES:
+        dst = torch.full((7, 32), 3.0, device=DEV).to(ops.torch_dtype(dtype))
+        ops.cast_pad(dtype, src.to(DEV), dst, 7, 19, 32)
+        torch.testing.assert_close(dst.float().cpu()[:, :19], rq(src, dtype), rtol=0, atol=0)
+        assert float(dst.float().abs()[:, 19:].max()) == 0.0
