@@ -363,7 +363,7 @@ def test_image_side_layers_via_im2col(dtype):
     ops.wgrad_reduce(slab, ns, N, N, Kp, 1, grad)
     torch.cuda.synchronize()
     rt, at = tol(dtype, B * OH * OH)
-    torch.testing.assert_close(grad.cpu(), w.grad, rtol=rt, atol=at * 4)
+    torch.testing.assert_close(grad.cpu(), w.grad, rtol=rt * 5, atol=at * math.sqrt(B * OH * OH) / 4)   # 3072-term fp32 sums
 
 
 def test_tanh_backward_with_bias_gradient_and_cast_pad():
