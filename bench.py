@@ -55,7 +55,8 @@ def roofline_pass(eg, trainer, dtype):
     rec, ops.RECORDER = ops.RECORDER, None
     REP = 5
     table = {}
-    for label, flops, fn in rec:
+    detail = {}
+    for label, flops, fn, shape in rec:
         fn()                                            # warm
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -68,6 +69,12 @@ def roofline_pass(eg, trainer, dtype):
         t["launches"] += 1
         t["ms"] += ms
         t["flops"] += flops
+        d = detail.setdefault((label, shape), [0, 0.0, flops])
+        d[0] += 1
+        d[1] += ms
+    if os.environ.get("EG_BENCH_DETAIL"):
+        for (label, shape), (n, ms, fl) in sorted(detail.items(), key=lambda kv: -kv[1][1]):
+            print(f"# {label:34s} {shape:44s} x{n:2d}  {ms / n * 1e3:8.1f} us/launch  {fl / (ms / n * 1e-3) / 1e12:7.1f} TF/s  total {ms:6.3f} ms", file=sys.stderr)
     if not table:
         return None, table
     dom = max(table, key=lambda k: table[k]["ms"])

@@ -241,47 +241,55 @@ class _GenFn(torch.autograd.Function):
 # ================================================================================================
 # Discriminator / Q network
 # ================================================================================================
-class _DTape:
-    """Everything one discriminator forward must keep for its backward (sigma/u/v are per-forward:
-    torch's hook clones u and v after the power iteration)."""
-
-    def __init__(self, B, dtype, dev, C, S):
-        tdt = ops.torch_dtype(dtype)
-        W = D_WIDTHS
-        self.img = None
-        self.patches = torch.empty(B * (S // 2) ** 2, C * 16, device=dev, dtype=tdt)      # im2col of the input image
-        self.a = [torch.empty(B, S >> (i + 1), S >> (i + 1), W[i], device=dev, dtype=tdt) for i in range(4)]
-        self.out = torch.empty(B, 19, device=dev, dtype=torch.float32)
-        kd = [C * 16] + [W[i] * 16 for i in range(3)]
-        self.sigma = [torch.empty(1, device=dev, dtype=torch.float32) for _ in range(4)]
-        self.u = [torch.empty(W[i], device=dev, dtype=torch.float32) for i in range(4)]
-        self.v = [torch.empty(kd[i], device=dev, dtype=torch.float32) for i in range(4)]
-
-
 class _DiscEngine:
-    NT = 3     # tapes alive at once: the info step runs three forwards before one backward
+    """Static-shape forward/backward of the discriminator for up to NT "tapes" (independent forwards, each with its
+    own spectral-norm power iteration).  D has no BatchNorm, so the tapes of one sub-step are batched along M into
+    single launches: epilogues pick 1/sigma per tape, ONE weight-gradient GEMM runs over all tapes on gradients that
+    already carry 1/sigma_tape (dzs = dz/sigma), and the rank-1 spectral-norm terms  -<G_t,W>/sigma_t^2 u_t v_t^T
+    are added by a single-pass reduction whose coefficients come from activations
+    (<G_t,W>/sigma_t^2 = sum dzs_t * (z_t - bias)), never from a second sweep over the weights."""
+
+    NT = 3     # the info step runs three forwards before one backward (celebA/EAD-GAN_celebA.py:380-388)
 
     def __init__(self, disc: "Discriminator", B: int, dtype: int):
         self.disc, self.B, self.dtype = disc, B, dtype
         dev = disc.arena.flat.device
         self.ws = ws = Workspace.get(dev)
-        W, C, S = D_WIDTHS, disc.channels, disc.img_size
+        W, C, S, NT = D_WIDTHS, disc.channels, disc.img_size, self.NT
         self.C, self.S = C, S
         self.nout = disc.n_out
-        self.l1 = ConvRec(dtype, B, S, S, C, W[0], 4, 2, 1, device=dev, want_fwd=False, want_wgrad=False, ws=ws)
-        self.kp = C * 16
-        self.l1p = ConvRec(dtype, B, S // 2, S // 2, self.kp, W[0], 1, 1, 0, device=dev, want_bwd=False, ws=ws)   # image side as 1x1 conv over patches
-        self.headw = ConvRec(dtype, B, 1, 1, 16 * W[3], 32, 1, 1, 0, device=dev, want_fwd=False, want_bwd=False, ws=ws)   # head weight gradient (TN GEMM)
-        self.dout_t = torch.empty(B, 32, device=dev, dtype=ops.torch_dtype(dtype))
-        self.mid = [ConvRec(dtype, B, S >> (i + 1), S >> (i + 1), W[i], W[i + 1], 4, 2, 1, device=dev, ws=ws) for i in range(3)]
-        self.head = ConvRec(dtype, B, 4, 4, W[3], self.nout, 4, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
-        ws.need_gtmp(W[0] * C * 16)
-        for i in range(4):
-            ws.need_small(ops.sn_ws_floats(W[i], (C if i == 0 else W[i - 1]) * 16))
-        self.tapes = [_DTape(B, dtype, dev, C, S) for _ in range(self.NT)]
         tdt = ops.torch_dtype(dtype)
-        self.dz = [torch.empty(B, S >> (i + 1), S >> (i + 1), W[i], device=dev, dtype=tdt) for i in range(4)]
+        self.kp = C * 16
+        self.cin = [self.kp, W[0], W[1], W[2]]                 # gathered channels of layer i (layer 0: im2col patches)
+        self.hw = [S >> (i + 1) for i in range(4)]             # output extent of layer i
+        # packed panels live in per-layer records built for the largest batch; geometry structs per tape count
+        self.l1 = ConvRec(dtype, B, S, S, C, W[0], 4, 2, 1, device=dev, want_fwd=False, want_wgrad=False, ws=ws)       # d(img), tape 0 only
+        self.l1p = ConvRec(dtype, NT * B, S // 2, S // 2, self.kp, W[0], 1, 1, 0, device=dev, want_bwd=False, ws=ws)  # image side as 1x1 conv over patches
+        self.mid = [ConvRec(dtype, NT * B, S >> (i + 1), S >> (i + 1), W[i], W[i + 1], 4, 2, 1, device=dev, ws=ws) for i in range(3)]
+        self.head = ConvRec(dtype, NT * B, 4, 4, W[3], self.nout, 4, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
+        self.headw = ConvRec(dtype, NT * B, 1, 1, 16 * W[3], 32, 1, 1, 0, device=dev, want_fwd=False, want_bwd=False, ws=ws)
+        self.geo = {}
+        for T in range(1, NT + 1):
+            g = {"l1p": ops.make_conv(T * B, S // 2, S // 2, self.kp, W[0], 1, 1, 0),
+                 "mid": [ops.make_conv(T * B, S >> (i + 1), S >> (i + 1), W[i], W[i + 1], 4, 2, 1) for i in range(3)],
+                 "headw": ops.make_conv(T * B, 1, 1, 16 * W[3], 32, 1, 1, 0)}
+            self.geo[T] = g
+        for i in range(4):
+            ws.need_small(ops.sn_ws_floats(W[i], self.cin[i] * (16 if i else 1)))
+            ws.need_small(ops.bias_grad_sn_ws_floats(NT * B * self.hw[i] ** 2, W[i], B * self.hw[i] ** 2))
+        # tapes: contiguous along the batch axis
+        self.patches = torch.empty(NT * B * (S // 2) ** 2, self.kp, device=dev, dtype=tdt)
+        self.a = [torch.empty(NT * B, self.hw[i], self.hw[i], W[i], device=dev, dtype=tdt) for i in range(4)]
+        self.out = torch.empty(NT * B, self.nout, device=dev, dtype=torch.float32)
+        self.dz = [torch.empty_like(t) for t in self.a]
+        self.dout_t = torch.empty(NT * B, 32, device=dev, dtype=tdt)
         self.dimg = torch.empty(B, C, S, S, device=dev, dtype=torch.float32)
+        kd = [self.kp] + [W[i] * 16 for i in range(3)]
+        self.sigma = [torch.ones(NT, device=dev, dtype=torch.float32) for _ in range(4)]
+        self.u = [torch.zeros(NT, W[i], device=dev, dtype=torch.float32) for i in range(4)]
+        self.v = [torch.zeros(NT, kd[i], device=dev, dtype=torch.float32) for i in range(4)]
+        self.coef = [torch.zeros(4, device=dev, dtype=torch.float32) for _ in range(4)]
+        self.imgs = [None] * NT
         self.repack()
 
     def _m(self, i):
@@ -294,59 +302,74 @@ class _DiscEngine:
             self.mid[i].pack(self._m(i + 1).weight_orig)
         self.head.pack(self._m(4).weight)
 
-    def forward(self, img, t: int, training=True):
-        dt, B, W, ws = self.dtype, self.B, D_WIDTHS, self.ws
-        tp = self.tapes[t]
-        tp.img = img
-        for i in range(4):
-            m = self._m(i)
-            w = m.weight_orig
-            ops.sn_power_iter(w, w.shape[0], w.numel() // w.shape[0], m.weight_u, m.weight_v, tp.sigma[i], tp.u[i], tp.v[i], ws.small,
-                              training, SN_EPS)
-            if not training:
-                tp.u[i].copy_(m.weight_u)
-                tp.v[i].copy_(m.weight_v)
-        ep = lambda i: ops.epilogue(bias=self._m(i).bias, sigma=tp.sigma[i], act=ACT_LRELU, slope=LRELU_SLOPE)
-        ops.im2col_img(dt, img, tp.patches, B, self.C, self.S, self.S, 4, 2, 1, self.kp)
-        ops.conv_fwd(self.l1p.c, dt, tp.patches, self.l1p.wp_fwd, tp.a[0], ep(0))
-        for i in range(3):
-            r = self.mid[i]
-            ops.conv_fwd(r.c, dt, tp.a[i], r.wp_fwd, tp.a[i + 1], ep(i + 1))
-        K = 16 * W[3]
-        ops.dense_small_fwd(dt, tp.a[3], self.head.wp_fwd, self._m(4).bias, tp.out, B, K, self.head.Kpad_fwd, self.nout)
-        return tp.out
+    def rows(self, i):
+        """lattice rows of one tape at the output of layer i"""
+        return self.B * self.hw[i] ** 2
 
-    def backward(self, t: int, dout, grad, need_wgrad=True, need_dimg=False):
-        """``dout``: d(loss)/d(head output) [B,19] fp32.  Accumulates into flat ``grad`` (arena layout)."""
+    def forward(self, imgs, t0=0, training=True):
+        """Runs len(imgs) forwards as tapes t0.. (power iterations in list order, like consecutive D(...) calls).
+        Returns the head outputs [len(imgs)*B, 19] (a view of the tape buffer)."""
+        dt, B, W, ws = self.dtype, self.B, D_WIDTHS, self.ws
+        T = len(imgs)
+        assert 1 <= T and t0 + T <= self.NT
+        for k, img in enumerate(imgs):
+            t = t0 + k
+            self.imgs[t] = img
+            for i in range(4):
+                m = self._m(i)
+                w = m.weight_orig
+                ops.sn_power_iter(w, w.shape[0], w.numel() // w.shape[0], m.weight_u, m.weight_v, self.sigma[i][t:t + 1], self.u[i][t], self.v[i][t],
+                                  ws.small, training, SN_EPS)
+                if not training:
+                    self.u[i][t].copy_(m.weight_u)
+                    self.v[i][t].copy_(m.weight_v)
+            npix = B * (self.S // 2) ** 2
+            ops.im2col_img(dt, img, self.patches[t * npix:(t + 1) * npix], B, self.C, self.S, self.S, 4, 2, 1, self.kp)
+        g = self.geo[T]
+        sl = lambda buf, i: buf[t0 * (buf.shape[0] // self.NT):]
+        ep = lambda i: ops.epilogue(bias=self._m(i).bias, sigma=self.sigma[i][t0:], sigma_rows=self.rows(i), act=ACT_LRELU, slope=LRELU_SLOPE)
+        ops.conv_fwd(g["l1p"], dt, sl(self.patches, 0), self.l1p.wp_fwd, sl(self.a[0], 0), ep(0))
+        for i in range(3):
+            ops.conv_fwd(g["mid"][i], dt, sl(self.a[i], i), self.mid[i].wp_fwd, sl(self.a[i + 1], i + 1), ep(i + 1))
+        K = 16 * W[3]
+        out = self.out[t0 * B:(t0 + T) * B]
+        ops.dense_small_fwd(dt, sl(self.a[3], 3), self.head.wp_fwd, self._m(4).bias, out, T * B, K, self.head.Kpad_fwd, self.nout)
+        return out
+
+    def backward(self, t0, T, dout, grad, need_wgrad=True, need_dimg=False):
+        """``dout``: d(loss)/d(head output) of tapes t0..t0+T-1, [T*B,19] fp32.  Accumulates into flat ``grad`` (arena
+        layout); returns d(loss)/d(img) of tape t0 when ``need_dimg``."""
         dt, B, W, ws, disc = self.dtype, self.B, D_WIDTHS, self.ws, self.disc
-        tp = self.tapes[t]
         gof = lambda name: disc.arena.grad_of(name, grad)
+        g = self.geo[T]
+        sl = lambda buf: buf[t0 * (buf.shape[0] // self.NT):]
         K = 16 * W[3]
         if need_wgrad:
-            ops.cast_pad(dt, dout, self.dout_t, B, self.nout, 32)
-            ns = ops.conv_wgrad(self.headw.c, dt, tp.a[3], self.dout_t, ws.slab)
+            ops.cast_pad(dt, dout, self.dout_t, T * B, self.nout, 32)
+            ns = ops.conv_wgrad(g["headw"], dt, sl(self.a[3]), self.dout_t, ws.slab)
             ops.wgrad_reduce(ws.slab, ns, 32, self.nout, W[3], 16, gof("main.8.weight"))
-            ops.dense_small_bgrad(dout, gof("main.8.bias"), B, self.nout)
-        ops.dense_small_bwd(dt, dout, self.head.wp_fwd, tp.a[3], self.dz[3], B, K, self.head.Kpad_fwd, self.nout, ACT_LRELU, LRELU_SLOPE)
-        for i in (3, 2, 1):
-            r = self.mid[i - 1]
+            ops.dense_small_bgrad(dout, gof("main.8.bias"), T * B, self.nout)
+        # dzs_3 = (W5^T dout) * lrelu'(a3) / sigma_3[tape]
+        ops.dense_small_bwd(dt, dout, self.head.wp_fwd, sl(self.a[3]), sl(self.dz[3]), T * B, K, self.head.Kpad_fwd, self.nout, ACT_LRELU, LRELU_SLOPE,
+                            self.sigma[3][t0:], B)
+        for i in (3, 2, 1, 0):
             m = self._m(i)
-            rows = B * r.OH * r.OW
+            geo = g["mid"][i - 1] if i > 0 else g["l1p"]
+            x_in = sl(self.a[i - 1]) if i > 0 else sl(self.patches)
             if need_wgrad:
-                ns = ops.conv_wgrad(r.c, dt, tp.a[i - 1], self.dz[i], ws.slab)
-                ops.wgrad_reduce_sn(r.c, ws.slab, ns, m.weight_orig, tp.sigma[i], tp.u[i], tp.v[i], ws.gtmp, ws.partials,
-                                    gof(f"main.{2 * i}.weight_orig"))
-                ops.bias_grad(dt, self.dz[i], rows, W[i], ws.small, gof(f"main.{2 * i}.bias"))
-            ops.conv_bwd_data(r.c, dt, self.dz[i], r.wp_bwd, self.dz[i - 1],
-                              ops.epilogue(sigma=tp.sigma[i], mask=tp.a[i - 1], mask_act=ACT_LRELU, mask_slope=LRELU_SLOPE))
-        m = self._m(0)
-        if need_wgrad:
-            ns = ops.conv_wgrad(self.l1p.c, dt, tp.patches, self.dz[0], ws.slab)
-            ops.wgrad_reduce_sn(self.l1p.c, ws.slab, ns, m.weight_orig, tp.sigma[0], tp.u[0], tp.v[0], ws.gtmp, ws.partials,
-                                gof("main.0.weight_orig"))
-            ops.bias_grad(dt, self.dz[0], B * (self.S // 2) ** 2, W[0], ws.small, gof("main.0.bias"))
+                ops.bias_grad_sn(dt, sl(self.dz[i]), sl(self.a[i]), m.bias, T * self.rows(i), W[i], self.rows(i), self.sigma[i][t0:], LRELU_SLOPE,
+                                 ws.small, gof(f"main.{2 * i}.bias"), self.coef[i])
+                ns = ops.conv_wgrad(geo, dt, x_in, sl(self.dz[i]), ws.slab)
+                taps = 16 if i > 0 else 1
+                ops.wgrad_reduce_rank1(ws.slab, ns, W[i], W[i], self.cin[i], taps, gof(f"main.{2 * i}.weight_orig"), T, self.coef[i],
+                                       self.u[i][t0:], self.v[i][t0:])
+            if i > 0:
+                # dzs_{i-1} = conv^T(dzs_i, W_i) * lrelu'(a_{i-1}) / sigma_{i-1}[tape]
+                ops.conv_bwd_data(geo, dt, sl(self.dz[i]), self.mid[i - 1].wp_bwd, sl(self.dz[i - 1]),
+                                  ops.epilogue(sigma=self.sigma[i - 1][t0:], sigma_rows=self.rows(i), mask=sl(self.a[i - 1]), mask_act=ACT_LRELU,
+                                               mask_slope=LRELU_SLOPE))
         if need_dimg:
-            ops.conv_bwd_data(self.l1.c, dt, self.dz[0], self.l1.wp_bwd, self.dimg, ops.epilogue(sigma=tp.sigma[0], out_mode=OUT_NCHW_F32))
+            ops.conv_bwd_data(self.l1.c, dt, sl(self.dz[0]), self.l1.wp_bwd, self.dimg, ops.epilogue(out_mode=OUT_NCHW_F32))
             return self.dimg
         return None
 
@@ -404,13 +427,13 @@ class _DiscFn(torch.autograd.Function):
         ctx.eng, ctx.t = eng, t
         ctx.need_w = any(p.requires_grad for p in params)
         ctx.need_img = img.requires_grad
-        return eng.forward(img, t, training).clone()
+        return eng.forward([img], t, training).clone()
 
     @staticmethod
     def backward(ctx, dout):
         eng = ctx.eng
         scratch = torch.zeros_like(eng.disc.arena.grad)
-        dimg = eng.backward(ctx.t, dout.contiguous(), scratch, need_wgrad=ctx.need_w, need_dimg=ctx.need_img)
+        dimg = eng.backward(ctx.t, 1, dout.contiguous(), scratch, need_wgrad=ctx.need_w, need_dimg=ctx.need_img)
         grads = [scratch[off:off + k].view(p.shape) for p, (off, k) in zip(eng.disc.parameters(), eng.disc.arena.slices.values())]
         return (None, None, None, dimg.clone() if dimg is not None else None, *grads)
 
@@ -512,7 +535,7 @@ class CelebATrainer:
         C, S = generator.channels, generator.img_size
         self.theta = torch.empty(B, 2, 3, device=dev, dtype=torch.float32)
         self.scaled = torch.empty(B, C, S, S, device=dev, dtype=torch.float32)
-        self.dout = [torch.empty(B, 19, device=dev, dtype=torch.float32) for _ in range(3)]
+        self.dout = torch.empty(3 * B, 19, device=dev, dtype=torch.float32)
         # static input slots (a captured graph reads these)
         self.real = torch.empty(B, C, S, S, device=dev, dtype=torch.float32)
         self.z = torch.empty(B, generator.latent_dim, device=dev, dtype=torch.float32)
@@ -537,39 +560,34 @@ class CelebATrainer:
         # ---- 1) generator adversarial step (:334-345) ----
         ops.fill_f32(ga.grad)
         gen = ge.forward(self.z, self.onehot, self.code)
-        out = de.forward(gen, 0)
-        ops.loss_bce_sigmoid(out, 19, 0, B, 1.0, 1.0, self.losses[0:1], self.dout[0])
-        dimg = de.backward(0, self.dout[0], da.grad, need_wgrad=False, need_dimg=True)
+        out = de.forward([gen])
+        ops.loss_bce_sigmoid(out, 19, 0, B, 1.0, 1.0, self.losses[0:1], self.dout[:B])
+        dimg = de.backward(0, 1, self.dout[:B], da.grad, need_wgrad=False, need_dimg=True)
         ge.backward(dimg, ga.grad)
         if self.allreduce is not None:
             self.allreduce(ga.grad)
         self._adam(ga, self.mG, self.vG, self.lr[0], 0, True)
         ge.repack()
-        # ---- 2) discriminator step (:353-366); gen is the (detached) output of step 1 ----
+        # ---- 2) discriminator step (:353-366); gen is the (detached) output of step 1; D(scaled) then D(gen), batched ----
         ops.fill_f32(da.grad)
-        o_real = de.forward(self.scaled, 0)
-        o_fake = de.forward(gen, 1)
-        ops.loss_bce_sigmoid(o_real, 19, 0, B, 1.0, 0.5, self.losses[1:2], self.dout[0])
-        ops.loss_bce_sigmoid(o_fake, 19, 0, B, 0.0, 0.5, self.losses[1:2], self.dout[1])
-        de.backward(1, self.dout[1], da.grad)
-        de.backward(0, self.dout[0], da.grad)
+        out = de.forward([self.scaled, gen])
+        ops.loss_bce_sigmoid(out[:B], 19, 0, B, 1.0, 0.5, self.losses[1:2], self.dout[:B])
+        ops.loss_bce_sigmoid(out[B:], 19, 0, B, 0.0, 0.5, self.losses[1:2], self.dout[B:2 * B])
+        de.backward(0, 2, self.dout[:2 * B], da.grad)
         if self.allreduce is not None:
             self.allreduce(da.grad)
         self._adam(da, self.mD, self.vD, self.lr[1], 1, True)
         de.repack()
-        # ---- 3) info + affine step (:375-401) ----
+        # ---- 3) info + affine step (:375-401): D(gen), D(scaled), D(real) batched as tapes 0,1,2 ----
         ops.fill_f32(ga.grad)
         ops.fill_f32(da.grad)
         gen = ge.forward(self.z, self.onehot, self.code)
-        o_gen = de.forward(gen, 0)
-        o_trans = de.forward(self.scaled, 1)
-        o_real = de.forward(self.real, 2)
-        ops.loss_mse(o_gen, 19, 1, cd, B, self.code, cd, 0.0, lcon, self.losses[2:3], self.dout[0])
-        ops.loss_ce_softmaxed(o_gen, 19, cd + 1, nc, B, self.labels, lcat, self.losses[2:3], self.dout[0])
-        ops.loss_affine_rpqxy(o_real, o_trans, 19, 1, B, self.code, cd, laff, self.losses[2:3], self.dout[2], self.dout[1])
-        de.backward(2, self.dout[2], da.grad)
-        de.backward(1, self.dout[1], da.grad)
-        dimg = de.backward(0, self.dout[0], da.grad, need_dimg=True)
+        out = de.forward([gen, self.scaled, self.real])
+        o_gen, o_trans, o_real = out[:B], out[B:2 * B], out[2 * B:]
+        ops.loss_mse(o_gen, 19, 1, cd, B, self.code, cd, 0.0, lcon, self.losses[2:3], self.dout[:B])
+        ops.loss_ce_softmaxed(o_gen, 19, cd + 1, nc, B, self.labels, lcat, self.losses[2:3], self.dout[:B])
+        ops.loss_affine_rpqxy(o_real, o_trans, 19, 1, B, self.code, cd, laff, self.losses[2:3], self.dout[2 * B:], self.dout[B:2 * B])
+        dimg = de.backward(0, 3, self.dout, da.grad, need_dimg=True)
         ge.backward(dimg, ga.grad)
         if self.allreduce is not None:
             self.allreduce(ga.grad)

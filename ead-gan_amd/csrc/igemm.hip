@@ -39,6 +39,7 @@ struct NtParams {
     int mask_act;
     float mask_slope;
     int out_mode;
+    int sigma_rows;
     int M;
     NtPhase ph[4];
 };
@@ -117,15 +118,17 @@ static int geom_bwd(const eg_conv* c, int dtype, NtParams& p, int* nphase) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// D = B-fragment x A-fragment: the weight-panel rows (n) land on the accumulator ROW index (4 consecutive n per lane),
+// the gathered rows (m) on the lane -> the epilogue packs 4 consecutive output channels per lane.
 template <typename T>
 __device__ __forceinline__ void mfma_step(const uint4& a, const uint4& b, f32x4& acc) {
     if constexpr (std::is_same<T, float>::value) {
         const float* af = reinterpret_cast<const float*>(&a);
         const float* bf = reinterpret_cast<const float*>(&b);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bf[e], acc, 0, 0, 0);
+        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[e], af[e], acc, 0, 0, 0);
     } else {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b), __builtin_bit_cast(bf16x8_t, a), acc, 0, 0, 0);
     }
 }
 
@@ -241,21 +244,86 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
     }
 
     // ---- epilogue ----
-    const float inv_sigma = p.sigma ? 1.f / p.sigma[0] : 1.f;
+    // acc[i][j][r] = C[m = m0 + (wm*TM+i)*16 + frow][n = n0 + (wn*TN+j)*16 + fq*4 + r]
+    if (p.out_mode == EG_OUT_NHWC && (p.N % VEC) == 0) {
+        // stage the fp32 tile through LDS (16-byte chunks XOR-swizzled by row), then store whole 16-byte vectors:
+        // every wave-store covers full 128..256-byte row segments instead of 2-byte scatters.
+        constexpr int CH = BN / 4;                       // fp32 16-byte chunks per tile row
+        constexpr int SW = CH < 32 ? CH - 1 : 31;
+        float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = (wm * TM + i) * 16 + frow;
+            const int mrow = min(m0 + row, p.M - 1);
+            const float inv_sigma = p.sigma ? 1.f / p.sigma[p.sigma_rows ? mrow / p.sigma_rows : 0] : 1.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nl = (wn * TN + j) * 16 + fq * 4;
+                float4 v;
+                float* ve = reinterpret_cast<float*>(&v);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[i][j][r] * inv_sigma;
+                    const int n = n0 + nl + r;
+                    if (p.bias && n < p.N) x += p.bias[p.bias_mod ? n % p.bias_mod : n];
+                    ve[r] = eg_act(x, p.act, p.slope);
+                }
+                *reinterpret_cast<float4*>(ct + row * BN + (((nl >> 2) ^ (row & SW)) << 2)) = v;
+            }
+        }
+        __syncthreads();
+        constexpr int VPR = BN / VEC;                    // output vectors per tile row
+        constexpr int RPP = 256 / VPR;                   // rows per pass
+        const int vc = tid % VPR, vr = tid / VPR;
+        const T* __restrict__ mask = reinterpret_cast<const T*>(p.mask);
+        const int n = n0 + vc * VEC;
+        if (n < p.N) {
+#pragma unroll 4
+            for (int row = vr; row < BM; row += RPP) {
+                const int m = m0 + row;
+                if (m >= p.M) break;
+                const int b = m >> (p.lOW + p.lOH);
+                const int y = ((m >> p.lOW) & OHm) * p.osy + ph.ooy;
+                const int x = (m & OWm) * p.osx + ph.oox;
+                const size_t o = (((size_t)b * p.DH + y) * p.DW + x) * p.N + n;
+                float f[VEC];
+#pragma unroll
+                for (int q = 0; q < VEC / 4; ++q) {
+                    const int chunk = (vc * (VEC / 4) + q) ^ (row & SW);
+                    const float4 v = *reinterpret_cast<const float4*>(ct + row * BN + (chunk << 2));
+                    f[q * 4 + 0] = v.x; f[q * 4 + 1] = v.y; f[q * 4 + 2] = v.z; f[q * 4 + 3] = v.w;
+                }
+                if (mask) {
+                    const uint4 mv = *reinterpret_cast<const uint4*>(mask + o);
+                    const T* me = reinterpret_cast<const T*>(&mv);
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) f[q] *= eg_act_grad_from_out(Elt<T>::ld(me + q), p.mask_act, p.mask_slope);
+                }
+                uint4 ov;
+                T* oe = reinterpret_cast<T*>(&ov);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) Elt<T>::st(oe + q, f[q]);
+                *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.dst) + o) = ov;
+            }
+        }
+        return;
+    }
+    // scalar path: NCHW fp32 image outputs (N = 1..4) and channel counts that are not a multiple of the vector width
     const T* __restrict__ mask = reinterpret_cast<const T*>(p.mask);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        const int m = m0 + (wm * TM + i) * 16 + frow;
+        if (m >= p.M) continue;
+        const float inv_sigma = p.sigma ? 1.f / p.sigma[p.sigma_rows ? m / p.sigma_rows : 0] : 1.f;
+        const int b = m >> (p.lOW + p.lOH);
+        const int y = ((m >> p.lOW) & OHm) * p.osy + ph.ooy;
+        const int x = (m & OWm) * p.osx + ph.oox;
+        const size_t pix = ((size_t)b * p.DH + y) * p.DW + x;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int m = m0 + (wm * TM + i) * 16 + fq * 4 + r;
-            if (m >= p.M) continue;
-            const int b = m >> (p.lOW + p.lOH);
-            const int y = ((m >> p.lOW) & OHm) * p.osy + ph.ooy;
-            const int x = (m & OWm) * p.osx + ph.oox;
-            const size_t pix = ((size_t)b * p.DH + y) * p.DW + x;
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + (wn * TN + j) * 16 + frow;
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + (wn * TN + j) * 16 + fq * 4 + r;
                 if (n >= p.N) continue;
                 float v = acc[i][j][r] * inv_sigma;
                 if (p.bias) v += p.bias[p.bias_mod ? n % p.bias_mod : n];
@@ -277,7 +345,7 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
 template <typename T, int BM, int BN, int WGM, int WGN>
 static void launch_nt_cfg(const NtParams& p, int nphase, hipStream_t st) {
     dim3 grid(cdiv(p.M, BM), cdiv(p.N, BN), nphase);
-    const size_t lds = 2 * (BM + BN) * 128;
+    const size_t lds = 2 * (BM + BN) * 128 > BM * BN * 4 ? 2 * (BM + BN) * 128 : BM * BN * 4;
     hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, WGM, WGN>), grid, dim3(256), lds, st, p);
 }
 
@@ -287,7 +355,7 @@ static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
         launch_nt_cfg<T, 128, 16, 4, 1>(p, nphase, st);
     else if (p.N <= 32)
         launch_nt_cfg<T, 128, 32, 4, 1>(p, nphase, st);
-    else if (p.N <= 64 || (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * nphase < 192)
+    else if (p.N <= 64 || (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * nphase < 512)
         launch_nt_cfg<T, 128, 64, 2, 2>(p, nphase, st);
     else
         launch_nt_cfg<T, 128, 128, 2, 2>(p, nphase, st);
@@ -297,7 +365,7 @@ static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
 extern "C" int eg_igemm_nt_tile(int M, int N, int nphase) {
     if (N <= 16) return 128 * 1000 + 16;
     if (N <= 32) return 128 * 1000 + 32;
-    if (N <= 64 || (long long)cdiv(M, 128) * cdiv(N, 128) * nphase < 192) return 128 * 1000 + 64;
+    if (N <= 64 || (long long)cdiv(M, 128) * cdiv(N, 128) * nphase < 512) return 128 * 1000 + 64;
     return 128 * 1000 + 128;
 }
 
@@ -311,6 +379,7 @@ static void fill_epilogue(NtParams& p, const eg_epilogue* ep) {
     p.mask_act = ep ? ep->mask_act : EG_ACT_NONE;
     p.mask_slope = ep ? ep->mask_slope : 0.f;
     p.out_mode = ep ? ep->out_mode : EG_OUT_NHWC;
+    p.sigma_rows = ep ? ep->sigma_rows : 0;
 }
 
 extern "C" int eg_conv_fwd(const eg_conv* c, int dtype, const void* X, const void* wp_fwd, void* Y,
@@ -768,6 +837,40 @@ extern "C" int eg_wgrad_reduce(const float* slab, int nsplit, int n_slab, int n_
     return 0;
 }
 
+// single-pass reduce with the spectral-norm rank-1 terms of up to 4 tapes
+__global__ void wgrad_reduce_rank1_kernel(const float* __restrict__ slab, int nsplit, int NS, int N, int C, int T, float* __restrict__ out,
+                                          int ntapes, const float* __restrict__ coef, const float* __restrict__ u, const float* __restrict__ v) {
+    const long long NC = (long long)N * C;
+    const size_t split_stride = (size_t)NS * T * C;
+    float cf[4];
+    for (int q = 0; q < 4; ++q) cf[q] = q < ntapes ? coef[q] : 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < NC; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / C), c = (int)(i % C);
+        float un[4];
+        for (int q = 0; q < 4; ++q) un[q] = q < ntapes ? cf[q] * u[(size_t)q * N + n] : 0.f;
+        for (int t = 0; t < T; ++t) {
+            const size_t si = ((size_t)n * T + t) * C + c;
+            float a = 0.f;
+            for (int z = 0; z < nsplit; ++z) a += slab[z * split_stride + si];
+            const size_t kk = (size_t)c * T + t;
+            for (int q = 0; q < ntapes; ++q) a -= un[q] * v[(size_t)q * C * T + kk];
+            const size_t oi = ((size_t)n * C + c) * T + t;
+            out[oi] += a;
+        }
+    }
+}
+
+extern "C" int eg_wgrad_reduce_rank1(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad, int ntapes,
+                                     const float* coef, const float* u, const float* v, eg_stream_t s) {
+    EG_REQUIRE(slab && grad && nsplit > 0 && n_rows <= n_slab && ntapes >= 0 && ntapes <= 4 && (ntapes == 0 || (coef && u && v)),
+               "eg_wgrad_reduce_rank1: bad argument");
+    const long long NC = (long long)n_rows * C;
+    const int blocks = (int)((NC + 255) / 256 > 4096 ? 4096 : (NC + 255) / 256);
+    hipLaunchKernelGGL(wgrad_reduce_rank1_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T, grad, ntapes, coef, u, v);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int eg_sn_partials(void) { return EG_SN_NPART; }
 
 extern "C" int eg_wgrad_reduce_sn(const eg_conv* c, const float* slab, int nsplit, const float* w_orig, const float* sigma,
@@ -851,6 +954,105 @@ extern "C" int eg_bias_grad(int dtype, const void* dY, int rows, int N, int bias
     else hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)dY, rows, N, partials);
     const int nb = bias_mod > 0 ? bias_mod : N;
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(nb, 4)), dim3(256), 0, (hipStream_t)s, partials, nrb, N, nb, (const float*)nullptr, gb);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- tape-segmented bias gradient + <G,W>/sigma^2 coefficient from activations (spectrally normalised layers) --------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_sn_partial_kernel(const T* __restrict__ x, const T* __restrict__ act, const float* __restrict__ bias,
+                                                                int N, int rows_per_tape, int blocks_per_tape, float inv_slope,
+                                                                float* __restrict__ partials, float* __restrict__ dots) {
+    constexpr int VEC = Elt<T>::VEC;
+    __shared__ float sm[256 * VEC];
+    __shared__ float smd[16];
+    const int cpr = N / VEC;
+    const int ccols = cpr < 256 ? cpr : 256;
+    const int lanes = 256 / ccols;
+    const int cj = threadIdx.x % ccols, rl = threadIdx.x / ccols;
+    const int chunk = blockIdx.x * ccols + cj;
+    const int tape = blockIdx.y / blocks_per_tape, blk = blockIdx.y % blocks_per_tape;
+    const int r0 = tape * rows_per_tape + blk * EG_BG_RPB;
+    const int r1 = min(tape * rows_per_tape + rows_per_tape, r0 + EG_BG_RPB);
+    float a[VEC], bv[VEC];
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { a[j] = 0.f; bv[j] = (chunk < cpr) ? bias[chunk * VEC + j] : 0.f; }
+    if (chunk < cpr)
+        for (int r = r0 + rl; r < r1; r += lanes) {
+            const size_t o = (size_t)r * N + (size_t)chunk * VEC;
+            const uint4 v = *reinterpret_cast<const uint4*>(x + o);
+            const uint4 w = *reinterpret_cast<const uint4*>(act + o);
+            const T* e = reinterpret_cast<const T*>(&v);
+            const T* ae = reinterpret_cast<const T*>(&w);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float g = Elt<T>::ld(e + j);
+                float z = Elt<T>::ld(ae + j);
+                z = z > 0.f ? z : z * inv_slope;
+                a[j] += g;
+                dot += g * (z - bv[j]);
+            }
+        }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sm[threadIdx.x * VEC + j] = a[j];
+    const float dtot = block_sum(dot, smd);      // contains the __syncthreads that also publishes sm
+    if (rl == 0 && chunk < cpr) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float t = 0.f;
+            for (int l = 0; l < lanes; ++l) t += sm[(l * ccols + cj) * VEC + j];
+            partials[(size_t)blockIdx.y * N + (size_t)chunk * VEC + j] = t;
+        }
+    }
+    if (threadIdx.x == 0) dots[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = dtot;
+}
+
+// gb[n] += sum_rb sigma[tape(rb)] * partials[rb][n]   (one wave per n);  coef[t] = sum of the tape's dot partials (block z)
+__global__ void colsum_sn_final_kernel(const float* __restrict__ partials, const float* __restrict__ dots, int nrb, int N, int blocks_per_tape,
+                                       int ndot_per_rb, int ntapes, const float* __restrict__ sigma, float* __restrict__ gb, float* __restrict__ coef) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (j < N) {
+        float a = 0.f;
+        for (int r = lane; r < nrb; r += 64) a += partials[(size_t)r * N + j] * sigma[r / blocks_per_tape];
+        a = wave_sum(a);
+        if (lane == 0) gb[j] += a;
+    } else if (j < N + ntapes) {
+        const int t = j - N;
+        float a = 0.f;
+        const int n = blocks_per_tape * ndot_per_rb;
+        for (int r = lane; r < n; r += 64) a += dots[(size_t)t * n + r];
+        a = wave_sum(a);
+        if (lane == 0) coef[t] = a;
+    }
+}
+
+extern "C" size_t eg_bias_grad_sn_ws_floats(int rows, int N, int rows_per_tape) {
+    const int ntapes = rows / rows_per_tape;
+    const int bpt = cdiv(rows_per_tape, EG_BG_RPB);
+    return (size_t)ntapes * bpt * (N + 64);
+}
+
+extern "C" int eg_bias_grad_sn(int dtype, const void* dzs, const void* a, const float* bias, int rows, int N, int rows_per_tape,
+                               const float* sigma, float slope, float* ws, float* gb, float* coef, eg_stream_t s) {
+    EG_REQUIRE(dzs && a && bias && sigma && ws && gb && coef && rows_per_tape > 0 && rows % rows_per_tape == 0 && slope > 0.f, "eg_bias_grad_sn: bad argument");
+    const int vecw = dtype == EG_F32 ? 4 : 8;
+    EG_REQUIRE(N % vecw == 0, "eg_bias_grad_sn: N must be a multiple of the 16-byte vector width");
+    const int cpr = N / vecw;
+    const int ccols = cpr < 256 ? cpr : 256;
+    EG_REQUIRE(256 % ccols == 0, "eg_bias_grad_sn: N/vec must divide 256 or be a multiple of it");
+    const int ntapes = rows / rows_per_tape;
+    EG_REQUIRE(ntapes <= 4, "eg_bias_grad_sn: at most 4 tapes");
+    const int bpt = cdiv(rows_per_tape, EG_BG_RPB);
+    const int nrb = ntapes * bpt;
+    const int gx = cdiv(cpr, ccols);
+    float* partials = ws;
+    float* dots = ws + (size_t)nrb * N;
+    dim3 grid(gx, nrb);
+    if (dtype == EG_F32) hipLaunchKernelGGL(colsum_sn_partial_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)dzs, (const float*)a, bias, N, rows_per_tape, bpt, 1.f / slope, partials, dots);
+    else hipLaunchKernelGGL(colsum_sn_partial_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)dzs, (const bf16_t*)a, bias, N, rows_per_tape, bpt, 1.f / slope, partials, dots);
+    hipLaunchKernelGGL(colsum_sn_final_kernel, dim3(cdiv(N + ntapes, 4)), dim3(256), 0, (hipStream_t)s, partials, dots, nrb, N, bpt, gx, ntapes, sigma, gb, coef);
     EG_LAUNCH_CHECK();
     return 0;
 }

@@ -392,10 +392,12 @@ __global__ __launch_bounds__(256) void dense_small_fwd_kernel(const T* __restric
 // dx[b][k] = (sum_n dy[b][n] * Wp[n][k]) * act'(mask[b][k])
 template <typename T>
 __global__ __launch_bounds__(256) void dense_small_bwd_kernel(const float* __restrict__ dy, const T* __restrict__ wp, const T* __restrict__ mask,
-                                                              T* __restrict__ dx, int K, int Kpad, int N, int mask_act, float mask_slope) {
+                                                              T* __restrict__ dx, int K, int Kpad, int N, int mask_act, float mask_slope,
+                                                              const float* __restrict__ sigma, int sigma_rows) {
     constexpr int VEC = Elt<T>::VEC;
     __shared__ float dl[64];
     const int b = blockIdx.x;
+    const float post = sigma ? 1.f / sigma[sigma_rows ? b / sigma_rows : 0] : 1.f;
     if (threadIdx.x < N) dl[threadIdx.x] = dy[(size_t)b * N + threadIdx.x];
     __syncthreads();
     for (int k0 = threadIdx.x * VEC; k0 < K; k0 += 256 * VEC) {
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(256) void dense_small_bwd_kernel(const float* __res
             for (int j = 0; j < VEC; ++j) a[j] *= eg_act_grad_from_out(Elt<T>::ld(me + j), mask_act, mask_slope);
         }
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) Elt<T>::st(oe + j, a[j]);
+        for (int j = 0; j < VEC; ++j) Elt<T>::st(oe + j, a[j] * post);
         *reinterpret_cast<uint4*>(dx + (size_t)b * K + k0) = ov;
     }
 }
@@ -457,10 +459,10 @@ extern "C" int eg_dense_small_fwd(int dtype, const void* x, const void* wp, cons
 }
 
 extern "C" int eg_dense_small_bwd(int dtype, const float* dy, const void* wp, const void* mask, void* dx, int B, int K, int Kpad, int N,
-                                  int mask_act, float mask_slope, eg_stream_t s) {
+                                  int mask_act, float mask_slope, const float* sigma, int sigma_rows, eg_stream_t s) {
     EG_REQUIRE(dy && wp && dx && N <= 64 && K % (dtype == EG_F32 ? 4 : 8) == 0, "eg_dense_small_bwd: bad argument");
-    if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_bwd_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)s, dy, (const float*)wp, (const float*)mask, (float*)dx, K, Kpad, N, mask_act, mask_slope);
-    else hipLaunchKernelGGL(dense_small_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)s, dy, (const bf16_t*)wp, (const bf16_t*)mask, (bf16_t*)dx, K, Kpad, N, mask_act, mask_slope);
+    if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_bwd_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)s, dy, (const float*)wp, (const float*)mask, (float*)dx, K, Kpad, N, mask_act, mask_slope, sigma, sigma_rows);
+    else hipLaunchKernelGGL(dense_small_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)s, dy, (const bf16_t*)wp, (const bf16_t*)mask, (bf16_t*)dx, K, Kpad, N, mask_act, mask_slope, sigma, sigma_rows);
     EG_LAUNCH_CHECK();
     return 0;
 }

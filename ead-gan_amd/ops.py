@@ -45,8 +45,8 @@ def make_conv(B, H, W, Cin, Cout, k, stride, pad, up=0) -> EgConv:
 
 
 def epilogue(bias=None, bias_mod=0, sigma=None, act=ACT_NONE, slope=0.0, mask=None, mask_act=ACT_NONE,
-             mask_slope=0.0, out_mode=OUT_NHWC) -> EgEpilogue:
-    return EgEpilogue(_p(bias), bias_mod, _p(sigma), act, slope, _p(mask), mask_act, mask_slope, out_mode)
+             mask_slope=0.0, out_mode=OUT_NHWC, sigma_rows=0) -> EgEpilogue:
+    return EgEpilogue(_p(bias), bias_mod, _p(sigma), act, slope, _p(mask), mask_act, mask_slope, out_mode, sigma_rows)
 
 
 # ---- implicit-GEMM family ------------------------------------------------------------------------
@@ -90,7 +90,8 @@ def _record(kind, c, dtype, fn):
         N, nph = (c.Cout, 1) if kind == "fwd" else (c.Cin, c.stride * c.stride)
         tile = lib().query("eg_igemm_nt_tile", M, N, nph)
         label = f"igemm_nt_kernel<{tname},{tile // 1000},{tile % 1000}>"
-    RECORDER.append((label, flops, fn))
+    shape = f"{kind} B{c.B} H{c.H} Cin{c.Cin} Cout{c.Cout} k{c.k} s{c.stride}"
+    RECORDER.append((label, flops, fn, shape))
 
 
 def conv_fwd(c, dtype, X, wp, Y, ep=None):
@@ -140,6 +141,18 @@ def bias_grad(dtype, dY, rows, N, partials, gb, bias_mod=0):
     lib().call("eg_bias_grad", dtype, _p(dY), rows, N, bias_mod, _p(partials), _p(gb), _stream())
 
 
+def bias_grad_sn_ws_floats(rows, N, rows_per_tape):
+    return lib().query("eg_bias_grad_sn_ws_floats", rows, N, rows_per_tape)
+
+
+def bias_grad_sn(dtype, dzs, a, bias, rows, N, rows_per_tape, sigma, slope, ws, gb, coef):
+    lib().call("eg_bias_grad_sn", dtype, _p(dzs), _p(a), _p(bias), rows, N, rows_per_tape, _p(sigma), slope, _p(ws), _p(gb), _p(coef), _stream())
+
+
+def wgrad_reduce_rank1(slab, nsplit, n_slab, n_rows, C, T, grad, ntapes, coef, u, v):
+    lib().call("eg_wgrad_reduce_rank1", _p(slab), nsplit, n_slab, n_rows, C, T, _p(grad), ntapes, _p(coef), _p(u), _p(v), _stream())
+
+
 # ---- image side / heads ----------------------------------------------------------------------------
 def conv_img_fwd(dtype, img, w_master, out, B, CI, H, W, N, k, stride, pad, ep=None):
     lib().call("eg_conv_img_fwd", dtype, _p(img), _p(w_master), _p(out), B, CI, H, W, N, k, stride, pad,
@@ -186,8 +199,8 @@ def dense_small_fwd(dtype, x, wp, bias, y, B, K, Kpad, N):
     lib().call("eg_dense_small_fwd", dtype, _p(x), _p(wp), _p(bias), _p(y), B, K, Kpad, N, _stream())
 
 
-def dense_small_bwd(dtype, dy, wp, mask, dx, B, K, Kpad, N, mask_act=ACT_NONE, mask_slope=0.0):
-    lib().call("eg_dense_small_bwd", dtype, _p(dy), _p(wp), _p(mask), _p(dx), B, K, Kpad, N, mask_act, mask_slope, _stream())
+def dense_small_bwd(dtype, dy, wp, mask, dx, B, K, Kpad, N, mask_act=ACT_NONE, mask_slope=0.0, sigma=None, sigma_rows=0):
+    lib().call("eg_dense_small_bwd", dtype, _p(dy), _p(wp), _p(mask), _p(dx), B, K, Kpad, N, mask_act, mask_slope, _p(sigma), sigma_rows, _stream())
 
 
 def dense_small_wgrad(dtype, dy, x, gw, gb, B, K, N, Cin, taps):

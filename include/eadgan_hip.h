@@ -41,10 +41,11 @@ typedef struct eg_conv {
     int B, H, W, Cin, Cout, k, stride, pad, up;
 } eg_conv;
 
-/* Fused epilogue of the implicit-GEMM kernels:  v = acc [/ *sigma] [+ bias[n % bias_mod]] ;
+/* Fused epilogue of the implicit-GEMM kernels:  v = acc [/ sigma[tape]] [+ bias[n % bias_mod]] ;
  * v = act(v) ; [v *= act'(mask)] ; store.  `mask` holds the activation OUTPUT of the layer whose
  * gradient is being formed (same dtype and layout as dst), so LeakyReLU/ReLU backward never needs a
- * separate pass. */
+ * separate pass.  Several forwards of one network ("tapes", each with its own spectral-norm sigma) can be
+ * batched along M: tape = lattice_row / sigma_rows (sigma_rows == 0: one sigma for the whole launch). */
 typedef struct eg_epilogue {
     const float* bias;
     int bias_mod;
@@ -55,6 +56,7 @@ typedef struct eg_epilogue {
     int mask_act;
     float mask_slope;
     int out_mode;
+    int sigma_rows;
 } eg_epilogue;
 
 /* --- implicit-GEMM convolution family (MFMA) ---------------------------------------------------
@@ -92,6 +94,18 @@ int eg_wgrad_reduce_sn(const eg_conv* c, const float* slab, int nsplit, const fl
 size_t eg_bias_grad_ws_floats(int rows, int N);
 int eg_bias_grad(int dtype, const void* dY, int rows, int N, int bias_mod, float* partials, float* gb,
                  eg_stream_t s);
+/* Batched-tape form for spectrally normalised layers.  dzs holds dL/dz ALREADY divided by the tape's sigma
+ * (dzs = dz / sigma[tape]); a = activation output (LeakyReLU), bias = the layer's bias.  Computes
+ *   gb[n]   += sum_tape sigma[tape] * sum_{rows of tape} dzs[row][n]
+ *   coef[t]  = sum_{rows of tape t, n} dzs[row][n] * (lrelu^-1(a[row][n]) - bias[n])      (== <G_t, W_orig> / sigma_t^2)
+ * ws: eg_bias_grad_sn_ws_floats(rows, N, rows_per_tape) floats. */
+size_t eg_bias_grad_sn_ws_floats(int rows, int N, int rows_per_tape);
+int eg_bias_grad_sn(int dtype, const void* dzs, const void* a, const float* bias, int rows, int N, int rows_per_tape,
+                    const float* sigma, float slope, float* ws, float* gb, float* coef, eg_stream_t s);
+/* grad[n][c][t] += sum_split slab[split][n][t][c] - sum_tape coef[tape] * u[tape][n] * v[tape][c*T + t]
+ * (u: [ntapes][n_rows], v: [ntapes][C*T]); single pass, deterministic. */
+int eg_wgrad_reduce_rank1(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad,
+                          int ntapes, const float* coef, const float* u, const float* v, eg_stream_t s);
 /* wp[n][k] = w[(n / n_div) * s_hi + (n % n_div) * s_lo + k * s_k], zero for K <= k < Kpad
  * (ConvTranspose2d on a 1x1 input as a GEMM: celebA/EAD-GAN_celebA.py:76; view-permuted Linear outputs) */
 int eg_pack_strided(int dtype, const float* w, void* wp, int N, int K, int Kpad, int n_div, long long s_hi,
@@ -122,8 +136,10 @@ int eg_bias_grad_nchw(const float* x, int B, int C, int HW, float* gb, eg_stream
  * y[b][n] = sum_k x[b][k] Wp[n][k] + bias[n];  x dtype T [B][K]; Wp dtype T [N][Kpad] (eg_pack_fwd order);  y fp32 */
 int eg_dense_small_fwd(int dtype, const void* x, const void* wp, const float* bias, float* y, int B, int K,
                        int Kpad, int N, eg_stream_t s);
+/* dx[b] = (dy[b] Wp) * act'(mask[b]) [/ sigma[b / sigma_rows]] */
 int eg_dense_small_bwd(int dtype, const float* dy, const void* wp, const void* mask, void* dx, int B, int K,
-                       int Kpad, int N, int mask_act, float mask_slope, eg_stream_t s);
+                       int Kpad, int N, int mask_act, float mask_slope, const float* sigma, int sigma_rows,
+                       eg_stream_t s);
 int eg_dense_small_wgrad(int dtype, const float* dy, const void* x, float* gw, float* gb, int B, int K, int N,
                          int Cin, int taps, eg_stream_t s);
 int eg_dense_small_bgrad(const float* dy, float* gb, int B, int N, eg_stream_t s);   /* gb[n] += sum_b dy[b][n] */

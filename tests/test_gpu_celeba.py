@@ -136,15 +136,27 @@ def test_discriminator_three_forwards_then_backward_fp32():
             x = F.leaky_relu(F.conv2d(x, co.spectral_weight(orc.D, f"main.{2 * i}."), orc.D[f"main.{2 * i}.bias"], 2, 1), 0.1)
         total = total + (F.conv2d(x, orc.D["main.8.weight"], orc.D["main.8.bias"]).squeeze() * douts[t]).sum()
     total.backward()
-    for t in range(3):
-        de.forward(imgs[t].to(DEV), t)
+    # (a) the three forwards batched into single launches (what the trainer does), one batched backward
+    out = de.forward([im.to(DEV) for im in imgs])
+    assert out.shape == (3 * B, 19)
     grad = torch.zeros_like(D.arena.grad)
-    for t in (2, 1, 0):
-        dimg = de.backward(t, douts[t].to(DEV).contiguous(), grad, need_wgrad=True, need_dimg=True)
-        assert rel_err(dimg, leaves[t].grad) < 2e-4, t
+    dimg = de.backward(0, 3, torch.cat(douts).to(DEV).contiguous(), grad, need_wgrad=True, need_dimg=True)
+    assert rel_err(dimg, leaves[0].grad) < 2e-4
     for k in dict(D.named_parameters()):
         off, n = D.arena.slices[k]
         assert rel_err(grad[off:off + n], orc.D[k].grad) < 2e-4, k
+    for i in range(4):
+        assert rel_err(D.state_dict()[f"main.{2 * i}.weight_u"], orc.D[f"main.{2 * i}.weight_u"]) < 1e-4
+    # (b) same weights, tapes run one at a time (eager drop-in path) -> per-tape image gradients
+    orc2, G2, D2 = build_pair(3, "f32")
+    de2 = D2.engine(B)
+    for t in range(3):
+        de2.forward([imgs[t].to(DEV)], t)
+    grad2 = torch.zeros_like(D2.arena.grad)
+    for t in (2, 1, 0):
+        dimg = de2.backward(t, 1, douts[t].to(DEV).contiguous(), grad2, need_wgrad=True, need_dimg=True)
+        assert rel_err(dimg, leaves[t].grad) < 2e-4, t
+    assert rel_err(grad2, grad) < 1e-5
 
 
 def test_generator_backward_from_given_image_gradient_fp32():
