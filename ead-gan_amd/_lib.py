@@ -30,6 +30,11 @@ class EgEpilogue(ctypes.Structure):
                 ("mask_act", ctypes.c_int), ("mask_slope", ctypes.c_float), ("out_mode", ctypes.c_int), ("sigma_rows", ctypes.c_int)]
 
 
+class EgSnLayer(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("u", ctypes.c_void_p), ("v", ctypes.c_void_p), ("sigma", ctypes.c_void_p),
+                ("u_snap", ctypes.c_void_p), ("v_snap", ctypes.c_void_p), ("R", ctypes.c_int), ("Kd", ctypes.c_int)]
+
+
 _SCALARS = {"int": ctypes.c_int, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
             "long long": ctypes.c_longlong, "eg_stream_t": ctypes.c_void_p}
 

@@ -290,7 +290,20 @@ class _DiscEngine:
         self.v = [torch.zeros(NT, kd[i], device=dev, dtype=torch.float32) for i in range(4)]
         self.coef = [torch.zeros(4, device=dev, dtype=torch.float32) for _ in range(4)]
         self.imgs = [None] * NT
+        self._sn_arrays = None
+        self._sn(0)
         self.repack()
+
+    def _sn(self, t):
+        """eg_sn_layer array of tape t (pointers are stable: module buffers and tape snapshots never move)."""
+        if self._sn_arrays is None:
+            self._sn_arrays = []
+            for tt in range(self.NT):
+                ent = [(self._m(i).weight_orig, self._m(i).weight_u, self._m(i).weight_v, self.sigma[i][tt:tt + 1], self.u[i][tt], self.v[i][tt])
+                       for i in range(4)]
+                self._sn_arrays.append(ops.sn_layers(ent))
+            self.ws.need_small(ops.sn_multi_ws_floats(self._sn_arrays[0]))
+        return self._sn_arrays[t]
 
     def _m(self, i):
         return self.disc.main[2 * i]
@@ -315,14 +328,12 @@ class _DiscEngine:
         for k, img in enumerate(imgs):
             t = t0 + k
             self.imgs[t] = img
-            for i in range(4):
-                m = self._m(i)
-                w = m.weight_orig
-                ops.sn_power_iter(w, w.shape[0], w.numel() // w.shape[0], m.weight_u, m.weight_v, self.sigma[i][t:t + 1], self.u[i][t], self.v[i][t],
-                                  ws.small, training, SN_EPS)
-                if not training:
-                    self.u[i][t].copy_(m.weight_u)
-                    self.v[i][t].copy_(m.weight_v)
+            arr = self._sn(t)
+            ops.sn_power_iter_multi(arr, self.ws.small, training, SN_EPS)
+            if not training:
+                for i in range(4):
+                    self.u[i][t].copy_(self._m(i).weight_u)
+                    self.v[i][t].copy_(self._m(i).weight_v)
             npix = B * (self.S // 2) ** 2
             ops.im2col_img(dt, img, self.patches[t * npix:(t + 1) * npix], B, self.C, self.S, self.S, 4, 2, 1, self.kp)
         g = self.geo[T]

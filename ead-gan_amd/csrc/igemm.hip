@@ -782,31 +782,49 @@ extern "C" int eg_conv_wgrad(const eg_conv* c, int dtype, const void* X, const v
 // ------------------------------------------------------------------------------------------------
 #define EG_SN_NPART 1024
 
-// one thread per (n, c): sums the splits for all taps and writes master[n][c][0..T)
-template <bool SN>
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int NS, int N, int C, int T,
-                                    float* __restrict__ out, int accumulate, const float* __restrict__ w_orig,
-                                    float* __restrict__ partials) {
+// One block per (n, chunk of 64 gathered channels): reads the [t][c] slab rows coalesced along c, sums the splits, subtracts
+// the rank-1 spectral-norm terms, transposes through LDS and read-modify-writes the master-layout gradient [n][c][t] as
+// one contiguous run of 64*T floats.  MODE 0: out += a; MODE 1: out = a (gtmp) + <a,W> partials; MODE 2: out += a - rank1.
+#define EG_RC 64
+template <int MODE>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int NS, int N, int C, int T,
+                                                           float* __restrict__ out, int accumulate, const float* __restrict__ w_orig,
+                                                           float* __restrict__ partials, int ntapes, const float* __restrict__ coef,
+                                                           const float* __restrict__ u, const float* __restrict__ v) {
+    extern __shared__ float tile[];      // [EG_RC][T+1]
     __shared__ float sm[16];
-    const long long NC = (long long)N * C;
+    const int cchunks = (C + EG_RC - 1) / EG_RC;
+    const int n = blockIdx.x / cchunks, c0 = (blockIdx.x % cchunks) * EG_RC;
+    const int cw = min(EG_RC, C - c0);
     const size_t split_stride = (size_t)NS * T * C;
-    float dot = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < NC; i += (long long)gridDim.x * blockDim.x) {
-        const int n = (int)(i / C), c = (int)(i % C);
-        for (int t = 0; t < T; ++t) {
-            const size_t si = ((size_t)n * T + t) * C + c;
+    float un[4] = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 2)
+        for (int q = 0; q < ntapes; ++q) un[q] = coef[q] * u[(size_t)q * N + n];
+    for (int e = threadIdx.x; e < T * EG_RC; e += 256) {
+        const int t = e / EG_RC, c = e % EG_RC;
+        if (c < cw) {
+            const size_t si = ((size_t)n * T + t) * C + c0 + c;
             float a = 0.f;
             for (int z = 0; z < nsplit; ++z) a += slab[z * split_stride + si];
-            const size_t oi = ((size_t)n * C + c) * T + t;
-            if (SN) {
-                out[oi] = a;
-                dot += a * w_orig[oi];
-            } else {
-                out[oi] = accumulate ? out[oi] + a : a;
-            }
+            if (MODE == 2)
+                for (int q = 0; q < ntapes; ++q) a -= un[q] * v[(size_t)q * C * T + (size_t)(c0 + c) * T + t];
+            tile[c * (T + 1) + t] = a;
         }
     }
-    if (SN) {
+    __syncthreads();
+    float dot = 0.f;
+    const size_t obase = ((size_t)n * C + c0) * T;
+    for (int e = threadIdx.x; e < cw * T; e += 256) {
+        const int c = e / T, t = e % T;
+        const float a = tile[c * (T + 1) + t];
+        if (MODE == 1) {
+            out[obase + e] = a;
+            dot += a * w_orig[obase + e];
+        } else {
+            out[obase + e] = (MODE == 2 || accumulate) ? out[obase + e] + a : a;
+        }
+    }
+    if (MODE == 1) {
         const float tot = block_sum(dot, sm);
         if (threadIdx.x == 0) partials[blockIdx.x] = tot;
     }
@@ -827,63 +845,41 @@ __global__ void sn_grad_apply_kernel(const float* __restrict__ gtmp, const float
     }
 }
 
+static inline int reduce_blocks(int n_rows, int C) { return n_rows * ((C + EG_RC - 1) / EG_RC); }
+static inline size_t reduce_lds(int T) { return (size_t)EG_RC * (T + 1) * sizeof(float); }
+
 extern "C" int eg_wgrad_reduce(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad, int accumulate, eg_stream_t s) {
-    EG_REQUIRE(slab && grad && nsplit > 0 && n_rows <= n_slab, "eg_wgrad_reduce: bad argument");
-    const long long NC = (long long)n_rows * C;
-    const int blocks = (int)((NC + 255) / 256 > 2048 ? 2048 : (NC + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T, grad, accumulate,
-                       (const float*)nullptr, (float*)nullptr);
+    EG_REQUIRE(slab && grad && nsplit > 0 && n_rows <= n_slab && T > 0 && T <= 64, "eg_wgrad_reduce: bad argument");
+    hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3(reduce_blocks(n_rows, C)), dim3(256), reduce_lds(T), (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T,
+                       grad, accumulate, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
     EG_LAUNCH_CHECK();
     return 0;
-}
-
-// single-pass reduce with the spectral-norm rank-1 terms of up to 4 tapes
-__global__ void wgrad_reduce_rank1_kernel(const float* __restrict__ slab, int nsplit, int NS, int N, int C, int T, float* __restrict__ out,
-                                          int ntapes, const float* __restrict__ coef, const float* __restrict__ u, const float* __restrict__ v) {
-    const long long NC = (long long)N * C;
-    const size_t split_stride = (size_t)NS * T * C;
-    float cf[4];
-    for (int q = 0; q < 4; ++q) cf[q] = q < ntapes ? coef[q] : 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < NC; i += (long long)gridDim.x * blockDim.x) {
-        const int n = (int)(i / C), c = (int)(i % C);
-        float un[4];
-        for (int q = 0; q < 4; ++q) un[q] = q < ntapes ? cf[q] * u[(size_t)q * N + n] : 0.f;
-        for (int t = 0; t < T; ++t) {
-            const size_t si = ((size_t)n * T + t) * C + c;
-            float a = 0.f;
-            for (int z = 0; z < nsplit; ++z) a += slab[z * split_stride + si];
-            const size_t kk = (size_t)c * T + t;
-            for (int q = 0; q < ntapes; ++q) a -= un[q] * v[(size_t)q * C * T + kk];
-            const size_t oi = ((size_t)n * C + c) * T + t;
-            out[oi] += a;
-        }
-    }
 }
 
 extern "C" int eg_wgrad_reduce_rank1(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad, int ntapes,
                                      const float* coef, const float* u, const float* v, eg_stream_t s) {
-    EG_REQUIRE(slab && grad && nsplit > 0 && n_rows <= n_slab && ntapes >= 0 && ntapes <= 4 && (ntapes == 0 || (coef && u && v)),
+    EG_REQUIRE(slab && grad && nsplit > 0 && n_rows <= n_slab && ntapes >= 0 && ntapes <= 4 && (ntapes == 0 || (coef && u && v)) && T > 0 && T <= 64,
                "eg_wgrad_reduce_rank1: bad argument");
-    const long long NC = (long long)n_rows * C;
-    const int blocks = (int)((NC + 255) / 256 > 4096 ? 4096 : (NC + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_rank1_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T, grad, ntapes, coef, u, v);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<2>, dim3(reduce_blocks(n_rows, C)), dim3(256), reduce_lds(T), (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T,
+                       grad, 1, (const float*)nullptr, (float*)nullptr, ntapes, coef, u, v);
     EG_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int eg_sn_partials(void) { return EG_SN_NPART; }
+extern "C" int eg_sn_partials(void) { return 1 << 17; }
 
 extern "C" int eg_wgrad_reduce_sn(const eg_conv* c, const float* slab, int nsplit, const float* w_orig, const float* sigma,
                                   const float* u, const float* v, float* gtmp, float* partials, float* grad, eg_stream_t s) {
     EG_REQUIRE(c && slab && w_orig && sigma && u && v && gtmp && partials && grad && nsplit > 0, "eg_wgrad_reduce_sn: bad argument");
-    const long long NC = (long long)c->Cout * c->Cin;
-    const int blocks = (int)((NC + 255) / 256 > EG_SN_NPART ? EG_SN_NPART : (NC + 255) / 256);
-    hipLaunchKernelGGL(wgrad_reduce_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)s, slab, nsplit, c->Cout, c->Cout, c->Cin,
-                       c->k * c->k, gtmp, 0, w_orig, partials);
-    const long long total = NC * c->k * c->k;
+    const int T = c->k * c->k;
+    const int blocks = reduce_blocks(c->Cout, c->Cin);
+    EG_REQUIRE(blocks <= (1 << 17), "eg_wgrad_reduce_sn: layer too large for the partials buffer");
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(blocks), dim3(256), reduce_lds(T), (hipStream_t)s, slab, nsplit, c->Cout, c->Cout, c->Cin, T, gtmp, 0,
+                       w_orig, partials, 0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
+    const long long total = (long long)c->Cout * c->Cin * T;
     const int blocks2 = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     hipLaunchKernelGGL(sn_grad_apply_kernel, dim3(blocks2), dim3(256), 0, (hipStream_t)s, gtmp, partials, blocks, sigma, u, v, total,
-                       c->Cin * c->k * c->k, grad);
+                       c->Cin * T, grad);
     EG_LAUNCH_CHECK();
     return 0;
 }

@@ -38,7 +38,8 @@ __global__ void bn_stats_partial_kernel(const T* __restrict__ x, int M, int C, f
 
 // one wave per channel: lanes combine row-block partials (Chan) in fp64, then a shuffle tree merges the lanes
 __global__ void bn_stats_final_kernel(const float* __restrict__ partial, int nrb, int C, int M, float eps, float momentum,
-                                      float* running_mean, float* running_var, long long* nbt, float* save_mean, float* save_invstd) {
+                                      float* running_mean, float* running_var, long long* nbt, float* save_mean, float* save_invstd,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ coef) {
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
@@ -67,7 +68,10 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ partial, int nrb
     if (lane != 0) return;
     const double var = m2 / (double)M;
     save_mean[c] = (float)mean;
-    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    const float istd = (float)(1.0 / sqrt(var + (double)eps));
+    save_invstd[c] = istd;
+    coef[c] = gamma[c] * istd;
+    coef[C + c] = beta[c] - (float)mean * gamma[c] * istd;
     if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
     if (running_var) {
         const double unb = M > 1 ? m2 / (double)(M - 1) : var;
@@ -75,27 +79,39 @@ __global__ void bn_stats_final_kernel(const float* __restrict__ partial, int nrb
     }
 }
 
+// y = act(x * A[c] + B[c]);  each thread keeps its 16-byte channel chunk fixed (grid stride is a multiple of the row length)
 template <typename T>
-__global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, size_t total, int C, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd, int act,
-                                float slope) {
+__global__ void bn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, size_t nrows, int C, const float* __restrict__ coef, int act, float slope) {
     constexpr int VEC = Elt<T>::VEC;
-    const size_t nchunk = total / VEC;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunk; i += (size_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)((i * VEC) % C);
-        uint4 v = *reinterpret_cast<const uint4*>(x + i * VEC);
+    const int cpr = C / VEC;
+    const int chunk = (blockIdx.x * blockDim.x + threadIdx.x) % cpr;
+    const size_t row0 = (size_t)(blockIdx.x * blockDim.x + threadIdx.x) / cpr;
+    const size_t rstride = (size_t)gridDim.x * blockDim.x / cpr;
+    float A[VEC], Bc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { A[j] = coef[chunk * VEC + j]; Bc[j] = coef[C + chunk * VEC + j]; }
+    for (size_t r = row0; r < nrows; r += rstride) {
+        const size_t o = r * C + (size_t)chunk * VEC;
+        uint4 v = *reinterpret_cast<const uint4*>(x + o);
         T* e = reinterpret_cast<T*>(&v);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const int c = c0 + j;
-            float f = (Elt<T>::ld(e + j) - mean[c]) * invstd[c] * gamma[c] + beta[c];
-            Elt<T>::st(e + j, eg_act(f, act, slope));
-        }
-        *reinterpret_cast<uint4*>(y + i * VEC) = v;
+        for (int j = 0; j < VEC; ++j) Elt<T>::st(e + j, eg_act(Elt<T>::ld(e + j) * A[j] + Bc[j], act, slope));
+        *reinterpret_cast<uint4*>(y + o) = v;
     }
 }
 
-extern "C" size_t eg_bn_ws_floats(int M, int C) { return (size_t)cdiv(M, BN_RPB) * 3 * C; }
+static inline int bn_apply_blocks(size_t nrows, int cpr) {
+    // total threads must be a multiple of cpr so that a thread's chunk column never changes across its grid-stride rows
+    size_t want = (nrows * cpr + 255) / 256;
+    if (want > 2048) want = 2048;
+    int a = cpr, b = 256;
+    while (b) { const int t = a % b; a = b; b = t; }      // a = gcd(cpr, 256)
+    const size_t mult = (size_t)cpr / a;                   // blocks must be a multiple of this
+    want = (want + mult - 1) / mult * mult;
+    return (int)want;
+}
+
+extern "C" size_t eg_bn_ws_floats(int M, int C) { return (size_t)cdiv(M, BN_RPB) * 3 * C + 5 * (size_t)C; }
 
 extern "C" int eg_bn_fwd_train(int dtype, const void* x, void* y, int M, int C, const float* gamma, const float* beta, float eps,
                                float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
@@ -107,13 +123,13 @@ extern "C" int eg_bn_fwd_train(int dtype, const void* x, void* y, int M, int C, 
     hipStream_t st = (hipStream_t)s;
     if (dtype == EG_F32) hipLaunchKernelGGL(bn_stats_partial_kernel<float>, g1, dim3(256), 0, st, (const float*)x, M, C, ws);
     else hipLaunchKernelGGL(bn_stats_partial_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)x, M, C, ws);
+    const int cpr = C / (dtype == EG_F32 ? 4 : 8);
+    float* coef = ws + (size_t)nrb * 3 * C;           // 2*C floats behind the partials
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, ws, nrb, C, M, eps, momentum, running_mean, running_var,
-                       num_batches_tracked, save_mean, save_invstd);
-    const size_t total = (size_t)M * C;
-    const size_t nchunk = total / (dtype == EG_F32 ? 4 : 8);
-    const int blocks = (int)((nchunk + 255) / 256 > 4096 ? 4096 : (nchunk + 255) / 256);
-    if (dtype == EG_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, total, C, gamma, beta, save_mean, save_invstd, act, slope);
-    else hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, total, C, gamma, beta, save_mean, save_invstd, act, slope);
+                       num_batches_tracked, save_mean, save_invstd, gamma, beta, coef);
+    const int blocks = bn_apply_blocks((size_t)M, cpr);
+    if (dtype == EG_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, (size_t)M, C, coef, act, slope);
+    else hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (size_t)M, C, coef, act, slope);
     EG_LAUNCH_CHECK();
     return 0;
 }
@@ -156,7 +172,10 @@ __global__ void bn_bwd_partial_kernel(const T* __restrict__ z, const T* __restri
     }
 }
 
-__global__ void bn_bwd_final_kernel(const float* __restrict__ partial, int nrb, int C, float* sums, float* dgamma, float* dbeta) {
+// dz = A*dy - Bz*z - Cc  with  A = g*is, Bz = g*is*is*s2/M, Cc = g*is*(s1/M - mean*is*s2/M);  mask: z*P + Q > 0
+__global__ void bn_bwd_final_kernel(const float* __restrict__ partial, int nrb, int C, float* sums, float* dgamma, float* dbeta,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, int M, float* __restrict__ coef) {
     const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (c >= C) return;
@@ -172,30 +191,41 @@ __global__ void bn_bwd_final_kernel(const float* __restrict__ partial, int nrb, 
     sums[C + c] = s2;
     if (dbeta) dbeta[c] += s1;
     if (dgamma) dgamma[c] += s2;
+    const float g = gamma[c], is = invstd[c], mu = mean[c], invM = 1.f / (float)M;
+    coef[c] = g * is;
+    coef[C + c] = g * is * is * s2 * invM;
+    coef[2 * C + c] = g * is * (s1 * invM - mu * is * s2 * invM);
+    coef[3 * C + c] = g * is;
+    coef[4 * C + c] = beta[c] - mu * g * is;
 }
 
 template <typename T>
-__global__ void bn_bwd_apply_kernel(const T* __restrict__ z, const T* __restrict__ da, T* __restrict__ dz, size_t total, int C, int M,
-                                    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
-                                    const float* __restrict__ invstd, const float* __restrict__ sums, int act, float slope) {
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ z, const T* __restrict__ da, T* __restrict__ dz, size_t nrows, int C,
+                                    const float* __restrict__ coef, int act, float slope) {
     constexpr int VEC = Elt<T>::VEC;
-    const size_t nchunk = total / VEC;
-    const float invM = 1.f / (float)M;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nchunk; i += (size_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)((i * VEC) % C);
-        uint4 vz = *reinterpret_cast<const uint4*>(z + i * VEC);
-        uint4 vd = *reinterpret_cast<const uint4*>(da + i * VEC);
+    const int cpr = C / VEC;
+    const int chunk = (blockIdx.x * blockDim.x + threadIdx.x) % cpr;
+    const size_t row0 = (size_t)(blockIdx.x * blockDim.x + threadIdx.x) / cpr;
+    const size_t rstride = (size_t)gridDim.x * blockDim.x / cpr;
+    float A[VEC], Bz[VEC], Cc[VEC], P[VEC], Q[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int c = chunk * VEC + j;
+        A[j] = coef[c]; Bz[j] = coef[C + c]; Cc[j] = coef[2 * C + c]; P[j] = coef[3 * C + c]; Q[j] = coef[4 * C + c];
+    }
+    for (size_t r = row0; r < nrows; r += rstride) {
+        const size_t o = r * C + (size_t)chunk * VEC;
+        const uint4 vz = *reinterpret_cast<const uint4*>(z + o);
+        uint4 vd = *reinterpret_cast<const uint4*>(da + o);
         const T* ez = reinterpret_cast<const T*>(&vz);
         T* ed = reinterpret_cast<T*>(&vd);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-            const int c = c0 + j;
-            const float is = invstd[c], g = gamma[c];
-            const float xh = (Elt<T>::ld(ez + j) - mean[c]) * is;
-            const float dy = Elt<T>::ld(ed + j) * pre_act_grad(xh * g + beta[c], act, slope);
-            Elt<T>::st(ed + j, g * is * (dy - sums[c] * invM - xh * sums[C + c] * invM));
+            const float zz = Elt<T>::ld(ez + j);
+            const float dy = Elt<T>::ld(ed + j) * pre_act_grad(zz * P[j] + Q[j], act, slope);
+            Elt<T>::st(ed + j, A[j] * dy - Bz[j] * zz - Cc[j]);
         }
-        *reinterpret_cast<uint4*>(dz + i * VEC) = vd;
+        *reinterpret_cast<uint4*>(dz + o) = vd;
     }
 }
 
@@ -209,12 +239,12 @@ extern "C" int eg_bn_bwd(int dtype, const void* z, const void* da, void* dz, int
     hipStream_t st = (hipStream_t)s;
     if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_partial_kernel<float>, g1, dim3(256), 0, st, (const float*)z, (const float*)da, M, C, gamma, beta, save_mean, save_invstd, act, slope, ws);
     else hipLaunchKernelGGL(bn_bwd_partial_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)da, M, C, gamma, beta, save_mean, save_invstd, act, slope, ws);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, ws, nrb, C, sums, dgamma, dbeta);
-    const size_t total = (size_t)M * C;
-    const size_t nchunk = total / (dtype == EG_F32 ? 4 : 8);
-    const int blocks = (int)((nchunk + 255) / 256 > 4096 ? 4096 : (nchunk + 255) / 256);
-    if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)z, (const float*)da, (float*)dz, total, C, M, gamma, beta, save_mean, save_invstd, sums, act, slope);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)da, (bf16_t*)dz, total, C, M, gamma, beta, save_mean, save_invstd, sums, act, slope);
+    const int cpr = C / (dtype == EG_F32 ? 4 : 8);
+    float* coef = ws + (size_t)nrb * 3 * C;
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, ws, nrb, C, sums, dgamma, dbeta, gamma, beta, save_mean, save_invstd, M, coef);
+    const int blocks = bn_apply_blocks((size_t)M, cpr);
+    if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)z, (const float*)da, (float*)dz, (size_t)M, C, coef, act, slope);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)da, (bf16_t*)dz, (size_t)M, C, coef, act, slope);
     EG_LAUNCH_CHECK();
     return 0;
 }

@@ -91,6 +91,136 @@ extern "C" int eg_sn_power_iter(const float* w_orig, int R, int Kd, float* u, fl
     return 0;
 }
 
+// ---- all spectrally-normalised layers of a network in ONE launch per stage (grid.z = layer) -------------------------
+#define SN_MAXL 8
+struct SnMulti {
+    const float* w[SN_MAXL];
+    float* u[SN_MAXL];
+    float* v[SN_MAXL];
+    float* sigma[SN_MAXL];
+    float* u_snap[SN_MAXL];
+    float* v_snap[SN_MAXL];
+    int R[SN_MAXL], Kd[SN_MAXL];
+    long long ws_off[SN_MAXL];
+    float* ws;
+    float eps;
+};
+
+__global__ void snm_wtu_partial_kernel(const SnMulti p) {
+    const int l = blockIdx.z, R = p.R[l], Kd = p.Kd[l];
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= Kd) return;
+    const int rb = (R + SN_NRB - 1) / SN_NRB;
+    const int r0 = blockIdx.y * rb, r1 = min(R, r0 + rb);
+    const float* __restrict__ W = p.w[l];
+    const float* __restrict__ u = p.u[l];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
+        a0 += W[(size_t)r * Kd + k] * u[r];
+        a1 += W[(size_t)(r + 1) * Kd + k] * u[r + 1];
+        a2 += W[(size_t)(r + 2) * Kd + k] * u[r + 2];
+        a3 += W[(size_t)(r + 3) * Kd + k] * u[r + 3];
+    }
+    for (; r < r1; ++r) a0 += W[(size_t)r * Kd + k] * u[r];
+    p.ws[p.ws_off[l] + (size_t)blockIdx.y * Kd + k] = (a0 + a1) + (a2 + a3);
+}
+
+__global__ void snm_v_final_kernel(const SnMulti p) {
+    __shared__ float sm[16];
+    const int l = blockIdx.z, Kd = p.Kd[l];
+    const float* partial = p.ws + p.ws_off[l];
+    float* v = p.v[l];
+    float* v_snap = p.v_snap[l];
+    float ss = 0.f;
+    for (int k = threadIdx.x; k < Kd; k += blockDim.x) {
+        float t = 0.f;
+        for (int r = 0; r < SN_NRB; ++r) t += partial[(size_t)r * Kd + k];
+        v[k] = t;
+        ss += t * t;
+    }
+    const float nrm = sqrtf(block_sum(ss, sm));
+    const float inv = 1.f / fmaxf(nrm, p.eps);
+    for (int k = threadIdx.x; k < Kd; k += blockDim.x) {
+        const float vn = v[k] * inv;
+        v[k] = vn;
+        if (v_snap) v_snap[k] = vn;
+    }
+}
+
+__global__ void snm_wv_kernel(const SnMulti p) {
+    __shared__ float sm[16];
+    const int l = blockIdx.z, R = p.R[l], Kd = p.Kd[l];
+    const int r = blockIdx.x;
+    if (r >= R) return;
+    const float* __restrict__ W = p.w[l] + (size_t)r * Kd;
+    const float* __restrict__ v = p.v[l];
+    float a = 0.f;
+    for (int k = threadIdx.x; k < Kd; k += blockDim.x) a += W[k] * v[k];
+    const float tot = block_sum(a, sm);
+    if (threadIdx.x == 0) p.ws[p.ws_off[l] + (size_t)SN_NRB * Kd + r] = tot;
+}
+
+__global__ void snm_u_final_kernel(const SnMulti p, int training) {
+    __shared__ float sm[16];
+    const int l = blockIdx.z, R = p.R[l], Kd = p.Kd[l];
+    const float* s = p.ws + p.ws_off[l] + (size_t)SN_NRB * Kd;
+    float* u = p.u[l];
+    if (!training) {
+        float d = 0.f;
+        for (int r = threadIdx.x; r < R; r += blockDim.x) d += u[r] * s[r];
+        const float sg = block_sum(d, sm);
+        if (threadIdx.x == 0) p.sigma[l][0] = sg;
+        return;
+    }
+    float ss = 0.f;
+    for (int r = threadIdx.x; r < R; r += blockDim.x) ss += s[r] * s[r];
+    const float nrm = sqrtf(block_sum(ss, sm));
+    const float inv = 1.f / fmaxf(nrm, p.eps);
+    float d = 0.f;
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        const float un = s[r] * inv;
+        u[r] = un;
+        if (p.u_snap[l]) p.u_snap[l][r] = un;
+        d += un * s[r];
+    }
+    const float sg = block_sum(d, sm);
+    if (threadIdx.x == 0) p.sigma[l][0] = sg;
+}
+
+extern "C" size_t eg_sn_multi_ws_floats(const eg_sn_layer* layers, int nlayers) {
+    size_t tot = 0;
+    for (int i = 0; i < nlayers; ++i) tot += (size_t)SN_NRB * layers[i].Kd + layers[i].R;
+    return tot;
+}
+
+extern "C" int eg_sn_power_iter_multi(const eg_sn_layer* layers, int nlayers, float* ws, int training, float eps, eg_stream_t s) {
+    EG_REQUIRE(layers && ws && nlayers > 0 && nlayers <= SN_MAXL, "eg_sn_power_iter_multi: bad argument");
+    SnMulti p;
+    memset(&p, 0, sizeof(p));
+    long long off = 0;
+    int maxK = 0, maxR = 0;
+    for (int i = 0; i < nlayers; ++i) {
+        const eg_sn_layer& L = layers[i];
+        EG_REQUIRE(L.w && L.u && L.v && L.sigma && L.R > 0 && L.Kd > 0, "eg_sn_power_iter_multi: bad layer %d", i);
+        p.w[i] = L.w; p.u[i] = L.u; p.v[i] = L.v; p.sigma[i] = L.sigma; p.u_snap[i] = L.u_snap; p.v_snap[i] = L.v_snap;
+        p.R[i] = L.R; p.Kd[i] = L.Kd; p.ws_off[i] = off;
+        off += (long long)SN_NRB * L.Kd + L.R;
+        maxK = L.Kd > maxK ? L.Kd : maxK;
+        maxR = L.R > maxR ? L.R : maxR;
+    }
+    p.ws = ws; p.eps = eps;
+    hipStream_t st = (hipStream_t)s;
+    if (training) {
+        hipLaunchKernelGGL(snm_wtu_partial_kernel, dim3(cdiv(maxK, 256), SN_NRB, nlayers), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(snm_v_final_kernel, dim3(1, 1, nlayers), dim3(1024), 0, st, p);
+    }
+    hipLaunchKernelGGL(snm_wv_kernel, dim3(maxR, 1, nlayers), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(snm_u_final_kernel, dim3(1, 1, nlayers), dim3(1024), 0, st, p, training);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- Adam -----------------------------------------------------------------------------------------
 __global__ void adam_tick_kernel(int* step) { step[0] += 1; }
 

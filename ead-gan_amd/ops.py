@@ -10,7 +10,7 @@ import ctypes
 import torch
 
 from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, EG_BF16, EG_F32, OUT_NCHW_F32,
-                   OUT_NHWC, EgConv, EgEpilogue, lib)
+                   OUT_NHWC, EgConv, EgEpilogue, EgSnLayer, lib)
 
 __all__ = ["EG_F32", "EG_BF16", "ACT_NONE", "ACT_LRELU", "ACT_RELU", "ACT_TANH", "ACT_SIGMOID", "OUT_NHWC",
            "OUT_NCHW_F32"]
@@ -228,6 +228,22 @@ def sn_ws_floats(R, Kd):
 
 def sn_power_iter(w_orig, R, Kd, u, v, sigma, u_snap, v_snap, ws, training=True, eps=1e-12):
     lib().call("eg_sn_power_iter", _p(w_orig), R, Kd, _p(u), _p(v), _p(sigma), _p(u_snap), _p(v_snap), _p(ws), int(training), eps, _stream())
+
+
+def sn_layers(entries):
+    """entries: list of (w_orig, u, v, sigma, u_snap, v_snap) tensors -> ctypes array of eg_sn_layer (keep it alive)."""
+    arr = (EgSnLayer * len(entries))()
+    for i, (w, u, v, sg, us, vs) in enumerate(entries):
+        arr[i] = EgSnLayer(_p(w), _p(u), _p(v), _p(sg), _p(us), _p(vs), w.shape[0], w.numel() // w.shape[0])
+    return arr
+
+
+def sn_multi_ws_floats(arr):
+    return lib().query("eg_sn_multi_ws_floats", arr, len(arr))
+
+
+def sn_power_iter_multi(arr, ws, training=True, eps=1e-12):
+    lib().call("eg_sn_power_iter_multi", arr, len(arr), _p(ws), int(training), eps, _stream())
 
 
 def adam_step(p, g, m, v, n, lr, b1, b2, eps, step, tick=True):

@@ -160,6 +160,19 @@ size_t eg_sn_ws_floats(int R, int Kd);
 int eg_sn_power_iter(const float* w_orig, int R, int Kd, float* u, float* v, float* sigma, float* u_snap,
                      float* v_snap, float* ws, int training, float eps, eg_stream_t s);
 
+/* all spectrally-normalised layers of a network in one launch per stage (4 launches per forward instead of 4 per layer) */
+typedef struct eg_sn_layer {
+    const float* w;
+    float* u;
+    float* v;
+    float* sigma;
+    float* u_snap;
+    float* v_snap;
+    int R, Kd;
+} eg_sn_layer;
+size_t eg_sn_multi_ws_floats(const eg_sn_layer* layers, int nlayers);
+int eg_sn_power_iter_multi(const eg_sn_layer* layers, int nlayers, float* ws, int training, float eps, eg_stream_t s);
+
 /* --- Adam (torch.optim.Adam, celebA/EAD-GAN_celebA.py:211-217) over a flat fp32 arena ----------------------- */
 int eg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                  int* step, int tick, eg_stream_t s);

@@ -384,3 +384,29 @@ def test_tanh_backward_with_bias_gradient_and_cast_pad():
         ops.cast_pad(dtype, src.to(DEV), dst, 7, 19, 32)
         torch.testing.assert_close(dst.float().cpu()[:, :19], rq(src, dtype), rtol=0, atol=0)
         assert float(dst.float().abs()[:, 19:].max()) == 0.0
+
+
+def test_spectral_norm_multi_layer_launch_matches_single():
+    g = torch.Generator().manual_seed(13)
+    shapes = [(128, 48), (256, 2048), (512, 4096), (16, 9)]
+    ws_single = torch.empty(max(ops.sn_ws_floats(r, k) for r, k in shapes), device=DEV)
+    ent, ref = [], []
+    for R, Kd in shapes:
+        w = torch.randn(R, Kd, generator=g).to(DEV)
+        u = F.normalize(torch.randn(R, generator=g), dim=0).to(DEV)
+        v = F.normalize(torch.randn(Kd, generator=g), dim=0).to(DEV)
+        sg, us, vs = torch.empty(1, device=DEV), torch.empty(R, device=DEV), torch.empty(Kd, device=DEV)
+        u1, v1, s1 = u.clone(), v.clone(), torch.empty(1, device=DEV)
+        ops.sn_power_iter(w, R, Kd, u1, v1, s1, None, None, ws_single, True, 1e-12)
+        ent.append((w, u, v, sg, us, vs))
+        ref.append((u1, v1, s1))
+    arr = ops.sn_layers(ent)
+    ws = torch.empty(ops.sn_multi_ws_floats(arr), device=DEV)
+    ops.sn_power_iter_multi(arr, ws, True, 1e-12)
+    torch.cuda.synchronize()
+    for (w, u, v, sg, us, vs), (u1, v1, s1) in zip(ent, ref):
+        torch.testing.assert_close(u, u1, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(v, v1, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(us, u1, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(vs, v1, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(sg, s1, rtol=1e-5, atol=1e-6)
