@@ -609,6 +609,29 @@ class CelebATrainer:
         de.repack()
 
     # -- public API -----------------------------------------------------------------------------------
+    def import_adam_state(self, opt_G, opt_D, opt_info):
+        """Load exp_avg / exp_avg_sq / step of three ``torch.optim.Adam`` objects built like the reference's
+        (celebA/EAD-GAN_celebA.py:211-217: G params | D params | G+D params, in ``.parameters()`` order)."""
+        def fill(opt, params, m, v, off0=0):
+            off = off0
+            step = 0
+            for p in params:
+                st = opt.state.get(p, {})
+                n = p.numel()
+                if st:
+                    m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                    v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    step = int(st["step"])
+                off += n
+            return step
+        gp, dp = opt_G.param_groups[0]["params"], opt_D.param_groups[0]["params"]
+        ip = opt_info.param_groups[0]["params"]
+        s0 = fill(opt_G, gp, self.mG, self.vG)
+        s1 = fill(opt_D, dp, self.mD, self.vD)
+        s2 = fill(opt_info, ip[:len(gp)], self.miG, self.viG)
+        fill(opt_info, ip[len(gp):], self.miD, self.viD)
+        self.steps.copy_(torch.tensor([s0, s1, s2], dtype=torch.int32))
+
     def load_inputs(self, real_imgs, z, code, labels):
         self.real.copy_(real_imgs, non_blocking=True)
         self.z.copy_(z, non_blocking=True)

