@@ -45,26 +45,19 @@ def parse():
     return ap.parse_args()
 
 
-def roofline_pass(eg, trainer, dtype):
-    """Replays every implicit-GEMM launch of one iteration, each bracketed by HIP events on the launch stream, and
-    returns the per-kernel table + the dominant kernel's roofline object."""
+def roofline_pass(eg, trainer, dtype, iters=3):
+    """Runs `iters` eager iterations with every implicit-GEMM launch bracketed by HIP events on the launch stream (the
+    launches sit in their real place in the step, so cache state is the real one) and returns the per-kernel table +
+    the roofline object of the dominant kernel (largest total time)."""
     ops = eg.ops
     ops.RECORDER = []
-    trainer._step_body()
+    for _ in range(iters):
+        trainer._step_body()
     torch.cuda.synchronize()
     rec, ops.RECORDER = ops.RECORDER, None
-    REP = 5
-    table = {}
-    detail = {}
-    for label, flops, fn, shape in rec:
-        fn()                                            # warm
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(REP):
-            fn()
-        e1.record()
-        e1.synchronize()
-        ms = e0.elapsed_time(e1) / REP
+    table, detail = {}, {}
+    for label, flops, e0, e1, shape in rec:
+        ms = e0.elapsed_time(e1)
         t = table.setdefault(label, {"launches": 0, "ms": 0.0, "flops": 0.0})
         t["launches"] += 1
         t["ms"] += ms
@@ -72,9 +65,13 @@ def roofline_pass(eg, trainer, dtype):
         d = detail.setdefault((label, shape), [0, 0.0, flops])
         d[0] += 1
         d[1] += ms
+    for t in table.values():
+        t["launches"] /= iters
+        t["ms"] /= iters
+        t["flops"] /= iters
     if os.environ.get("EG_BENCH_DETAIL"):
         for (label, shape), (n, ms, fl) in sorted(detail.items(), key=lambda kv: -kv[1][1]):
-            print(f"# {label:34s} {shape:44s} x{n:2d}  {ms / n * 1e3:8.1f} us/launch  {fl / (ms / n * 1e-3) / 1e12:7.1f} TF/s  total {ms:6.3f} ms", file=sys.stderr)
+            print(f"# {label:34s} {shape:44s} x{n / iters:4.1f}  {ms / n * 1e3:8.1f} us/launch  {fl / (ms / n * 1e-3) / 1e12:7.1f} TF/s  total {ms / iters:6.3f} ms/iter", file=sys.stderr)
     if not table:
         return None, table
     dom = max(table, key=lambda k: table[k]["ms"])
@@ -82,7 +79,7 @@ def roofline_pass(eg, trainer, dtype):
     peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": None, "launches_per_step": d["launches"],
+            "frac": round(achieved / peak, 4), "traffic": None, "launches_per_step": round(d["launches"], 1),
             "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3)}
     return roof, table
 

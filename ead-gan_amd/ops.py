@@ -70,8 +70,9 @@ def pack_strided(dtype, w, wp, N, K, Kpad, n_div, s_hi, s_lo, s_k):
     lib().call("eg_pack_strided", dtype, _p(w), _p(wp), N, K, Kpad, n_div, s_hi, s_lo, s_k, _stream())
 
 
-# Optional launch recorder (bench.py's roofline pass): when set to a list, every implicit-GEMM launch appends
-# (kernel label, algorithmic FLOPs, replay closure).  Never set on the training path.
+# Optional launch recorder (bench.py's roofline pass): when set to a list, every implicit-GEMM launch is bracketed by HIP
+# events on the launch stream and appends (kernel label, algorithmic FLOPs, start event, end event, shape string).
+# Never set on the training path.
 RECORDER = None
 
 
@@ -79,7 +80,7 @@ def _out_hw(c):
     return ((c.H << c.up) + 2 * c.pad - c.k) // c.stride + 1, ((c.W << c.up) + 2 * c.pad - c.k) // c.stride + 1
 
 
-def _record(kind, c, dtype, fn):
+def _timed(kind, c, dtype, args):
     oh, ow = _out_hw(c)
     M = c.B * oh * ow
     flops = 2.0 * M * c.Cout * c.Cin * c.k * c.k
@@ -90,22 +91,25 @@ def _record(kind, c, dtype, fn):
         N, nph = (c.Cout, 1) if kind == "fwd" else (c.Cin, c.stride * c.stride)
         tile = lib().query("eg_igemm_nt_tile", M, N, nph)
         label = f"igemm_nt_kernel<{tname},{tile // 1000},{tile % 1000}>"
-    shape = f"{kind} B{c.B} H{c.H} Cin{c.Cin} Cout{c.Cout} k{c.k} s{c.stride}"
-    RECORDER.append((label, flops, fn, shape))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    lib().call(*args, _stream())
+    e1.record()
+    RECORDER.append((label, flops, e0, e1, f"{kind} B{c.B} H{c.H} Cin{c.Cin} Cout{c.Cout} k{c.k} s{c.stride}"))
 
 
 def conv_fwd(c, dtype, X, wp, Y, ep=None):
     args = ("eg_conv_fwd", ctypes.byref(c), dtype, _p(X), _p(wp), _p(Y), ctypes.byref(ep) if ep is not None else None)
-    lib().call(*args, _stream())
     if RECORDER is not None:
-        _record("fwd", c, dtype, lambda keep=(c, ep, X, wp, Y): lib().call(*args, _stream()))
+        return _timed("fwd", c, dtype, args)
+    lib().call(*args, _stream())
 
 
 def conv_bwd_data(c, dtype, dY, wp, dX, ep=None):
     args = ("eg_conv_bwd_data", ctypes.byref(c), dtype, _p(dY), _p(wp), _p(dX), ctypes.byref(ep) if ep is not None else None)
-    lib().call(*args, _stream())
     if RECORDER is not None:
-        _record("bwd", c, dtype, lambda keep=(c, ep, dY, wp, dX): lib().call(*args, _stream()))
+        return _timed("bwd", c, dtype, args)
+    lib().call(*args, _stream())
 
 
 def conv_wgrad_ws_bytes(c, dtype):
@@ -115,9 +119,10 @@ def conv_wgrad_ws_bytes(c, dtype):
 def conv_wgrad(c, dtype, X, dY, slab) -> int:
     ns = ctypes.c_int(0)
     args = ("eg_conv_wgrad", ctypes.byref(c), dtype, _p(X), _p(dY), _p(slab), ctypes.addressof(ns))
-    lib().call(*args, _stream())
     if RECORDER is not None:
-        _record("tn", c, dtype, lambda keep=(c, ns, X, dY, slab): lib().call(*args, _stream()))
+        _timed("tn", c, dtype, args)
+    else:
+        lib().call(*args, _stream())
     return ns.value
 
 
