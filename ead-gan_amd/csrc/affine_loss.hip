@@ -193,3 +193,158 @@ extern "C" int eg_loss_affine_rpqxy(const float* o_real, const float* o_trans, i
     EG_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// MNIST: theta from 7 codes, and the affine-consistency loss through the frozen MLP approximator
+// (MNIST/utils_rpqmnxy.py:12-43,117-134).  One block (256 threads) per sample; hidden width 256.
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ void theta_rpqmnxy_kernel(const float* __restrict__ code, int ldc, int B, float* __restrict__ theta) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float c[7];
+    for (int i = 0; i < 7; ++i) c[i] = code[(size_t)b * ldc + i];
+    const Aff<float> m = matrix_rpqmnxy<float>(c);
+    float* t = theta + (size_t)b * 6;
+    t[0] = m.a; t[1] = m.b; t[2] = m.c; t[3] = m.d; t[4] = m.e; t[5] = m.f;
+}
+extern "C" int eg_theta_rpqmnxy(const float* code, int ldc, int B, float* theta, eg_stream_t s) {
+    EG_REQUIRE(code && theta && ldc >= 7, "eg_theta_rpqmnxy: bad argument");
+    hipLaunchKernelGGL(theta_rpqmnxy_kernel, dim3(cdiv(B, 128)), dim3(128), 0, (hipStream_t)s, code, ldc, B, theta);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+#define MLP_H 256
+// float offsets inside the mlp blob
+#define MLP_W1 0
+#define MLP_B1 (MLP_W1 + MLP_H * 6)
+#define MLP_W2 (MLP_B1 + MLP_H)
+#define MLP_B2 (MLP_W2 + MLP_H * MLP_H)
+#define MLP_W3 (MLP_B2 + MLP_H)
+#define MLP_B3 (MLP_W3 + MLP_H * MLP_H)
+#define MLP_W4 (MLP_B3 + MLP_H)
+#define MLP_B4 (MLP_W4 + MLP_H * MLP_H)
+#define MLP_W5 (MLP_B4 + MLP_H)
+#define MLP_B5 (MLP_W5 + 7 * MLP_H)
+#define MLP_W2T (MLP_B5 + 8)
+#define MLP_W3T (MLP_W2T + MLP_H * MLP_H)
+#define MLP_W4T (MLP_W3T + MLP_H * MLP_H)
+#define MLP_TOTAL (MLP_W4T + MLP_H * MLP_H)
+
+extern "C" size_t eg_mlp_rpqmnxy_floats(void) { return MLP_TOTAL; }
+
+__device__ __forceinline__ float lrelu01(float v) { return v > 0.f ? v : 0.01f * v; }
+
+__global__ __launch_bounds__(256) void affine_reg_rpqmnxy_kernel(const float* __restrict__ o_real, const float* __restrict__ o_trans, int ld, int c0,
+                                                                 int B, const float* __restrict__ code, int ldc, const float* __restrict__ mlp,
+                                                                 float scale, float* __restrict__ sample_loss, float* __restrict__ d_real,
+                                                                 float* __restrict__ d_trans, float* __restrict__ pred_out) {
+    __shared__ float h[5][MLP_H];      // h[0][0..5] = input, h[1..4] = hidden activations (post LeakyReLU)
+    __shared__ float dl[2][MLP_H];     // back-propagated deltas (ping-pong)
+    __shared__ float jac[6][14];       // d flat6 / d (real7, trans7)
+    __shared__ float out7[8], dout7[8], dx6[8];
+    __shared__ float sm[16];
+    const int b = blockIdx.x, j = threadIdx.x;
+    if (j == 0) {
+        Dual<14> rc[7], tc[7], flat[6];
+        for (int i = 0; i < 7; ++i) {
+            rc[i] = dvar<14>(o_real[(size_t)b * ld + c0 + i], i);
+            tc[i] = dvar<14>(o_trans[(size_t)b * ld + c0 + i], 7 + i);
+        }
+        relative_rpqmnxy<Dual<14>>(rc, tc, flat);
+        for (int i = 0; i < 6; ++i) {
+            h[0][i] = flat[i].v;
+            for (int q = 0; q < 14; ++q) jac[i][q] = flat[i].d[q];
+        }
+    }
+    __syncthreads();
+    // forward
+    {
+        float a = mlp[MLP_B1 + j];
+        for (int i = 0; i < 6; ++i) a += mlp[MLP_W1 + j * 6 + i] * h[0][i];
+        h[1][j] = lrelu01(a);
+    }
+    __syncthreads();
+    const int wt[3] = {MLP_W2T, MLP_W3T, MLP_W4T}, bo[3] = {MLP_B2, MLP_B3, MLP_B4};
+    for (int l = 0; l < 3; ++l) {
+        float a = mlp[bo[l] + j];
+        const float* w = mlp + wt[l];
+        for (int i = 0; i < MLP_H; ++i) a += w[i * MLP_H + j] * h[l + 1][i];
+        h[l + 2][j] = lrelu01(a);
+        __syncthreads();
+    }
+    if (j < 7) {
+        float a = mlp[MLP_B5 + j];
+        for (int i = 0; i < MLP_H; ++i) a += mlp[MLP_W5 + j * MLP_H + i] * h[4][i];
+        // affine parameters -> latent units (utils_rpqmnxy.py:66-84)
+        float lat, dlat;
+        if (j == 0) { lat = a * (9.f / EG_PI_F); dlat = 9.f / EG_PI_F; }
+        else if (j <= 2) { lat = (a - 1.f) / 0.2f; dlat = 1.f / 0.2f; }
+        else if (j <= 4) { lat = a / 0.2f; dlat = 1.f / 0.2f; }
+        else { lat = a / 0.1f; dlat = 1.f / 0.1f; }
+        const float d = lat - code[(size_t)b * ldc + j];
+        out7[j] = d * d;
+        dout7[j] = 2.f * scale / (float)(B * 7) * d * dlat;
+        if (pred_out) pred_out[(size_t)b * 7 + j] = lat;
+    }
+    __syncthreads();
+    if (j == 0) {
+        float a = 0.f;
+        for (int i = 0; i < 7; ++i) a += out7[i];
+        sample_loss[b] = a;
+    }
+    if (!d_real) return;
+    // backward through the frozen MLP (input gradient only)
+    {
+        float a = 0.f;
+        for (int i = 0; i < 7; ++i) a += mlp[MLP_W5 + i * MLP_H + j] * dout7[i];
+        dl[0][j] = a * (h[4][j] > 0.f ? 1.f : 0.01f);
+    }
+    __syncthreads();
+    const int wo[3] = {MLP_W4, MLP_W3, MLP_W2};
+    for (int l = 0; l < 3; ++l) {
+        const float* w = mlp + wo[l];
+        float a = 0.f;
+        for (int i = 0; i < MLP_H; ++i) a += w[i * MLP_H + j] * dl[l & 1][i];
+        dl[(l + 1) & 1][j] = a * (h[3 - l][j] > 0.f ? 1.f : 0.01f);
+        __syncthreads();
+    }
+    // dl[1] holds delta of layer 1 (3 ping-pong steps); d input_i = sum_j W1[j][i] * delta1[j]
+    for (int i = 0; i < 6; ++i) {
+        const float tot = block_sum(mlp[MLP_W1 + j * 6 + i] * dl[1][j], sm);
+        if (j == 0) dx6[i] = tot;
+    }
+    __syncthreads();
+    if (j < 14) {
+        float g = 0.f;
+        for (int i = 0; i < 6; ++i) g += dx6[i] * jac[i][j];
+        if (j < 7) d_real[(size_t)b * ld + c0 + j] = g;
+        else d_trans[(size_t)b * ld + c0 + (j - 7)] = g;
+    }
+}
+
+__global__ void affine_reg_finish_kernel(const float* __restrict__ sample_loss, int B, int ncode, float scale, float* loss) {
+    __shared__ float sm[16];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) a += sample_loss[i];
+    const float tot = block_sum(a, sm);
+    if (threadIdx.x == 0 && loss) loss[0] += scale * tot / (float)(B * ncode);
+}
+
+__global__ void zero_rows_kernel(float* a, float* b, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { a[i] = 0.f; b[i] = 0.f; }
+}
+
+/* ws: B floats */
+extern "C" int eg_loss_affine_rpqmnxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc,
+                                      const float* mlp, float scale, float* loss, float* d_real, float* d_trans, float* pred_out, float* ws,
+                                      eg_stream_t s) {
+    EG_REQUIRE(o_real && o_trans && code && mlp && ws && B > 0 && (!d_real == !d_trans), "eg_loss_affine_rpqmnxy: bad argument");
+    hipStream_t st = (hipStream_t)s;
+    if (d_real) hipLaunchKernelGGL(zero_rows_kernel, dim3(cdiv(B * ld, 256)), dim3(256), 0, st, d_real, d_trans, B * ld);
+    hipLaunchKernelGGL(affine_reg_rpqmnxy_kernel, dim3(B), dim3(256), 0, st, o_real, o_trans, ld, c0, B, code, ldc, mlp, scale, ws, d_real, d_trans, pred_out);
+    hipLaunchKernelGGL(affine_reg_finish_kernel, dim3(1), dim3(256), 0, st, ws, B, 7, scale, loss);
+    EG_LAUNCH_CHECK();
+    return 0;
+}

@@ -75,3 +75,25 @@ template <typename Num> __device__ __forceinline__ void regularizer_rpqxy(const 
     out[3] = x / 0.1f;
     out[4] = y / 0.1f;
 }
+
+// ---- MNIST variant, 7 codes (theta,p,q,m,n,x,y): MNIST/utils_rpqmnxy.py:46-114 ---------------------------------------
+// A = Rot(theta) * diag(p,q,1) * Skew(m,n) * Trans(x,y),  Skew = [[1,m,0],[n,1,0],[0,0,1]]
+template <typename Num> __device__ __forceinline__ Aff<Num> matrix_rpqmnxy(const Num* c) {
+    const Num th = c[0] * (EG_PI_F / 9.f);
+    const Num p = c[1] * 0.2f + 1.f, q = c[2] * 0.2f + 1.f;
+    const Num m = c[3] * 0.2f, n = c[4] * 0.2f;
+    const Num x = c[5] * 0.1f, y = c[6] * 0.1f;
+    const Num cs = ncos(th), sn = nsin(th);
+    const Num a0 = p * cs, b0 = -(q * sn), d0 = p * sn, e0 = q * cs;   // R*Z
+    Aff<Num> r;
+    r.a = a0 + b0 * n; r.b = a0 * m + b0;
+    r.d = d0 + e0 * n; r.e = d0 * m + e0;
+    r.c = r.a * x + r.b * y;
+    r.f = r.d * x + r.e * y;
+    return r;
+}
+// relative matrix rows 0,1 flattened (a,b,c,d,e,f): the approximator's input (utils_rpqmnxy.py:125-128)
+template <typename Num> __device__ __forceinline__ void relative_rpqmnxy(const Num* real7, const Num* trans7, Num* flat6) {
+    const Aff<Num> rel = aff_mul(matrix_rpqmnxy(trans7), aff_inv(matrix_rpqmnxy(real7)));
+    flat6[0] = rel.a; flat6[1] = rel.b; flat6[2] = rel.c; flat6[3] = rel.d; flat6[4] = rel.e; flat6[5] = rel.f;
+}

@@ -92,3 +92,55 @@ extern "C" int eg_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C,
     EG_LAUNCH_CHECK();
     return 0;
 }
+
+// out[i] += src[(i / div) * s_div + (i % div) * s_mod]
+__global__ void gather_add_kernel(float* __restrict__ out, const float* __restrict__ src, int n, int div, int s_div, int s_mod) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] += src[(i / div) * s_div + (i % div) * s_mod];
+}
+extern "C" int eg_gather_add(float* out, const float* src, int n, int div, int s_div, int s_mod, eg_stream_t s) {
+    EG_REQUIRE(out && src && div > 0, "eg_gather_add: bad argument");
+    hipLaunchKernelGGL(gather_add_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, out, src, n, div, s_div, s_mod);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// y[b][h][w][:] = sum of the 2x2 block of x[b][2h..2h+1][2w..2w+1][:]   (nearest-upsample backward), 16-byte vectors along C
+template <typename T>
+__global__ void sumpool2x2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int cpr = C / VEC;
+    const size_t total = (size_t)B * H * W * cpr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpr);
+        const size_t pix = i / cpr;
+        const int w = (int)(pix % W), h = (int)((pix / W) % H), b = (int)(pix / ((size_t)W * H));
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const size_t o = ((((size_t)b * 2 * H + 2 * h + dy) * 2 * W) + 2 * w + dx) * C + (size_t)ch * VEC;
+                const uint4 v = *reinterpret_cast<const uint4*>(x + o);
+                const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] += Elt<T>::ld(e + j);
+            }
+        uint4 ov;
+        T* oe = reinterpret_cast<T*>(&ov);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) Elt<T>::st(oe + j, acc[j]);
+        *reinterpret_cast<uint4*>(y + pix * C + (size_t)ch * VEC) = ov;
+    }
+}
+extern "C" int eg_sumpool2x2(int dtype, const void* x, void* y, int B, int H, int W, int C, eg_stream_t s) {
+    EG_REQUIRE(x && y && C % (dtype == EG_F32 ? 4 : 8) == 0, "eg_sumpool2x2: bad argument");
+    const size_t total = (size_t)B * H * W * (C / (dtype == EG_F32 ? 4 : 8));
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (dtype == EG_F32) hipLaunchKernelGGL(sumpool2x2_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)x, (float*)y, B, H, W, C);
+    else hipLaunchKernelGGL(sumpool2x2_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
+    EG_LAUNCH_CHECK();
+    return 0;
+}

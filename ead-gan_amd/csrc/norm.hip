@@ -201,7 +201,8 @@ __global__ void bn_bwd_final_kernel(const float* __restrict__ partial, int nrb, 
 
 template <typename T>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ z, const T* __restrict__ da, T* __restrict__ dz, size_t nrows, int C,
-                                    const float* __restrict__ coef, int act, float slope) {
+                                    const float* __restrict__ coef, int act, float slope, int post_act, float post_slope,
+                                    const float* __restrict__ post_sigma) {
     constexpr int VEC = Elt<T>::VEC;
     const int cpr = C / VEC;
     const int chunk = (blockIdx.x * blockDim.x + threadIdx.x) % cpr;
@@ -213,6 +214,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ z, const T* __restrict
         const int c = chunk * VEC + j;
         A[j] = coef[c]; Bz[j] = coef[C + c]; Cc[j] = coef[2 * C + c]; P[j] = coef[3 * C + c]; Q[j] = coef[4 * C + c];
     }
+    const float post = post_sigma ? 1.f / post_sigma[0] : 1.f;
     for (size_t r = row0; r < nrows; r += rstride) {
         const size_t o = r * C + (size_t)chunk * VEC;
         const uint4 vz = *reinterpret_cast<const uint4*>(z + o);
@@ -223,28 +225,43 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ z, const T* __restrict
         for (int j = 0; j < VEC; ++j) {
             const float zz = Elt<T>::ld(ez + j);
             const float dy = Elt<T>::ld(ed + j) * pre_act_grad(zz * P[j] + Q[j], act, slope);
-            Elt<T>::st(ed + j, A[j] * dy - Bz[j] * zz - Cc[j]);
+            Elt<T>::st(ed + j, (A[j] * dy - Bz[j] * zz - Cc[j]) * eg_act_grad_from_out(zz, post_act, post_slope) * post);
         }
         *reinterpret_cast<uint4*>(dz + o) = vd;
     }
 }
 
-// ws: >= max(eg_bn_ws_floats(M,C), ...) floats; sums: 2*C floats
-extern "C" int eg_bn_bwd(int dtype, const void* z, const void* da, void* dz, int M, int C, const float* gamma, const float* beta,
-                         const float* save_mean, const float* save_invstd, int act, float slope, float* dgamma, float* dbeta,
-                         float* sums, float* ws, eg_stream_t s) {
-    EG_REQUIRE(z && da && dz && gamma && beta && save_mean && save_invstd && sums && ws, "eg_bn_bwd: null pointer");
+// ws: >= eg_bn_ws_floats(M,C) floats; sums: 2*C floats
+static int bn_bwd_impl(int dtype, const void* z, const void* da, void* dz, int M, int C, const float* gamma, const float* beta,
+                       const float* save_mean, const float* save_invstd, int act, float slope, float* dgamma, float* dbeta, float* sums, float* ws,
+                       int post_act, float post_slope, const float* post_sigma, hipStream_t st) {
     const int nrb = cdiv(M, BN_RPB);
     dim3 g1(cdiv(C, 64), nrb);
-    hipStream_t st = (hipStream_t)s;
     if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_partial_kernel<float>, g1, dim3(256), 0, st, (const float*)z, (const float*)da, M, C, gamma, beta, save_mean, save_invstd, act, slope, ws);
     else hipLaunchKernelGGL(bn_bwd_partial_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)da, M, C, gamma, beta, save_mean, save_invstd, act, slope, ws);
     const int cpr = C / (dtype == EG_F32 ? 4 : 8);
     float* coef = ws + (size_t)nrb * 3 * C;
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, ws, nrb, C, sums, dgamma, dbeta, gamma, beta, save_mean, save_invstd, M, coef);
     const int blocks = bn_apply_blocks((size_t)M, cpr);
-    if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)z, (const float*)da, (float*)dz, (size_t)M, C, coef, act, slope);
-    else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)da, (bf16_t*)dz, (size_t)M, C, coef, act, slope);
+    if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)z, (const float*)da, (float*)dz, (size_t)M, C, coef, act, slope, post_act, post_slope, post_sigma);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)da, (bf16_t*)dz, (size_t)M, C, coef, act, slope, post_act, post_slope, post_sigma);
+    return 0;
+}
+
+extern "C" int eg_bn_bwd(int dtype, const void* z, const void* da, void* dz, int M, int C, const float* gamma, const float* beta,
+                         const float* save_mean, const float* save_invstd, int act, float slope, float* dgamma, float* dbeta,
+                         float* sums, float* ws, eg_stream_t s) {
+    EG_REQUIRE(z && da && dz && gamma && beta && save_mean && save_invstd && sums && ws, "eg_bn_bwd: null pointer");
+    bn_bwd_impl(dtype, z, da, dz, M, C, gamma, beta, save_mean, save_invstd, act, slope, dgamma, dbeta, sums, ws, EG_ACT_NONE, 0.f, nullptr, (hipStream_t)s);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int eg_bn_bwd_post(int dtype, const void* z, const void* da, void* dz, int M, int C, const float* gamma, const float* beta,
+                              const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* sums, float* ws,
+                              int post_act, float post_slope, const float* post_sigma, eg_stream_t s) {
+    EG_REQUIRE(z && da && dz && gamma && beta && save_mean && save_invstd && sums && ws, "eg_bn_bwd_post: null pointer");
+    bn_bwd_impl(dtype, z, da, dz, M, C, gamma, beta, save_mean, save_invstd, EG_ACT_NONE, 0.f, dgamma, dbeta, sums, ws, post_act, post_slope, post_sigma, (hipStream_t)s);
     EG_LAUNCH_CHECK();
     return 0;
 }

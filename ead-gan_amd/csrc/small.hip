@@ -354,7 +354,8 @@ extern "C" int eg_cast_pad(int dtype, const float* src, void* dst, int rows, int
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void dense_small_fwd_kernel(const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ bias,
-                                                              float* __restrict__ y, int K, int Kpad, int N) {
+                                                              float* __restrict__ y, int K, int Kpad, int N, const float* __restrict__ sigma,
+                                                              int sigma_rows) {
     constexpr int VEC = Elt<T>::VEC;
     __shared__ float part[4][64];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -386,7 +387,9 @@ __global__ __launch_bounds__(256) void dense_small_fwd_kernel(const T* __restric
         }
     }
     __syncthreads();
-    if (threadIdx.x < N) y[(size_t)b * N + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x] + (bias ? bias[threadIdx.x] : 0.f);
+    const float inv = sigma ? 1.f / sigma[sigma_rows ? b / sigma_rows : 0] : 1.f;
+    if (threadIdx.x < N)
+        y[(size_t)b * N + threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) * inv + (bias ? bias[threadIdx.x] : 0.f);
 }
 
 // dx[b][k] = (sum_n dy[b][n] * Wp[n][k]) * act'(mask[b][k])
@@ -452,8 +455,53 @@ __global__ __launch_bounds__(256) void dense_small_wgrad_kernel(const float* __r
 extern "C" int eg_dense_small_fwd(int dtype, const void* x, const void* wp, const float* bias, float* y, int B, int K, int Kpad, int N,
                                   eg_stream_t s) {
     EG_REQUIRE(x && wp && y && N <= 64 && K % (dtype == EG_F32 ? 4 : 8) == 0, "eg_dense_small_fwd: bad argument (N<=64)");
-    if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_fwd_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)s, (const float*)x, (const float*)wp, bias, y, K, Kpad, N);
-    else hipLaunchKernelGGL(dense_small_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)wp, bias, y, K, Kpad, N);
+    if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_fwd_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)s, (const float*)x, (const float*)wp, bias, y, K, Kpad, N, (const float*)nullptr, 0);
+    else hipLaunchKernelGGL(dense_small_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)wp, bias, y, K, Kpad, N, (const float*)nullptr, 0);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int eg_dense_small_fwd_sn(int dtype, const void* x, const void* wp, const float* bias, float* y, int B, int K, int Kpad, int N,
+                                     const float* sigma, int sigma_rows, eg_stream_t s) {
+    EG_REQUIRE(x && wp && y && sigma && N <= 64 && K % (dtype == EG_F32 ? 4 : 8) == 0, "eg_dense_small_fwd_sn: bad argument (N<=64)");
+    if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_fwd_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)s, (const float*)x, (const float*)wp, bias, y, K, Kpad, N, sigma, sigma_rows);
+    else hipLaunchKernelGGL(dense_small_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)wp, bias, y, K, Kpad, N, sigma, sigma_rows);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// single block: dys = dy / sigma[tape] (cast, written at column col0 of a [rows][npad] buffer), coef[tape] = sum dys*(y-bias),
+// gb[n] += sum_rows dy[row][n].  Head tensors are tiny (rows <= a few thousand, N <= 64).
+template <typename T>
+__global__ void head_prep_sn_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ y, int ldyy, const float* __restrict__ bias,
+                                    int rows, int N, const float* __restrict__ sigma, int rows_per_tape, T* __restrict__ dys, int npad, int col0,
+                                    float* __restrict__ gb, float* __restrict__ coef) {
+    __shared__ float sm[16];
+    const int ntapes = rows / rows_per_tape;
+    for (int t = 0; t < ntapes; ++t) {
+        const float inv = 1.f / sigma[t];
+        float dot = 0.f;
+        for (int i = threadIdx.x; i < rows_per_tape * N; i += blockDim.x) {
+            const int r = t * rows_per_tape + i / N, n = i % N;
+            const float gs = dy[(size_t)r * ldy + n] * inv;
+            Elt<T>::st(dys + (size_t)r * npad + col0 + n, gs);
+            dot += gs * (y[(size_t)r * ldyy + n] - bias[n]);
+        }
+        const float tot = block_sum(dot, sm);
+        if (threadIdx.x == 0 && coef) coef[t] = tot;
+    }
+    if (gb && threadIdx.x < N) {
+        float a = 0.f;
+        for (int r = 0; r < rows; ++r) a += dy[(size_t)r * ldy + threadIdx.x];
+        gb[threadIdx.x] += a;
+    }
+}
+
+extern "C" int eg_head_prep_sn(int dtype, const float* dy, int ldy, const float* y, int ldyy, const float* bias, int rows, int N,
+                               const float* sigma, int rows_per_tape, void* dys, int npad, int col0, float* gb, float* coef, eg_stream_t s) {
+    EG_REQUIRE(dy && y && bias && sigma && dys && rows_per_tape > 0 && rows % rows_per_tape == 0 && N <= 64 && col0 + N <= npad, "eg_head_prep_sn: bad argument");
+    if (dtype == EG_F32) hipLaunchKernelGGL(head_prep_sn_kernel<float>, dim3(1), dim3(256), 0, (hipStream_t)s, dy, ldy, y, ldyy, bias, rows, N, sigma, rows_per_tape, (float*)dys, npad, col0, gb, coef);
+    else hipLaunchKernelGGL(head_prep_sn_kernel<bf16_t>, dim3(1), dim3(256), 0, (hipStream_t)s, dy, ldy, y, ldyy, bias, rows, N, sigma, rows_per_tape, (bf16_t*)dys, npad, col0, gb, coef);
     EG_LAUNCH_CHECK();
     return 0;
 }

@@ -83,6 +83,14 @@ int eg_conv_wgrad(const eg_conv* c, int dtype, const void* X, const void* dY, fl
  * C = gathered channels, T = taps.  Master layouts [Cout][Cin][k][k] / [Cin_T][Cout_T][k][k] are both [n][c][t]. */
 int eg_wgrad_reduce(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad,
                     int accumulate, eg_stream_t s);
+/* same with a row permutation: slab row n lands in gradient row (n % row_div) * row_mul + n / row_div
+ * (Linear whose output is viewed [B,C,H,W] and kept NHWC on device: MNIST/EAD-GAN_rpqmnxy.py:77,95-96) */
+int eg_wgrad_reduce_perm(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad,
+                         int row_div, int row_mul, eg_stream_t s);
+/* out[i] += src[(i / div) * s_div + (i % div) * s_mod]   (un-permute a bias gradient) */
+int eg_gather_add(float* out, const float* src, int n, int div, int s_div, int s_mod, eg_stream_t s);
+/* y[B,H,W,C] = 2x2 sum-pool of x[B,2H,2W,C]  (backward of nn.Upsample(scale_factor=2), MNIST/EAD-GAN_rpqmnxy.py:81,85) */
+int eg_sumpool2x2(int dtype, const void* x, void* y, int B, int H, int W, int C, eg_stream_t s);
 /* spectral-norm variant (torch.nn.utils.spectral_norm backward, celebA/EAD-GAN_celebA.py:110-120):
  * G = sum slab ;  grad += G/sigma - (<G,W_orig>/sigma^2) u v^T.  gtmp: Cout*Cin*k*k floats,
  * partials: >= eg_sn_partials() floats. */
@@ -136,6 +144,14 @@ int eg_bias_grad_nchw(const float* x, int B, int C, int HW, float* gb, eg_stream
  * y[b][n] = sum_k x[b][k] Wp[n][k] + bias[n];  x dtype T [B][K]; Wp dtype T [N][Kpad] (eg_pack_fwd order);  y fp32 */
 int eg_dense_small_fwd(int dtype, const void* x, const void* wp, const float* bias, float* y, int B, int K,
                        int Kpad, int N, eg_stream_t s);
+/* spectrally normalised variant: y = (x Wp^T) / sigma[b / sigma_rows] + bias */
+int eg_dense_small_fwd_sn(int dtype, const void* x, const void* wp, const float* bias, float* y, int B, int K,
+                          int Kpad, int N, const float* sigma, int sigma_rows, eg_stream_t s);
+/* gradient prep of a spectrally normalised dense head: dys = dy / sigma[tape] (cast to dtype T, padded to npad columns
+ * at column offset col0 of a [rows][npad] buffer), gb[n] += sum_rows dy, coef[tape] = sum dys * (y - bias) */
+int eg_head_prep_sn(int dtype, const float* dy, int ldy, const float* y, int ldyy, const float* bias, int rows, int N,
+                    const float* sigma, int rows_per_tape, void* dys, int npad, int col0, float* gb, float* coef,
+                    eg_stream_t s);
 /* dx[b] = (dy[b] Wp) * act'(mask[b]) [/ sigma[b / sigma_rows]] */
 int eg_dense_small_bwd(int dtype, const float* dy, const void* wp, const void* mask, void* dx, int B, int K,
                        int Kpad, int N, int mask_act, float mask_slope, const float* sigma, int sigma_rows,
@@ -154,6 +170,11 @@ int eg_bn_fwd_train(int dtype, const void* x, void* y, int M, int C, const float
 int eg_bn_bwd(int dtype, const void* z, const void* da, void* dz, int M, int C, const float* gamma, const float* beta,
               const float* save_mean, const float* save_invstd, int act, float slope, float* dgamma, float* dbeta,
               float* sums, float* ws, eg_stream_t s);
+/* as eg_bn_bwd, then dz *= act'(z as an activation OUTPUT) / post_sigma  -- for blocks ordered conv -> LeakyReLU -> BN
+ * (MNIST/EAD-GAN_rpqmnxy.py:143-146): the BN input IS the LeakyReLU output, so its backward mask is fused here */
+int eg_bn_bwd_post(int dtype, const void* z, const void* da, void* dz, int M, int C, const float* gamma, const float* beta,
+                   const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, float* sums, float* ws,
+                   int post_act, float post_slope, const float* post_sigma, eg_stream_t s);
 
 /* --- spectral norm power iteration (torch.nn.utils.spectral_norm, celebA/EAD-GAN_celebA.py:110-120) -------- */
 size_t eg_sn_ws_floats(int R, int Kd);
@@ -196,6 +217,15 @@ int eg_loss_mse(const float* o, int ld, int col0, int n, int B, const float* tgt
                 float* loss, float* dout, int zero_rows, eg_stream_t s);
 int eg_loss_ce_softmaxed(const float* o, int ld, int c0, int n, int B, const long long* labels, float scale,
                          float* loss, float* dout, eg_stream_t s);
+/* MNIST variant, 7 codes (theta,p,q,m,n,x,y): MNIST/utils_rpqmnxy.py:46-134.  eg_theta_rpqmnxy = rows 0,1 of R Z S T.
+ * eg_loss_affine_rpqmnxy: MSE(latent(MLP(flat(rel))), code) * scale with the frozen 6-256-256-256-256-7 LeakyReLU(0.01)
+ * approximator; mlp = eg_mlp_rpqmnxy_floats() floats: W1[256][6] b1 W2[256][256] b2 W3 b3 W4 b4 W5[7][256] b5, then the
+ * transposes W2t W3t W4t ([in][out]) for the forward sweep. */
+size_t eg_mlp_rpqmnxy_floats(void);
+int eg_theta_rpqmnxy(const float* code, int ldc, int B, float* theta, eg_stream_t s);
+int eg_loss_affine_rpqmnxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc,
+                           const float* mlp, float scale, float* loss, float* d_real, float* d_trans, float* pred_out,
+                           float* ws /* B floats */, eg_stream_t s);
 int eg_loss_affine_rpqxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc,
                          float scale, float* loss, float* d_real, float* d_trans, float* pred_out, eg_stream_t s);
 

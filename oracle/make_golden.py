@@ -16,6 +16,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import ref_harness as rh            # noqa: E402
 from oracle import celeba_oracle as co          # noqa: E402
+from oracle import mnist_oracle as mo           # noqa: E402
 
 GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
@@ -87,7 +88,59 @@ def make_celeba_affine(B=16, seed=3):
     print("celeba affine golden written")
 
 
-MAKERS = {"celeba": make_celeba, "celeba_affine": make_celeba_affine}
+def make_mnist(B=8, steps=3, seed=0, mlp_seed=123):
+    """MNIST loop (MNIST/EAD-GAN_rpqmnxy.py:338-446) on synthetic 32x32 batches; the frozen approximator the script loads at
+    import (utils_rpqmnxy.py:36-43) is a seeded stand-in written to the temp cwd."""
+    torch.set_num_threads(8)
+    real = mo.synthetic_real(B * steps, seed=4321).view(steps, B, 1, 32, 32)
+    out = {"B": np.array(B), "steps": np.array(steps), "seed": np.array(seed), "real_seed": np.array(4321), "mlp_seed": np.array(mlp_seed)}
+    names = ("d_loss", "g_loss", "info_loss")
+    mlp = mo.make_approximator(mlp_seed)
+
+    real_save = torch.save          # torch.save is patched to a no-op inside the harness: keep the real one for the prerequisite
+
+    def prereq2(tmp):
+        real_save(mlp, os.path.join(tmp, "rpqmnxy_approximator.pt"))
+
+    for n in (1, steps):
+        batches = [(real[i].clone(), torch.zeros(B, dtype=torch.int64)) for i in range(n)]
+        g, recs = rh.run_script_loop("MNIST/EAD-GAN_rpqmnxy.py", rh.mnist_opt(B), batches, names, seed, prereq=prereq2)
+        if n == 1:
+            probe_state("G1", g["generator"].state_dict(), out)
+            probe_state("D1", g["discriminator"].state_dict(), out)
+            probe_state("E1", g["encoder"].state_dict(), out)
+            probe_grads("gG1", g["generator"], out)
+            probe_grads("gE1", g["encoder"], out)
+    for k in names:
+        out[k] = np.array([r[k] for r in recs], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, f"mnist_b{B}_s{steps}.npz"), **out)
+    print("mnist golden:", {k: out[k] for k in names})
+
+
+def make_mnist_affine(B=16, seed=5, mlp_seed=123):
+    names = ("Affine_classifier", "from_latent_vector_2_affine_para", "from_affine_para_2_latent_vector", "get_matrix", "affine_regularizer")
+    mlp = mo.make_approximator(mlp_seed)
+    g = rh.load_defs("MNIST/utils_rpqmnxy.py", names)
+    with rh._cpu_only_patches():
+        net = g["Affine_classifier"]()
+        net.load_state_dict(mlp)
+        net.eval()
+        g["BFGS_approximator"] = net
+        rng = np.random.RandomState(seed)
+        code = torch.tensor(rng.uniform(-1, 1, (B, 7)), dtype=torch.float32)
+        real_code = torch.tensor(rng.uniform(-1, 1, (B, 7)), dtype=torch.float32, requires_grad=True)
+        trans_code = torch.tensor(rng.uniform(-1, 1, (B, 7)), dtype=torch.float32, requires_grad=True)
+        A = g["get_matrix"](code)
+        pred = g["affine_regularizer"](real_code, trans_code)
+        w = torch.tensor(rng.normal(0, 1, (B, 7)), dtype=torch.float32)
+        (pred * w).sum().backward()
+    np.savez_compressed(os.path.join(GOLD, "mnist_affine.npz"), code=code.numpy(), A=A.detach().numpy(), real_code=real_code.detach().numpy(),
+                        trans_code=trans_code.detach().numpy(), pred=pred.detach().numpy(), w=w.numpy(), d_real=real_code.grad.numpy(),
+                        d_trans=trans_code.grad.numpy(), mlp_seed=np.array(mlp_seed))
+    print("mnist affine golden written")
+
+
+MAKERS = {"celeba": make_celeba, "celeba_affine": make_celeba_affine, "mnist": make_mnist, "mnist_affine": make_mnist_affine}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

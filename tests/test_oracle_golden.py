@@ -6,6 +6,7 @@ import torch
 
 from conftest import GOLDEN
 from oracle import celeba_oracle as co
+from oracle import mnist_oracle as mo
 
 
 def check_probes(prefix, tensors, gold, rtol, atol, noise_floor=0.0):
@@ -58,6 +59,41 @@ def test_celeba_affine_functions_match_reference():
     rc = torch.tensor(gold["real_code"], requires_grad=True)
     tc = torch.tensor(gold["trans_code"], requires_grad=True)
     pred = co.affine_regularzier(rc, tc)
+    np.testing.assert_allclose(pred.detach().numpy(), gold["pred"], rtol=1e-4, atol=1e-5)
+    (pred * torch.tensor(gold["w"])).sum().backward()
+    np.testing.assert_allclose(rc.grad.numpy(), gold["d_real"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(tc.grad.numpy(), gold["d_trans"], rtol=1e-3, atol=1e-4)
+
+
+def test_mnist_step_matches_reference():
+    gold = np.load(os.path.join(GOLDEN, "mnist_b8_s3.npz"))
+    B, steps, seed = int(gold["B"]), int(gold["steps"]), int(gold["seed"])
+    torch.set_num_threads(8)
+    orc = mo.MnistOracle(seed=seed, mlp=mo.make_approximator(int(gold["mlp_seed"])))
+    rng = np.random.RandomState(seed)
+    real = mo.synthetic_real(B * steps, seed=int(gold["real_seed"])).view(steps, B, 1, 32, 32)
+    for i in range(steps):
+        z, code, labels = mo.draw_step_inputs(rng, B)
+        out = orc.train_step(real[i], z, code, labels)
+        tol = (2e-6, 1e-3, 1e-2)[i]
+        for k in ("g_loss", "d_loss", "info_loss"):
+            assert abs(out[k] - gold[k][i]) < tol, (i, k, out[k], gold[k][i])
+        if i == 0:
+            check_probes("gG1", {k: v.grad for k, v in orc.G.items() if getattr(v, "grad", None) is not None}, gold, 1e-2, 1e-9, noise_floor=1e-8)
+            check_probes("gE1", {k: v.grad for k, v in orc.E.items() if getattr(v, "grad", None) is not None}, gold, 1e-2, 1e-9, noise_floor=1e-8)
+            check_probes("G1", orc.G, gold, 2e-3, 3e-4)
+            check_probes("D1", orc.D, gold, 2e-3, 3e-4)
+            check_probes("E1", orc.E, gold, 2e-3, 3e-4)
+
+
+def test_mnist_affine_functions_match_reference():
+    gold = np.load(os.path.join(GOLDEN, "mnist_affine.npz"))
+    mlp = mo.make_approximator(int(gold["mlp_seed"]))
+    A = mo.get_matrix(torch.tensor(gold["code"]))
+    np.testing.assert_allclose(A.numpy(), gold["A"], rtol=1e-6, atol=1e-7)
+    rc = torch.tensor(gold["real_code"], requires_grad=True)
+    tc = torch.tensor(gold["trans_code"], requires_grad=True)
+    pred = mo.affine_regularizer(mlp, rc, tc)
     np.testing.assert_allclose(pred.detach().numpy(), gold["pred"], rtol=1e-4, atol=1e-5)
     (pred * torch.tensor(gold["w"])).sum().backward()
     np.testing.assert_allclose(rc.grad.numpy(), gold["d_real"], rtol=1e-3, atol=1e-4)
