@@ -790,7 +790,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int NS, int N, int C, int T,
                                                            float* __restrict__ out, int accumulate, const float* __restrict__ w_orig,
                                                            float* __restrict__ partials, int ntapes, const float* __restrict__ coef,
-                                                           const float* __restrict__ u, const float* __restrict__ v, int row_div, int row_mul) {
+                                                           const float* __restrict__ u, const float* __restrict__ v, int row_div, int row_mul, int c_row) {
     extern __shared__ float tile[];      // [EG_RC][T+1]
     __shared__ float sm[16];
     const int cchunks = (C + EG_RC - 1) / EG_RC;
@@ -800,22 +800,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     float un[4] = {0.f, 0.f, 0.f, 0.f};
     if (MODE == 2)
         for (int q = 0; q < ntapes; ++q) un[q] = coef[q] * u[(size_t)q * N + n];
+    const int crow = c_row ? c_row : C;                 // row length of the destination (<= C when the slab is column padded)
     for (int e = threadIdx.x; e < T * EG_RC; e += 256) {
         const int t = e / EG_RC, c = e % EG_RC;
-        if (c < cw) {
+        if (c < cw && c0 + c < crow) {
             const size_t si = ((size_t)n * T + t) * C + c0 + c;
             float a = 0.f;
             for (int z = 0; z < nsplit; ++z) a += slab[z * split_stride + si];
             if (MODE == 2)
-                for (int q = 0; q < ntapes; ++q) a -= un[q] * v[(size_t)q * C * T + (size_t)(c0 + c) * T + t];
+                for (int q = 0; q < ntapes; ++q) a -= un[q] * v[(size_t)q * crow * T + (size_t)(c0 + c) * T + t];
             tile[c * (T + 1) + t] = a;
         }
     }
     __syncthreads();
     float dot = 0.f;
     const int nout = row_div ? (n % row_div) * row_mul + n / row_div : n;
-    const size_t obase = ((size_t)nout * C + c0) * T;
-    for (int e = threadIdx.x; e < cw * T; e += 256) {
+    const size_t obase = ((size_t)nout * crow + c0) * T;
+    const int cwo = min(cw, crow - c0);
+    for (int e = threadIdx.x; e < cwo * T; e += 256) {
         const int c = e / T, t = e % T;
         const float a = tile[c * (T + 1) + t];
         if (MODE == 1) {
@@ -852,25 +854,25 @@ static inline size_t reduce_lds(int T) { return (size_t)EG_RC * (T + 1) * sizeof
 extern "C" int eg_wgrad_reduce(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad, int accumulate, eg_stream_t s) {
     EG_REQUIRE(slab && grad && nsplit > 0 && n_rows <= n_slab && T > 0 && T <= 64, "eg_wgrad_reduce: bad argument");
     hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3(reduce_blocks(n_rows, C)), dim3(256), reduce_lds(T), (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T,
-                       grad, accumulate, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0);
+                       grad, accumulate, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0, 0);
     EG_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int eg_wgrad_reduce_perm(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad, int row_div, int row_mul, eg_stream_t s) {
-    EG_REQUIRE(slab && grad && nsplit > 0 && n_rows <= n_slab && T > 0 && T <= 64 && row_div > 0, "eg_wgrad_reduce_perm: bad argument");
+extern "C" int eg_wgrad_reduce_perm(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad, int row_div, int row_mul, int c_row, eg_stream_t s) {
+    EG_REQUIRE(slab && grad && nsplit > 0 && n_rows <= n_slab && T > 0 && T <= 64 && row_div >= 0 && c_row >= 0 && c_row <= C, "eg_wgrad_reduce_perm: bad argument");
     hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3(reduce_blocks(n_rows, C)), dim3(256), reduce_lds(T), (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T,
-                       grad, 1, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, row_div, row_mul);
+                       grad, 1, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, row_div, row_mul, c_row);
     EG_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int eg_wgrad_reduce_rank1(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad, int ntapes,
-                                     const float* coef, const float* u, const float* v, eg_stream_t s) {
+                                     const float* coef, const float* u, const float* v, int c_row, eg_stream_t s) {
     EG_REQUIRE(slab && grad && nsplit > 0 && n_rows <= n_slab && ntapes >= 0 && ntapes <= 4 && (ntapes == 0 || (coef && u && v)) && T > 0 && T <= 64,
                "eg_wgrad_reduce_rank1: bad argument");
     hipLaunchKernelGGL(wgrad_reduce_kernel<2>, dim3(reduce_blocks(n_rows, C)), dim3(256), reduce_lds(T), (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T,
-                       grad, 1, (const float*)nullptr, (float*)nullptr, ntapes, coef, u, v, 0, 0);
+                       grad, 1, (const float*)nullptr, (float*)nullptr, ntapes, coef, u, v, 0, 0, c_row);
     EG_LAUNCH_CHECK();
     return 0;
 }
@@ -884,7 +886,7 @@ extern "C" int eg_wgrad_reduce_sn(const eg_conv* c, const float* slab, int nspli
     const int blocks = reduce_blocks(c->Cout, c->Cin);
     EG_REQUIRE(blocks <= (1 << 17), "eg_wgrad_reduce_sn: layer too large for the partials buffer");
     hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(blocks), dim3(256), reduce_lds(T), (hipStream_t)s, slab, nsplit, c->Cout, c->Cout, c->Cin, T, gtmp, 0,
-                       w_orig, partials, 0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0);
+                       w_orig, partials, 0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0, 0);
     const long long total = (long long)c->Cout * c->Cin * T;
     const int blocks2 = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     hipLaunchKernelGGL(sn_grad_apply_kernel, dim3(blocks2), dim3(256), 0, (hipStream_t)s, gtmp, partials, blocks, sigma, u, v, total,

@@ -475,16 +475,17 @@ extern "C" int eg_dense_small_fwd_sn(int dtype, const void* x, const void* wp, c
 template <typename T>
 __global__ void head_prep_sn_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ y, int ldyy, const float* __restrict__ bias,
                                     int rows, int N, const float* __restrict__ sigma, int rows_per_tape, T* __restrict__ dys, int npad, int col0,
-                                    float* __restrict__ gb, float* __restrict__ coef) {
+                                    float* __restrict__ gb, float* __restrict__ coef, float* __restrict__ dys32, int ld32) {
     __shared__ float sm[16];
     const int ntapes = rows / rows_per_tape;
     for (int t = 0; t < ntapes; ++t) {
-        const float inv = 1.f / sigma[t];
+        const float inv = sigma ? 1.f / sigma[t] : 1.f;
         float dot = 0.f;
         for (int i = threadIdx.x; i < rows_per_tape * N; i += blockDim.x) {
             const int r = t * rows_per_tape + i / N, n = i % N;
             const float gs = dy[(size_t)r * ldy + n] * inv;
             Elt<T>::st(dys + (size_t)r * npad + col0 + n, gs);
+            if (dys32) dys32[(size_t)r * ld32 + col0 + n] = gs;
             dot += gs * (y[(size_t)r * ldyy + n] - bias[n]);
         }
         const float tot = block_sum(dot, sm);
@@ -498,10 +499,11 @@ __global__ void head_prep_sn_kernel(const float* __restrict__ dy, int ldy, const
 }
 
 extern "C" int eg_head_prep_sn(int dtype, const float* dy, int ldy, const float* y, int ldyy, const float* bias, int rows, int N,
-                               const float* sigma, int rows_per_tape, void* dys, int npad, int col0, float* gb, float* coef, eg_stream_t s) {
-    EG_REQUIRE(dy && y && bias && sigma && dys && rows_per_tape > 0 && rows % rows_per_tape == 0 && N <= 64 && col0 + N <= npad, "eg_head_prep_sn: bad argument");
-    if (dtype == EG_F32) hipLaunchKernelGGL(head_prep_sn_kernel<float>, dim3(1), dim3(256), 0, (hipStream_t)s, dy, ldy, y, ldyy, bias, rows, N, sigma, rows_per_tape, (float*)dys, npad, col0, gb, coef);
-    else hipLaunchKernelGGL(head_prep_sn_kernel<bf16_t>, dim3(1), dim3(256), 0, (hipStream_t)s, dy, ldy, y, ldyy, bias, rows, N, sigma, rows_per_tape, (bf16_t*)dys, npad, col0, gb, coef);
+                               const float* sigma, int rows_per_tape, void* dys, int npad, int col0, float* gb, float* coef, float* dys32, int ld32,
+                               eg_stream_t s) {
+    EG_REQUIRE(dy && y && bias && dys && rows_per_tape > 0 && rows % rows_per_tape == 0 && N <= 64 && col0 + N <= npad, "eg_head_prep_sn: bad argument");
+    if (dtype == EG_F32) hipLaunchKernelGGL(head_prep_sn_kernel<float>, dim3(1), dim3(256), 0, (hipStream_t)s, dy, ldy, y, ldyy, bias, rows, N, sigma, rows_per_tape, (float*)dys, npad, col0, gb, coef, dys32, ld32);
+    else hipLaunchKernelGGL(head_prep_sn_kernel<bf16_t>, dim3(1), dim3(256), 0, (hipStream_t)s, dy, ldy, y, ldyy, bias, rows, N, sigma, rows_per_tape, (bf16_t*)dys, npad, col0, gb, coef, dys32, ld32);
     EG_LAUNCH_CHECK();
     return 0;
 }

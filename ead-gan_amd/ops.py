@@ -130,6 +130,18 @@ def wgrad_reduce(slab, nsplit, n_slab, n_rows, C, T, grad, accumulate=True):
     lib().call("eg_wgrad_reduce", _p(slab), nsplit, n_slab, n_rows, C, T, _p(grad), int(accumulate), _stream())
 
 
+def wgrad_reduce_perm(slab, nsplit, n_slab, n_rows, C, T, grad, row_div=0, row_mul=0, c_row=0):
+    lib().call("eg_wgrad_reduce_perm", _p(slab), nsplit, n_slab, n_rows, C, T, _p(grad), row_div, row_mul, c_row, _stream())
+
+
+def gather_add(out, src, n, div, s_div, s_mod):
+    lib().call("eg_gather_add", _p(out), _p(src), n, div, s_div, s_mod, _stream())
+
+
+def sumpool2x2(dtype, x, y, B, H, W, C):
+    lib().call("eg_sumpool2x2", dtype, _p(x), _p(y), B, H, W, C, _stream())
+
+
 def sn_partials():
     return lib().query("eg_sn_partials")
 
@@ -154,8 +166,8 @@ def bias_grad_sn(dtype, dzs, a, bias, rows, N, rows_per_tape, sigma, slope, ws, 
     lib().call("eg_bias_grad_sn", dtype, _p(dzs), _p(a), _p(bias), rows, N, rows_per_tape, _p(sigma), slope, _p(ws), _p(gb), _p(coef), _stream())
 
 
-def wgrad_reduce_rank1(slab, nsplit, n_slab, n_rows, C, T, grad, ntapes, coef, u, v):
-    lib().call("eg_wgrad_reduce_rank1", _p(slab), nsplit, n_slab, n_rows, C, T, _p(grad), ntapes, _p(coef), _p(u), _p(v), _stream())
+def wgrad_reduce_rank1(slab, nsplit, n_slab, n_rows, C, T, grad, ntapes, coef, u, v, c_row=0):
+    lib().call("eg_wgrad_reduce_rank1", _p(slab), nsplit, n_slab, n_rows, C, T, _p(grad), ntapes, _p(coef), _p(u), _p(v), c_row, _stream())
 
 
 # ---- image side / heads ----------------------------------------------------------------------------
@@ -204,6 +216,15 @@ def dense_small_fwd(dtype, x, wp, bias, y, B, K, Kpad, N):
     lib().call("eg_dense_small_fwd", dtype, _p(x), _p(wp), _p(bias), _p(y), B, K, Kpad, N, _stream())
 
 
+def dense_small_fwd_sn(dtype, x, wp, bias, y, B, K, Kpad, N, sigma, sigma_rows):
+    lib().call("eg_dense_small_fwd_sn", dtype, _p(x), _p(wp), _p(bias), _p(y), B, K, Kpad, N, _p(sigma), sigma_rows, _stream())
+
+
+def head_prep_sn(dtype, dy, ldy, y, ldyy, bias, rows, N, sigma, rows_per_tape, dys, npad, col0, gb, coef, dys32=None, ld32=0):
+    lib().call("eg_head_prep_sn", dtype, _p(dy), ldy, _p(y), ldyy, _p(bias), rows, N, _p(sigma), rows_per_tape, _p(dys), npad, col0, _p(gb), _p(coef),
+               _p(dys32), ld32, _stream())
+
+
 def dense_small_bwd(dtype, dy, wp, mask, dx, B, K, Kpad, N, mask_act=ACT_NONE, mask_slope=0.0, sigma=None, sigma_rows=0):
     lib().call("eg_dense_small_bwd", dtype, _p(dy), _p(wp), _p(mask), _p(dx), B, K, Kpad, N, mask_act, mask_slope, _p(sigma), sigma_rows, _stream())
 
@@ -225,6 +246,11 @@ def bn_fwd_train(dtype, x, y, M, C, gamma, beta, eps, momentum, rmean, rvar, nbt
 def bn_bwd(dtype, z, da, dz, M, C, gamma, beta, save_mean, save_invstd, act, slope, dgamma, dbeta, sums, ws):
     lib().call("eg_bn_bwd", dtype, _p(z), _p(da), _p(dz), M, C, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd), act, slope,
                _p(dgamma), _p(dbeta), _p(sums), _p(ws), _stream())
+
+
+def bn_bwd_post(dtype, z, da, dz, M, C, gamma, beta, save_mean, save_invstd, dgamma, dbeta, sums, ws, post_act, post_slope, post_sigma):
+    lib().call("eg_bn_bwd_post", dtype, _p(z), _p(da), _p(dz), M, C, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd), _p(dgamma), _p(dbeta),
+               _p(sums), _p(ws), post_act, post_slope, _p(post_sigma), _stream())
 
 
 def sn_ws_floats(R, Kd):
@@ -286,6 +312,19 @@ def theta_rpqxy(code, ldc, B, theta):
 
 def warp_affine(img, theta, out, B, C, H, W):
     lib().call("eg_warp_affine", _p(img), _p(theta), _p(out), B, C, H, W, _stream())
+
+
+def mlp_rpqmnxy_floats():
+    return lib().query("eg_mlp_rpqmnxy_floats")
+
+
+def theta_rpqmnxy(code, ldc, B, theta):
+    lib().call("eg_theta_rpqmnxy", _p(code), ldc, B, _p(theta), _stream())
+
+
+def loss_affine_rpqmnxy(o_real, o_trans, ld, c0, B, code, ldc, mlp, scale, loss, d_real, d_trans, pred_out, ws):
+    lib().call("eg_loss_affine_rpqmnxy", _p(o_real), _p(o_trans), ld, c0, B, _p(code), ldc, _p(mlp), scale, _p(loss), _p(d_real), _p(d_trans),
+               _p(pred_out), _p(ws), _stream())
 
 
 def loss_bce_sigmoid(o, ld, col, B, target, scale, loss, dout, zero_rows=True):

@@ -1,0 +1,262 @@
+"""Generic engine for the reference's discriminator/encoder trunks: a stack of spectrally-normalised stride-2 convolutions
+(LeakyReLU, optionally followed by BatchNorm2d) ending in one or more dense heads over the flattened feature map.
+
+Used by MNIST's Discriminator / Encoder (MNIST/EAD-GAN_rpqmnxy.py:101-175).  Same design as the CelebA discriminator
+engine: activations NHWC in the compute dtype, W/sigma never materialised (1/sigma folded into epilogues), every forward
+("tape") keeps its own sigma/u/v, tapes without BatchNorm are batched along M, gradients travel as dzs = dz/sigma so that
+ONE weight-gradient GEMM covers all tapes and the spectral-norm rank-1 terms are added by a single-pass reduce.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import torch
+
+from . import ops
+from .engine import ConvRec, Workspace
+from .ops import ACT_LRELU, ACT_NONE, EG_F32, OUT_NCHW_F32
+
+SN_EPS = 1e-12
+
+
+@dataclass
+class Head:
+    name: str            # parameter prefix inside the owning module, e.g. "adv_layer.0"
+    module: object       # nn.Linear / nn.Conv2d container (spectral-normed or plain)
+    sn: bool
+    compute: bool = True     # evaluate the head output (False: only its power iteration runs, e.g. MNIST noise_layer)
+    grad: bool = True        # takes part in backward
+    N: int = 0
+    off: int = 0             # row offset inside the combined head panel
+
+
+class TrunkEngine:
+    def __init__(self, owner, convs, conv_names, bns, bn_names, heads, in_ch, size, k, slope, B, dtype, NT):
+        """convs: SN conv modules; bns: per-layer BatchNorm module or None (applied AFTER the LeakyReLU of that layer)."""
+        self.owner, self.convs, self.conv_names, self.bns, self.bn_names = owner, convs, conv_names, bns, bn_names
+        self.heads, self.B, self.dtype, self.NT, self.k, self.slope = heads, B, dtype, NT, k, slope
+        self.in_ch, self.S = in_ch, size
+        dev = owner.arena.flat.device
+        self.ws = ws = Workspace.get(dev)
+        tdt = ops.torch_dtype(dtype)
+        L = len(convs)
+        self.L = L
+        self.W = [c.weight_orig.shape[0] for c in convs]
+        self.hw = [size >> (i + 1) for i in range(L)]
+        self.taps = k * k
+        self.k0 = in_ch * k * k                                   # real K of the image-side layer
+        self.kp = ops.round_up(self.k0, 8)
+        self.cin = [self.kp] + self.W[:-1]
+        self.has_bn = any(b is not None for b in bns)
+        pad = 1
+        # records (packed panels) for the largest batch; per-tape-count geometries
+        self.l0img = ConvRec(dtype, B, size, size, in_ch, self.W[0], k, 2, pad, device=dev, want_fwd=False, want_wgrad=False, ws=ws)
+        self.l0p = ConvRec(dtype, NT * B, size // 2, size // 2, self.kp, self.W[0], 1, 1, 0, device=dev, want_bwd=False, ws=ws)
+        self.mid = [ConvRec(dtype, NT * B, self.hw[i], self.hw[i], self.W[i], self.W[i + 1], k, 2, pad, device=dev, ws=ws) for i in range(L - 1)]
+        self.hk = self.hw[-1]
+        self.K = self.hk * self.hk * self.W[-1]
+        off = 0
+        for h in heads:
+            w = h.module.weight_orig if h.sn else h.module.weight
+            h.N = w.shape[0]
+            if h.compute:
+                h.off = off
+                off += h.N
+        self.ncomb = off
+        assert self.ncomb <= 32, "combined head panel holds at most 32 outputs"
+        self.head_rec = ConvRec(dtype, NT * B, self.hk, self.hk, self.W[-1], 32, self.hk, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
+        self.head_rec.wp_fwd.zero_()
+        self.headw = ConvRec(dtype, NT * B, 1, 1, self.K, 32, 1, 1, 0, device=dev, want_fwd=False, want_bwd=False, ws=ws)
+        self.geo = {}
+        for T in range(1, NT + 1):
+            self.geo[T] = {"l0p": ops.make_conv(T * B, size // 2, size // 2, self.kp, self.W[0], 1, 1, 0),
+                           "mid": [ops.make_conv(T * B, self.hw[i], self.hw[i], self.W[i], self.W[i + 1], k, 2, pad) for i in range(L - 1)],
+                           "headw": ops.make_conv(T * B, 1, 1, self.K, 32, 1, 1, 0)}
+        for i in range(L):
+            ws.need_small(ops.bias_grad_sn_ws_floats(NT * B * self.hw[i] ** 2, self.W[i], B * self.hw[i] ** 2))
+            if bns[i] is not None:
+                ws.need_small(ops.bn_ws_floats(B * self.hw[i] ** 2, self.W[i]))
+                ws.need_sums(2 * self.W[i])
+        e = lambda *s, dt=tdt: torch.empty(s, device=dev, dtype=dt)
+        z = lambda *s: torch.zeros(s, device=dev, dtype=torch.float32)
+        self.patches = torch.zeros(NT * B * (size // 2) ** 2, self.kp, device=dev, dtype=tdt)
+        self.a = [e(NT * B, self.hw[i], self.hw[i], self.W[i]) for i in range(L)]          # LeakyReLU outputs
+        self.y = [e(NT * B, self.hw[i], self.hw[i], self.W[i]) if bns[i] is not None else None for i in range(L)]   # BatchNorm outputs
+        self.dz = [torch.empty_like(t) for t in self.a]                                     # dL/dz / sigma
+        self.dyb = [torch.empty_like(t) if bns[i] is not None else None for i, t in enumerate(self.a)]   # dL/d(BN output)
+        self.mean = [z(NT, self.W[i]) if bns[i] is not None else None for i in range(L)]
+        self.invstd = [z(NT, self.W[i]) if bns[i] is not None else None for i in range(L)]
+        self.outs = {h.name: z(NT * B, h.N) for h in heads if h.compute}
+        self.dys_t = torch.zeros(NT * B, 32, device=dev, dtype=tdt)
+        self.dys32 = z(NT * B, max(self.ncomb, 1))
+        self.dimg = z(B, in_ch, size, size)
+        kd = [self.k0] + [self.W[i] * self.taps for i in range(L - 1)]
+        self.sigma = [torch.ones(NT, device=dev) for _ in range(L)]
+        self.u = [z(NT, self.W[i]) for i in range(L)]
+        self.v = [z(NT, kd[i]) for i in range(L)]
+        self.coef = [z(4) for _ in range(L)]
+        self.hsigma = {h.name: torch.ones(NT, device=dev) for h in heads if h.sn}
+        self.hu = {h.name: z(NT, h.N) for h in heads if h.sn}
+        self.hv = {h.name: z(NT, self.K) for h in heads if h.sn}
+        self.hcoef = {h.name: z(4) for h in heads}
+        self._sn_arrays = []
+        for t in range(NT):
+            ent = [(c.weight_orig, c.weight_u, c.weight_v, self.sigma[i][t:t + 1], self.u[i][t], self.v[i][t]) for i, c in enumerate(convs)]
+            ent += [(h.module.weight_orig, h.module.weight_u, h.module.weight_v, self.hsigma[h.name][t:t + 1], self.hu[h.name][t], self.hv[h.name][t])
+                    for h in heads if h.sn]
+            self._sn_arrays.append(ops.sn_layers(ent))
+        ws.need_small(ops.sn_multi_ws_floats(self._sn_arrays[0]))
+        self.imgs = [None] * NT
+        self.repack()
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def repack(self):
+        dt = self.dtype
+        self.l0img.pack(self.convs[0].weight_orig)
+        ops.pack_strided(dt, self.convs[0].weight_orig, self.l0p.wp_fwd, self.W[0], self.k0, self.l0p.Kpad_fwd, 1, self.k0, 0, 1)
+        for i in range(self.L - 1):
+            self.mid[i].pack(self.convs[i + 1].weight_orig)
+        kpad = self.head_rec.Kpad_fwd
+        for h in self.heads:
+            if not h.compute:
+                continue
+            w = h.module.weight_orig if h.sn else h.module.weight
+            c = ops.make_conv(self.B, self.hk, self.hk, self.W[-1], h.N, self.hk, 1, 0)
+            ops.pack_fwd(c, dt, w, self.head_rec.wp_fwd[h.off * kpad:])
+
+    def rows(self, i):
+        return self.B * self.hw[i] ** 2
+
+    def _sl(self, buf, t0):
+        return buf[t0 * (buf.shape[0] // self.NT):]
+
+    def _inp(self, i, t0):
+        """input activation of layer i (output of layer i-1 after its optional BatchNorm; patches for i == 0)"""
+        if i == 0:
+            return self._sl(self.patches, t0)
+        return self._sl(self.y[i - 1] if self.bns[i - 1] is not None else self.a[i - 1], t0)
+
+    def _fwd_pass(self, t0, T):
+        dt, B = self.dtype, self.B
+        g = self.geo[T]
+        for i in range(self.L):
+            geo = g["l0p"] if i == 0 else g["mid"][i - 1]
+            wp = self.l0p.wp_fwd if i == 0 else self.mid[i - 1].wp_fwd
+            ops.conv_fwd(geo, dt, self._inp(i, t0), wp, self._sl(self.a[i], t0),
+                         ops.epilogue(bias=self.convs[i].bias, sigma=self.sigma[i][t0:], sigma_rows=self.rows(i), act=ACT_LRELU, slope=self.slope))
+            bn = self.bns[i]
+            if bn is not None:
+                assert T == 1
+                ops.bn_fwd_train(dt, self._sl(self.a[i], t0), self._sl(self.y[i], t0), self.rows(i), self.W[i], bn.weight, bn.bias, bn.eps, bn.momentum,
+                                 bn.running_mean, bn.running_var, bn.num_batches_tracked, self.mean[i][t0], self.invstd[i][t0], self.ws.small, ACT_NONE)
+        x = self._inp(self.L, t0)
+        kpad = self.head_rec.Kpad_fwd
+        for h in self.heads:
+            if not h.compute:
+                continue
+            out = self.outs[h.name][t0 * B:(t0 + T) * B]
+            wp = self.head_rec.wp_fwd[h.off * kpad:]
+            if h.sn:
+                ops.dense_small_fwd_sn(dt, x, wp, h.module.bias, out, T * B, self.K, kpad, h.N, self.hsigma[h.name][t0:], B)
+            else:
+                ops.dense_small_fwd(dt, x, wp, h.module.bias, out, T * B, self.K, kpad, h.N)
+
+    def forward(self, imgs, t0=0, training=True):
+        """len(imgs) forwards as tapes t0.. (power iterations in list order).  Returns {head name: [len(imgs)*B, N]} views."""
+        dt, B = self.dtype, self.B
+        T = len(imgs)
+        assert 1 <= T and t0 + T <= self.NT
+        npix = B * (self.S // 2) ** 2
+        for kk, img in enumerate(imgs):
+            t = t0 + kk
+            self.imgs[t] = img
+            ops.sn_power_iter_multi(self._sn_arrays[t], self.ws.small, training, SN_EPS)
+            if not training:
+                for i, c in enumerate(self.convs):
+                    self.u[i][t].copy_(c.weight_u)
+                    self.v[i][t].copy_(c.weight_v)
+                for h in self.heads:
+                    if h.sn:
+                        self.hu[h.name][t].copy_(h.module.weight_u)
+                        self.hv[h.name][t].copy_(h.module.weight_v)
+            ops.im2col_img(dt, img, self.patches[t * npix:(t + 1) * npix], B, self.in_ch, self.S, self.S, self.k, 2, 1, self.kp)
+        if self.has_bn:
+            for kk in range(T):
+                self._fwd_pass(t0 + kk, 1)
+        else:
+            self._fwd_pass(t0, T)
+        return {h.name: self.outs[h.name][t0 * B:(t0 + T) * B] for h in self.heads if h.compute}
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _bwd_pass(self, t0, T, douts, grad, need_wgrad, need_dimg):
+        dt, B, ws, L = self.dtype, self.B, self.ws, self.L
+        gof = lambda name: self.owner.arena.grad_of(name, grad)
+        g = self.geo[T]
+        kpad = self.head_rec.Kpad_fwd
+        rows = T * B
+        dys_t, dys32 = self.dys_t[t0 * B:], self.dys32[t0 * B:]
+        gheads = [h for h in self.heads if h.compute]
+        for h in gheads:
+            dout = douts.get(h.name)
+            assert dout is not None, f"missing head gradient for {h.name} (pass zeros)"
+            out = self.outs[h.name][t0 * B:]
+            ops.head_prep_sn(dt, dout, h.N, out, h.N, h.module.bias, rows, h.N, self.hsigma[h.name][t0:] if h.sn else None, B, dys_t, 32, h.off,
+                             gof(h.name + ".bias") if (need_wgrad and h.grad) else None, self.hcoef[h.name] if h.sn else None, dys32, self.ncomb)
+        x = self._inp(L, t0)
+        if need_wgrad:
+            ns = ops.conv_wgrad(g["headw"], dt, x, dys_t, ws.slab)
+            tk = self.hk * self.hk
+            for h in gheads:
+                if not h.grad:
+                    continue
+                slab = ws.slab[h.off * self.K:]
+                if h.sn:
+                    ops.wgrad_reduce_rank1(slab, ns, 32, h.N, self.W[-1], tk, gof(h.name + ".weight_orig"), T, self.hcoef[h.name],
+                                           self.hu[h.name][t0:], self.hv[h.name][t0:])
+                else:
+                    ops.wgrad_reduce(slab, ns, 32, h.N, self.W[-1], tk, gof(h.name + ".weight"))
+        last = L - 1
+        if self.bns[last] is not None:
+            ops.dense_small_bwd(dt, dys32, self.head_rec.wp_fwd, None, self._sl(self.dyb[last], t0), rows, self.K, kpad, self.ncomb)
+        else:
+            ops.dense_small_bwd(dt, dys32, self.head_rec.wp_fwd, self._sl(self.a[last], t0), self._sl(self.dz[last], t0), rows, self.K, kpad, self.ncomb,
+                                ACT_LRELU, self.slope, self.sigma[last][t0:], B)
+        for i in range(L - 1, -1, -1):
+            bn = self.bns[i]
+            if bn is not None:
+                assert T == 1
+                nm = self.bn_names[i]
+                ops.bn_bwd_post(dt, self._sl(self.a[i], t0), self._sl(self.dyb[i], t0), self._sl(self.dz[i], t0), self.rows(i), self.W[i], bn.weight, bn.bias,
+                                self.mean[i][t0], self.invstd[i][t0], gof(nm + ".weight") if need_wgrad else None, gof(nm + ".bias") if need_wgrad else None,
+                                ws.sums, ws.small, ACT_LRELU, self.slope, self.sigma[i][t0:t0 + 1])
+            geo = g["l0p"] if i == 0 else g["mid"][i - 1]
+            if need_wgrad:
+                nm = self.conv_names[i]
+                ops.bias_grad_sn(dt, self._sl(self.dz[i], t0), self._sl(self.a[i], t0), self.convs[i].bias, T * self.rows(i), self.W[i], self.rows(i),
+                                 self.sigma[i][t0:], self.slope, ws.small, gof(nm + ".bias"), self.coef[i])
+                ns = ops.conv_wgrad(geo, dt, self._inp(i, t0), self._sl(self.dz[i], t0), ws.slab)
+                ops.wgrad_reduce_rank1(ws.slab, ns, self.W[i], self.W[i], self.cin[i], self.taps if i > 0 else 1, gof(nm + ".weight_orig"), T, self.coef[i],
+                                       self.u[i][t0:], self.v[i][t0:], self.k0 if i == 0 else 0)
+            if i > 0:
+                if self.bns[i - 1] is not None:
+                    ops.conv_bwd_data(geo, dt, self._sl(self.dz[i], t0), self.mid[i - 1].wp_bwd, self._sl(self.dyb[i - 1], t0), None)
+                else:
+                    ops.conv_bwd_data(geo, dt, self._sl(self.dz[i], t0), self.mid[i - 1].wp_bwd, self._sl(self.dz[i - 1], t0),
+                                      ops.epilogue(sigma=self.sigma[i - 1][t0:], sigma_rows=self.rows(i), mask=self._sl(self.a[i - 1], t0), mask_act=ACT_LRELU,
+                                                   mask_slope=self.slope))
+        if need_dimg:
+            ops.conv_bwd_data(self.l0img.c, dt, self._sl(self.dz[0], t0), self.l0img.wp_bwd, self.dimg, ops.epilogue(out_mode=OUT_NCHW_F32))
+            return self.dimg
+        return None
+
+    def backward(self, t0, T, douts, grad, need_wgrad=True, need_dimg=False):
+        """douts: {head name: d(loss)/d(head output) [T*B, N] fp32} for every computed head (zeros where a head carries no
+        loss).  Accumulates into flat ``grad``; returns d(loss)/d(img) of tape t0 if ``need_dimg``."""
+        if self.has_bn and T > 1:
+            dimg = None
+            for kk in range(T):
+                sub = {k: v[kk * self.B:(kk + 1) * self.B] for k, v in douts.items()}
+                r = self._bwd_pass(t0 + kk, 1, sub, grad, need_wgrad, need_dimg and kk == 0)
+                dimg = r if kk == 0 else dimg
+            return dimg
+        return self._bwd_pass(t0, T, douts, grad, need_wgrad, need_dimg)

@@ -86,7 +86,7 @@ int eg_wgrad_reduce(const float* slab, int nsplit, int n_slab, int n_rows, int C
 /* same with a row permutation: slab row n lands in gradient row (n % row_div) * row_mul + n / row_div
  * (Linear whose output is viewed [B,C,H,W] and kept NHWC on device: MNIST/EAD-GAN_rpqmnxy.py:77,95-96) */
 int eg_wgrad_reduce_perm(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad,
-                         int row_div, int row_mul, eg_stream_t s);
+                         int row_div, int row_mul, int c_row /* destination row length in channels, 0 = C */, eg_stream_t s);
 /* out[i] += src[(i / div) * s_div + (i % div) * s_mod]   (un-permute a bias gradient) */
 int eg_gather_add(float* out, const float* src, int n, int div, int s_div, int s_mod, eg_stream_t s);
 /* y[B,H,W,C] = 2x2 sum-pool of x[B,2H,2W,C]  (backward of nn.Upsample(scale_factor=2), MNIST/EAD-GAN_rpqmnxy.py:81,85) */
@@ -111,9 +111,10 @@ size_t eg_bias_grad_sn_ws_floats(int rows, int N, int rows_per_tape);
 int eg_bias_grad_sn(int dtype, const void* dzs, const void* a, const float* bias, int rows, int N, int rows_per_tape,
                     const float* sigma, float slope, float* ws, float* gb, float* coef, eg_stream_t s);
 /* grad[n][c][t] += sum_split slab[split][n][t][c] - sum_tape coef[tape] * u[tape][n] * v[tape][c*T + t]
- * (u: [ntapes][n_rows], v: [ntapes][C*T]); single pass, deterministic. */
+ * (u: [ntapes][n_rows], v: [ntapes][c_row*T]); single pass, deterministic.  c_row: destination row length in channels
+ * (0 = C; < C when the gathered operand was zero padded, e.g. 9 of 16 im2col columns). */
 int eg_wgrad_reduce_rank1(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad,
-                          int ntapes, const float* coef, const float* u, const float* v, eg_stream_t s);
+                          int ntapes, const float* coef, const float* u, const float* v, int c_row, eg_stream_t s);
 /* wp[n][k] = w[(n / n_div) * s_hi + (n % n_div) * s_lo + k * s_k], zero for K <= k < Kpad
  * (ConvTranspose2d on a 1x1 input as a GEMM: celebA/EAD-GAN_celebA.py:76; view-permuted Linear outputs) */
 int eg_pack_strided(int dtype, const float* w, void* wp, int N, int K, int Kpad, int n_div, long long s_hi,
@@ -147,11 +148,12 @@ int eg_dense_small_fwd(int dtype, const void* x, const void* wp, const float* bi
 /* spectrally normalised variant: y = (x Wp^T) / sigma[b / sigma_rows] + bias */
 int eg_dense_small_fwd_sn(int dtype, const void* x, const void* wp, const float* bias, float* y, int B, int K,
                           int Kpad, int N, const float* sigma, int sigma_rows, eg_stream_t s);
-/* gradient prep of a spectrally normalised dense head: dys = dy / sigma[tape] (cast to dtype T, padded to npad columns
- * at column offset col0 of a [rows][npad] buffer), gb[n] += sum_rows dy, coef[tape] = sum dys * (y - bias) */
+/* gradient prep of a dense head: dys = dy / sigma[tape] (sigma == NULL: plain head) written as dtype T at column col0 of a
+ * [rows][npad] buffer and, if dys32 != NULL, as fp32 at column col0 of a [rows][ld32] buffer; gb[n] += sum_rows dy;
+ * coef[tape] = sum dys * (y - bias)  (== <G_t,W>/sigma_t^2, the spectral-norm rank-1 coefficient) */
 int eg_head_prep_sn(int dtype, const float* dy, int ldy, const float* y, int ldyy, const float* bias, int rows, int N,
                     const float* sigma, int rows_per_tape, void* dys, int npad, int col0, float* gb, float* coef,
-                    eg_stream_t s);
+                    float* dys32, int ld32, eg_stream_t s);
 /* dx[b] = (dy[b] Wp) * act'(mask[b]) [/ sigma[b / sigma_rows]] */
 int eg_dense_small_bwd(int dtype, const float* dy, const void* wp, const void* mask, void* dx, int B, int K,
                        int Kpad, int N, int mask_act, float mask_slope, const float* sigma, int sigma_rows,
