@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--workload", default="celeba", choices=["celeba", "mnist"],
+                    help="celeba = the headline metric (default); mnist = BASELINE config[1] (MNIST 32x32, use --batch 256 --dtype f32)")
     return ap.parse_args()
 
 
@@ -101,6 +103,45 @@ def cpu_baseline(B, steps):
             "sample": f"{steps} timed iterations of the same workload (B={B}, fp32, torch-CPU oracle) after 1 warm-up; median"}
 
 
+def main_mnist(a, eg, rank, world, local, dev):
+    """secondary line: MNIST/EAD-GAN_rpqmnxy.py iteration (1.403 GFLOP/img necessary); launch-bound, not MFMA-bound."""
+    from oracle import mnist_oracle as mo          # only for the seeded stand-in of the frozen approximator file
+    B = a.batch
+    torch.manual_seed(0)
+    eg.mnist.load_approximator(mo.make_approximator(123))
+    G, D, E = eg.mnist.Generator(dtype=a.dtype).to(dev), eg.mnist.Discriminator(dtype=a.dtype).to(dev), eg.mnist.Encoder(dtype=a.dtype).to(dev)
+    for m in (G, D, E):
+        m.apply(eg.mnist.weights_init_normal)
+    tr = eg.mnist.MnistTrainer(G, D, E, B, dtype=a.dtype, allreduce=eg.dp.GradAllReduce(world) if world > 1 else None)
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    tr.load_inputs(torch.rand((B, 1, 32, 32), device=dev, generator=g) * 2 - 1, torch.randn((B, 62), device=dev, generator=g),
+                   torch.rand((B, 7), device=dev, generator=g) * 2 - 1, torch.randint(0, 10, (B,), device=dev, generator=g))
+    tr.step_resident()
+    use_graph = (not a.no_graph) and world == 1
+    if use_graph:
+        tr.capture()
+    for _ in range(max(a.warmup - 1, 0)):
+        tr.step_resident()
+    eg.dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.step_resident()
+    torch.cuda.synchronize()
+    eg.dp.barrier()
+    dt = eg.dp.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        ips = B * world * a.steps / dt
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        print(json.dumps({"metric": "imgs/sec per G+D+E train step, MNIST 32x32", "value": round(ips, 1), "unit": "imgs/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+                          "config": {"workload": f"EAD-GAN MNIST 32x32x1 full train iteration (G + D + info/affine over G+E), batch {B}/GPU, "
+                                                 f"{'hipGraph replay' if use_graph else 'eager launches'}", "per_gpu_batch": B, "parallelism": f"dp{world}"},
+                          "whole_step_mfma_frac": round(ips / world * 1.403 / 1e3 / peak, 5), "roofline": None, "cpu_baseline": None,
+                          "final_losses": [round(x, 4) for x in tr.losses.tolist()[:3]]}), flush=True)
+
+
 def main():
     a = parse()
     eg = importlib.import_module("ead-gan_amd")
@@ -110,6 +151,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     B = a.batch
+    if a.workload == "mnist":
+        return main_mnist(a, eg, rank, world, local, dev)
 
     torch.manual_seed(0)                                 # identical replicas on every rank
     G = eg.celeba.Generator(dtype=a.dtype).to(dev)
