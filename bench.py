@@ -80,8 +80,14 @@ def roofline_pass(eg, trainer, dtype, iters=3):
     d = table[dom]
     peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json), if this kernel is in them
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
+    except OSError:
+        pass
     roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": None, "launches_per_step": round(d["launches"], 1),
+            "frac": round(achieved / peak, 4), "traffic": traffic, "launches_per_step": round(d["launches"], 1),
             "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3)}
     return roof, table
 
