@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--force-dist", action="store_true", help="initialise a process group and run the all-reduce hooks even with one rank "
+                                                              "(rehearses the N>1 code path, incl. RCCL capture into the hipGraph, on one GPU)")
     ap.add_argument("--workload", default="celeba", choices=["celeba", "mnist"],
                     help="celeba = the headline metric (default); mnist = BASELINE config[1] (MNIST 32x32, use --batch 256 --dtype f32)")
     return ap.parse_args()
@@ -151,6 +153,11 @@ def main_mnist(a, eg, rank, world, local, dev):
 def main():
     a = parse()
     eg = importlib.import_module("ead-gan_amd")
+    if a.force_dist and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        torch.cuda.set_device(0)
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1)
     rank, world, local = eg.dp.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
@@ -163,7 +170,7 @@ def main():
     torch.manual_seed(0)                                 # identical replicas on every rank
     G = eg.celeba.Generator(dtype=a.dtype).to(dev)
     D = eg.celeba.Discriminator(dtype=a.dtype).to(dev)
-    allreduce = eg.dp.GradAllReduce(world) if world > 1 else None
+    allreduce = eg.dp.GradAllReduce(world, force=a.force_dist) if (world > 1 or a.force_dist) else None
     tr = eg.celeba.CelebATrainer(G, D, B, dtype=a.dtype, allreduce=allreduce)
 
     # synthetic inputs resident in HBM before the timed region: per-rank shard of the global batch
@@ -174,10 +181,16 @@ def main():
     labels = torch.randint(0, 10, (B,), device=dev, generator=g)
     tr.load_inputs(real, z, code, labels)
 
-    use_graph = (not a.no_graph) and world == 1
-    tr.step_resident()                                   # first eager iteration: loads kernels, sizes workspaces
+    use_graph = not a.no_graph                           # RCCL collectives are captured into the same hipGraph
+    tr.step_resident()                                   # first eager iteration: loads kernels, sizes workspaces (and RCCL channels)
     if use_graph:
-        tr.capture()
+        try:
+            tr.capture()
+        except Exception as exc:                         # e.g. a collective that refuses capture: keep going with eager launches
+            print(f"[bench] hipGraph capture failed on rank {rank} ({type(exc).__name__}: {exc}); falling back to eager launches", file=sys.stderr)
+            tr.graph = None
+            use_graph = False
+            torch.cuda.synchronize()
     for _ in range(max(a.warmup - 1, 0)):
         tr.step_resident()
     eg.dp.barrier()
@@ -217,7 +230,7 @@ def main():
             out["kernel_table"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                        "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in table.items()}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

@@ -599,10 +599,14 @@ class CelebATrainer:
         ops.loss_ce_softmaxed(o_gen, 19, cd + 1, nc, B, self.labels, lcat, self.losses[2:3], self.dout[:B])
         ops.loss_affine_rpqxy(o_real, o_trans, 19, 1, B, self.code, cd, laff, self.losses[2:3], self.dout[2 * B:], self.dout[B:2 * B])
         dimg = de.backward(0, 3, self.dout, da.grad, need_dimg=True)
-        ge.backward(dimg, ga.grad)
+        pending = self.allreduce.start(da.grad) if (self.allreduce is not None and hasattr(self.allreduce, "start")) else None
+        ge.backward(dimg, ga.grad)                      # overlaps with the D-gradient all-reduce
         if self.allreduce is not None:
             self.allreduce(ga.grad)
-            self.allreduce(da.grad)
+            if pending is not None:
+                self.allreduce.finish(pending)
+            elif not hasattr(self.allreduce, "start"):
+                self.allreduce(da.grad)
         self._adam(ga, self.miG, self.viG, self.lr[2], 2, True)
         self._adam(da, self.miD, self.viD, self.lr[2], 2, False)
         ge.repack()

@@ -30,17 +30,35 @@ class GradAllReduce:
     """callable(flat_grad): in-place mean over ranks.  One collective per arena per backward pass (the arenas are
     58 MB / 45 MB fp32 on CelebA: large, few messages -- what per-link-bound xGMI rings want)."""
 
-    def __init__(self, world: int, group=None):
-        self.world, self.group = world, group
+    def __init__(self, world: int, group=None, force: bool = False):
+        self.world, self.group, self.force = world, group, force
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
 
     def __call__(self, flat: torch.Tensor):
-        if self.world <= 1:
+        if self.world <= 1 and not self.force:
             return
         if self.backend == "nccl":
             dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.mul_(1.0 / self.world)
+
+
+    # asynchronous form: the collective runs on RCCL's own stream; compute enqueued after start() overlaps with it and
+    # finish() makes the compute stream wait (works eagerly and under hipGraph capture: the dependency is an event edge)
+    def start(self, flat: torch.Tensor):
+        if self.world <= 1 and not self.force:
+            return None
+        if self.backend == "nccl":
+            return (dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None)
+        return (dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat)
+
+    def finish(self, handle):
+        if handle is None:
+            return
+        work, flat = handle
+        work.wait()
+        if flat is not None:
             flat.mul_(1.0 / self.world)
 
 

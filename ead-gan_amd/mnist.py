@@ -479,10 +479,14 @@ class MnistTrainer:
         ops.loss_affine_rpqmnxy(lat[2 * B:], lat[B:2 * B], cd, 0, B, self.code, cd, self.mlp, laff, self.losses[2:3], self.d_code[2 * B:],
                                 self.d_code[B:2 * B], None, self.ws_aff)
         dimg = ee.backward(0, 3, {"aux_layer.0": self.d_cat, "latent_layer.0": self.d_code}, ea.grad, need_dimg=True)
-        ge.backward(dimg, ga.grad)
+        pending = self.allreduce.start(ea.grad) if (self.allreduce is not None and hasattr(self.allreduce, "start")) else None
+        ge.backward(dimg, ga.grad)                      # overlaps with the encoder-gradient all-reduce
         if self.allreduce is not None:
             self.allreduce(ga.grad)
-            self.allreduce(ea.grad)
+            if pending is not None:
+                self.allreduce.finish(pending)
+            elif not hasattr(self.allreduce, "start"):
+                self.allreduce(ea.grad)
         self._adam(ga, self.miG, self.viG, self.lr[2], 2, True)
         self._adam(ea, self.miE, self.viE, self.lr[2], 2, False)
         ge.repack()

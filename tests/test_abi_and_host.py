@@ -76,6 +76,10 @@ g = torch.arange(10, dtype=torch.float32) * (rank + 1)
 ar(g)
 want = torch.arange(10, dtype=torch.float32) * sum(r + 1 for r in range(world)) / world
 assert torch.allclose(g, want), (g, want)
+g2 = torch.ones(6) * (rank + 1)
+h = ar.start(g2)            # asynchronous form used to overlap the all-reduce with the generator backward
+ar.finish(h)
+assert torch.allclose(g2, torch.ones(6) * 1.5), g2
 t = eg.dp.max_over_ranks(float(rank + 1), torch.device("cpu"))
 assert t == float(world), t
 eg.dp.barrier()
