@@ -75,6 +75,10 @@ int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, const void* wp
                      const eg_epilogue* ep, eg_stream_t s);
 /* tile (BM*1000+BN) of the igemm_nt instantiation a problem is dispatched to (profiling labels only) */
 int eg_igemm_nt_tile(int M, int N, int nphase);
+/* LDS-DMA (global_load_lds) staged variants of the NT kernel for large launches: 0 = off (register staging only),
+ * 1 = 256x128 tile / 3-stage ring, 2 = 128x128 tile / 2 stages (default), 3 = 128x128 / 3 stages.  Returns the previous
+ * setting.  All variants are bit-identical to the register-staged kernel; measurements in DESIGN.md section 4. */
+int eg_set_igemm_dma(int on);
 /* dW partial slabs: slab[split][Cout][k*k][Cin] fp32.  Returns the split count through *nsplit. */
 size_t eg_conv_wgrad_ws_bytes(const eg_conv* c, int dtype);
 int eg_conv_wgrad(const eg_conv* c, int dtype, const void* X, const void* dY, float* slab, int* nsplit,

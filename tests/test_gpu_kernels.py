@@ -410,3 +410,57 @@ def test_spectral_norm_multi_layer_launch_matches_single():
         torch.testing.assert_close(us, u1, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(vs, v1, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(sg, s1, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_igemm_dma_variant_matches_register_staged_kernel(dtype):
+    """256x128 LDS-DMA variant of the NT kernel (large launches only): bit-exact vs the 128x128 register-staged kernel (same
+    K order) and within tolerance of torch, for a padded stride-2 forward conv and a 4-phase backward-data."""
+    lib = eg._lib.lib()
+    g = torch.Generator().manual_seed(21)
+    # forward: B=64, 64x64x32 -> 32x32x128  (M = 65536 -> 256 tiles)
+    B, H, Cin, Cout = 64, 64, 32, 128
+    x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
+    w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    c = ops.make_conv(B, H, H, Cin, Cout, 4, 2, 1)
+    wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
+    ops.pack_fwd(c, dtype, w.to(DEV), wp)
+    xd = nhwc(x, dtype)
+    outs = []
+    for on in (1, 2, 0):
+        lib.query("eg_set_igemm_dma", on)
+        assert lib.query("eg_igemm_nt_tile", B * 32 * 32, Cout, 1) == {1: 256128, 2: 128129, 0: 128128}[on]
+        y = torch.zeros(B, 32, 32, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
+        ops.conv_fwd(c, dtype, xd, wp, y, ops.epilogue(bias=b.to(DEV), act=ops.ACT_LRELU, slope=0.2))
+        torch.cuda.synchronize()
+        outs.append(y)
+    lib.query("eg_set_igemm_dma", 2)
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
+    want = F.leaky_relu(F.conv2d(x, rq(w, dtype), b, 2, 1), 0.2)
+    rt, at = tol(dtype, Cin * 16)
+    torch.testing.assert_close(nchw(outs[0]), want, rtol=rt, atol=at)
+    # backward-data: dY [16,32,32,64] -> dX [16,64,64,128], 4 phases of M = 16384
+    B, H, Cin, Cout = 16, 64, 128, 64
+    dy = rq(torch.randn(B, Cout, 32, 32, generator=g), dtype)
+    w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.05
+    a = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
+    c = ops.make_conv(B, H, H, Cin, Cout, 4, 2, 1)
+    wp = torch.empty(ops.pack_bwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
+    ops.pack_bwd(c, dtype, w.to(DEV), wp)
+    sig = torch.tensor([1.3, 0.7], device=DEV)
+    outs = []
+    for on in (1, 2, 0):
+        lib.query("eg_set_igemm_dma", on)
+        dx = torch.zeros(B, H, H, Cin, device=DEV, dtype=ops.torch_dtype(dtype))
+        ops.conv_bwd_data(c, dtype, nhwc(dy, dtype), wp, dx,
+                          ops.epilogue(sigma=sig, sigma_rows=8 * 32 * 32, mask=nhwc(a, dtype), mask_act=ops.ACT_LRELU, mask_slope=0.1))
+        torch.cuda.synchronize()
+        outs.append(dx)
+    lib.query("eg_set_igemm_dma", 2)
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
+    want = F.conv_transpose2d(dy, rq(w, dtype), None, 2, 1) * torch.where(a > 0, 1.0, 0.1)
+    want[:8] /= 1.3
+    want[8:] /= 0.7
+    rt, at = tol(dtype, Cout * 4)
+    torch.testing.assert_close(nchw(outs[0]), want, rtol=rt, atol=at)
