@@ -348,3 +348,117 @@ extern "C" int eg_loss_affine_rpqmnxy(const float* o_real, const float* o_trans,
     EG_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// dSprites: theta kernels (dSprites/utils_rp.py:38-59,94-115; utils_pxy.py:69-87 with the torch.inverse of rp.py:376 folded
+// in: the alignment matrix is a pure translation T(x,y), so its inverse is T(-x,-y)), closed-form affine regulariser and
+// mutual_info_loss (rp.py:225-232).
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ void theta_rp_kernel(const float* __restrict__ code, int ldc, int B, float* __restrict__ theta) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float c[4];
+    for (int i = 0; i < 4; ++i) c[i] = code[(size_t)b * ldc + i];
+    const Aff<float> m = matrix_rp<float>(c);
+    float* t = theta + (size_t)b * 6;
+    t[0] = m.a; t[1] = m.b; t[2] = m.c; t[3] = m.d; t[4] = m.e; t[5] = m.f;
+}
+extern "C" int eg_theta_rp(const float* code, int ldc, int B, float* theta, eg_stream_t s) {
+    EG_REQUIRE(code && theta && ldc >= 4, "eg_theta_rp: bad argument");
+    hipLaunchKernelGGL(theta_rp_kernel, dim3(cdiv(B, 128)), dim3(128), 0, (hipStream_t)s, code, ldc, B, theta);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// theta of inverse(get_matrix_pxy_align(code)) rows 0,1: code = (p, x, y) latent units, x,y scaled by 0.1 (p is not used by the align matrix)
+__global__ void theta_pxy_align_inv_kernel(const float* __restrict__ code, int ldc, int B, float* __restrict__ theta) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float* t = theta + (size_t)b * 6;
+    t[0] = 1.f; t[1] = 0.f; t[2] = -(code[(size_t)b * ldc + 1] * 0.1f);
+    t[3] = 0.f; t[4] = 1.f; t[5] = -(code[(size_t)b * ldc + 2] * 0.1f);
+}
+extern "C" int eg_theta_pxy_align_inv(const float* code, int ldc, int B, float* theta, eg_stream_t s) {
+    EG_REQUIRE(code && theta && ldc >= 3, "eg_theta_pxy_align_inv: bad argument");
+    hipLaunchKernelGGL(theta_pxy_align_inv_kernel, dim3(cdiv(B, 128)), dim3(128), 0, (hipStream_t)s, code, ldc, B, theta);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void affine_reg_rp_kernel(const float* __restrict__ o_real, const float* __restrict__ o_trans, int ld, int c0, int B,
+                                     const float* __restrict__ code, int ldc, float scale, float* loss, float* __restrict__ d_real,
+                                     float* __restrict__ d_trans, float* __restrict__ pred_out) {
+    __shared__ float sm[16];
+    float acc = 0.f;
+    const float gs = 2.f * scale / (float)(B * 4);
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        Dual<8> rc[4], tc[4], out[4];
+        for (int i = 0; i < 4; ++i) {
+            rc[i] = dvar<8>(o_real[(size_t)b * ld + c0 + i], i);
+            tc[i] = dvar<8>(o_trans[(size_t)b * ld + c0 + i], 4 + i);
+        }
+        regularizer_rp<Dual<8>>(rc, tc, out);
+        float gr[8];
+        for (int i = 0; i < 8; ++i) gr[i] = 0.f;
+        for (int j = 0; j < 4; ++j) {
+            const float d = out[j].v - code[(size_t)b * ldc + j];
+            acc += d * d;
+            if (pred_out) pred_out[(size_t)b * 4 + j] = out[j].v;
+            for (int i = 0; i < 8; ++i) gr[i] += gs * d * out[j].d[i];
+        }
+        if (d_real && d_trans) {
+            for (int j = 0; j < ld; ++j) { d_real[(size_t)b * ld + j] = 0.f; d_trans[(size_t)b * ld + j] = 0.f; }
+            for (int i = 0; i < 4; ++i) { d_real[(size_t)b * ld + c0 + i] = gr[i]; d_trans[(size_t)b * ld + c0 + i] = gr[4 + i]; }
+        }
+    }
+    const float tot = block_sum(acc, sm);
+    if (threadIdx.x == 0 && loss) loss[0] += scale * tot / (float)(B * 4);
+}
+extern "C" int eg_loss_affine_rp(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc, float scale,
+                                 float* loss, float* d_real, float* d_trans, float* pred_out, eg_stream_t s) {
+    EG_REQUIRE(o_real && o_trans && code && B > 0, "eg_loss_affine_rp: bad argument");
+    hipLaunchKernelGGL(affine_reg_rp_kernel, dim3(1), dim3(128), 0, (hipStream_t)s, o_real, o_trans, ld, c0, B, code, ldc, scale, loss, d_real, d_trans, pred_out);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// mutual_info_loss(softmax(o), c) = mean_b( -sum_j log(p_j + eps) c_j ) + mean_b( -sum_j log(c_j + eps) c_j ),  eps = 1e-8.
+// target: probabilities tgt[b][j] (target_logits == 0) or softmax of logits tgt (target_logits != 0, treated as a constant).
+// dout (+=) d loss / d o.
+__global__ void mutual_info_kernel(const float* __restrict__ o, int ld, int c0, int n, int B, const float* __restrict__ tgt, int ldt, int t0,
+                                   int target_logits, float scale, float* loss, float* __restrict__ dout) {
+    __shared__ float sm[16];
+    const float eps = 1e-8f;
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        float p[EG_MAXCAT], c[EG_MAXCAT];
+        float mx = -INFINITY, se = 0.f;
+        for (int j = 0; j < n; ++j) mx = fmaxf(mx, o[(size_t)b * ld + c0 + j]);
+        for (int j = 0; j < n; ++j) { p[j] = expf(o[(size_t)b * ld + c0 + j] - mx); se += p[j]; }
+        for (int j = 0; j < n; ++j) p[j] /= se;
+        if (target_logits) {
+            float m2 = -INFINITY, s2 = 0.f;
+            for (int j = 0; j < n; ++j) m2 = fmaxf(m2, tgt[(size_t)b * ldt + t0 + j]);
+            for (int j = 0; j < n; ++j) { c[j] = expf(tgt[(size_t)b * ldt + t0 + j] - m2); s2 += c[j]; }
+            for (int j = 0; j < n; ++j) c[j] /= s2;
+        } else
+            for (int j = 0; j < n; ++j) c[j] = tgt[(size_t)b * ldt + t0 + j];
+        float dp[EG_MAXCAT], dot = 0.f;
+        for (int j = 0; j < n; ++j) {
+            acc += -logf(p[j] + eps) * c[j] - logf(c[j] + eps) * c[j];
+            dp[j] = -c[j] / (p[j] + eps) * (scale / (float)B);
+            dot += dp[j] * p[j];
+        }
+        if (dout)
+            for (int j = 0; j < n; ++j) dout[(size_t)b * ld + c0 + j] += p[j] * (dp[j] - dot);
+    }
+    const float tot = block_sum(acc, sm);
+    if (threadIdx.x == 0 && loss) loss[0] += scale * tot / (float)B;
+}
+extern "C" int eg_loss_mutual_info(const float* o, int ld, int c0, int n, int B, const float* tgt, int ldt, int t0, int target_logits, float scale,
+                                   float* loss, float* dout, eg_stream_t s) {
+    EG_REQUIRE(o && tgt && n <= EG_MAXCAT && B > 0, "eg_loss_mutual_info: bad argument");
+    hipLaunchKernelGGL(mutual_info_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, o, ld, c0, n, B, tgt, ldt, t0, target_logits, scale, loss, dout);
+    EG_LAUNCH_CHECK();
+    return 0;
+}

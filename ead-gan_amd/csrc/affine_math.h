@@ -97,3 +97,30 @@ template <typename Num> __device__ __forceinline__ void relative_rpqmnxy(const N
     const Aff<Num> rel = aff_mul(matrix_rpqmnxy(trans7), aff_inv(matrix_rpqmnxy(real7)));
     flat6[0] = rel.a; flat6[1] = rel.b; flat6[2] = rel.c; flat6[3] = rel.d; flat6[4] = rel.e; flat6[5] = rel.f;
 }
+
+// ---- dSprites variant, 4 codes (theta,p,x,y): dSprites/utils_rp.py:23-147 ----------------------------------------------
+// A = Rot(theta) * diag(p,p,1) * Trans(x,y)   (get_matrix == get_matrix_D)
+template <typename Num> __device__ __forceinline__ Aff<Num> matrix_rp(const Num* c) {
+    const Num th = c[0] * (EG_PI_F / 9.f);
+    const Num p = c[1] * 0.2f + 1.f;
+    const Num x = c[2] * 0.1f, y = c[3] * 0.1f;
+    const Num cs = ncos(th), sn = nsin(th);
+    Aff<Num> m;
+    m.a = p * cs; m.b = -(p * sn); m.d = p * sn; m.e = p * cs;
+    m.c = m.a * x + m.b * y;
+    m.f = m.d * x + m.e * y;
+    return m;
+}
+// closed-form recovery, utils_rp.py:118-147; out = 4 latent units
+template <typename Num> __device__ __forceinline__ void regularizer_rp(const Num* real4, const Num* trans4, Num* out) {
+    const Aff<Num> rel = aff_mul(matrix_rp(trans4), aff_inv(matrix_rp(real4)));
+    const Num th = natan((rel.d - rel.b) / (rel.a + rel.e));
+    const Num cs = ncos(th), sn = nsin(th);
+    const Num p = (cs * (rel.a + rel.e) + sn * (rel.d - rel.b)) * 0.5f;
+    const Num x = (rel.c * cs + rel.f * sn) / p;
+    const Num y = (rel.f * cs - rel.c * sn) / p;
+    out[0] = th * (9.f / EG_PI_F);
+    out[1] = (p - 1.f) / 0.2f;
+    out[2] = x / 0.1f;
+    out[3] = y / 0.1f;
+}

@@ -144,3 +144,24 @@ extern "C" int eg_sumpool2x2(int dtype, const void* x, void* y, int B, int H, in
     EG_LAUNCH_CHECK();
     return 0;
 }
+
+__global__ void add_f32_kernel(float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = a[i] + b[i];
+}
+extern "C" int eg_add_f32(float* out, const float* a, const float* b, size_t n, eg_stream_t s) {
+    EG_REQUIRE(out && a && b, "eg_add_f32: null pointer");
+    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(add_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, out, a, b, n);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void u8_to_f32_kernel(const unsigned char* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = (float)x[i];
+}
+extern "C" int eg_u8_to_f32(const unsigned char* x, float* y, size_t n, eg_stream_t s) {
+    EG_REQUIRE(x && y, "eg_u8_to_f32: null pointer");
+    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(u8_to_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, x, y, n);
+    EG_LAUNCH_CHECK();
+    return 0;
+}

@@ -327,6 +327,30 @@ def loss_affine_rpqmnxy(o_real, o_trans, ld, c0, B, code, ldc, mlp, scale, loss,
                _p(pred_out), _p(ws), _stream())
 
 
+def theta_rp(code, ldc, B, theta):
+    lib().call("eg_theta_rp", _p(code), ldc, B, _p(theta), _stream())
+
+
+def theta_pxy_align_inv(code, ldc, B, theta):
+    lib().call("eg_theta_pxy_align_inv", _p(code), ldc, B, _p(theta), _stream())
+
+
+def loss_affine_rp(o_real, o_trans, ld, c0, B, code, ldc, scale, loss, d_real, d_trans, pred_out=None):
+    lib().call("eg_loss_affine_rp", _p(o_real), _p(o_trans), ld, c0, B, _p(code), ldc, scale, _p(loss), _p(d_real), _p(d_trans), _p(pred_out), _stream())
+
+
+def loss_mutual_info(o, ld, c0, n, B, tgt, ldt, t0, target_logits, scale, loss, dout):
+    lib().call("eg_loss_mutual_info", _p(o), ld, c0, n, B, _p(tgt), ldt, t0, int(target_logits), scale, _p(loss), _p(dout), _stream())
+
+
+def add_f32(out, a, b):
+    lib().call("eg_add_f32", _p(out), _p(a), _p(b), out.numel(), _stream())
+
+
+def u8_to_f32(x, y):
+    lib().call("eg_u8_to_f32", _p(x), _p(y), y.numel(), _stream())
+
+
 def loss_bce_sigmoid(o, ld, col, B, target, scale, loss, dout, zero_rows=True):
     lib().call("eg_loss_bce_sigmoid", _p(o), ld, col, B, target, scale, _p(loss), _p(dout), int(zero_rows), _stream())
 

@@ -31,9 +31,11 @@ class Head:
 
 
 class TrunkEngine:
-    def __init__(self, owner, convs, conv_names, bns, bn_names, heads, in_ch, size, k, slope, B, dtype, NT):
-        """convs: SN conv modules; bns: per-layer BatchNorm module or None (applied AFTER the LeakyReLU of that layer)."""
+    def __init__(self, owner, convs, conv_names, bns, bn_names, heads, in_ch, size, k, slope, B, dtype, NT, fcs=None, fc_names=None):
+        """convs: SN conv modules; bns: per-layer BatchNorm module or None (applied AFTER the LeakyReLU of that layer);
+        fcs: optional hidden SN-Linear layers (each followed by LeakyReLU(slope)) between the conv trunk and the heads."""
         self.owner, self.convs, self.conv_names, self.bns, self.bn_names = owner, convs, conv_names, bns, bn_names
+        self.fcs, self.fc_names = list(fcs or []), list(fc_names or [])
         self.heads, self.B, self.dtype, self.NT, self.k, self.slope = heads, B, dtype, NT, k, slope
         self.in_ch, self.S = in_ch, size
         dev = owner.arena.flat.device
@@ -54,7 +56,14 @@ class TrunkEngine:
         self.l0p = ConvRec(dtype, NT * B, size // 2, size // 2, self.kp, self.W[0], 1, 1, 0, device=dev, want_bwd=False, ws=ws)
         self.mid = [ConvRec(dtype, NT * B, self.hw[i], self.hw[i], self.W[i], self.W[i + 1], k, 2, pad, device=dev, ws=ws) for i in range(L - 1)]
         self.hk = self.hw[-1]
-        self.K = self.hk * self.hk * self.W[-1]
+        self.Kc = self.hk * self.hk * self.W[-1]                    # flattened conv-trunk features
+        self.fN = [f.weight_orig.shape[0] for f in self.fcs]
+        self.fK = [self.Kc] + self.fN[:-1]
+        self.K = self.fN[-1] if self.fcs else self.Kc               # features the heads read
+        self.head_hk = 1 if self.fcs else self.hk
+        self.head_C = self.K if self.fcs else self.W[-1]
+        assert not (self.fcs and bns[-1] is not None), "hidden FC layers after a BatchNorm-terminated trunk are not needed by any reference net"
+        self.frec = [ConvRec(dtype, NT * B, 1, 1, self.fK[i], self.fN[i], 1, 1, 0, device=dev, ws=ws) for i in range(len(self.fcs))]
         off = 0
         for h in heads:
             w = h.module.weight_orig if h.sn else h.module.weight
@@ -64,14 +73,15 @@ class TrunkEngine:
                 off += h.N
         self.ncomb = off
         assert self.ncomb <= 32, "combined head panel holds at most 32 outputs"
-        self.head_rec = ConvRec(dtype, NT * B, self.hk, self.hk, self.W[-1], 32, self.hk, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
+        self.head_rec = ConvRec(dtype, NT * B, self.head_hk, self.head_hk, self.head_C, 32, self.head_hk, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
         self.head_rec.wp_fwd.zero_()
         self.headw = ConvRec(dtype, NT * B, 1, 1, self.K, 32, 1, 1, 0, device=dev, want_fwd=False, want_bwd=False, ws=ws)
         self.geo = {}
         for T in range(1, NT + 1):
             self.geo[T] = {"l0p": ops.make_conv(T * B, size // 2, size // 2, self.kp, self.W[0], 1, 1, 0),
                            "mid": [ops.make_conv(T * B, self.hw[i], self.hw[i], self.W[i], self.W[i + 1], k, 2, pad) for i in range(L - 1)],
-                           "headw": ops.make_conv(T * B, 1, 1, self.K, 32, 1, 1, 0)}
+                           "headw": ops.make_conv(T * B, 1, 1, self.K, 32, 1, 1, 0),
+                           "fc": [ops.make_conv(T * B, 1, 1, self.fK[i], self.fN[i], 1, 1, 0) for i in range(len(self.fcs))]}
         for i in range(L):
             ws.need_small(ops.bias_grad_sn_ws_floats(NT * B * self.hw[i] ** 2, self.W[i], B * self.hw[i] ** 2))
             if bns[i] is not None:
@@ -86,6 +96,14 @@ class TrunkEngine:
         self.dyb = [torch.empty_like(t) if bns[i] is not None else None for i, t in enumerate(self.a)]   # dL/d(BN output)
         self.mean = [z(NT, self.W[i]) if bns[i] is not None else None for i in range(L)]
         self.invstd = [z(NT, self.W[i]) if bns[i] is not None else None for i in range(L)]
+        self.fa = [e(NT * B, n) for n in self.fN]                                            # hidden FC outputs (LeakyReLU)
+        self.fdz = [torch.empty_like(t) for t in self.fa]
+        for n in self.fN:
+            ws.need_small(ops.bias_grad_sn_ws_floats(NT * B, n, B))
+        self.fsigma = [torch.ones(NT, device=dev) for _ in self.fcs]
+        self.fu = [z(NT, n) for n in self.fN]
+        self.fv = [z(NT, kk) for kk in self.fK]
+        self.fcoef = [z(4) for _ in self.fcs]
         self.outs = {h.name: z(NT * B, h.N) for h in heads if h.compute}
         self.dys_t = torch.zeros(NT * B, 32, device=dev, dtype=tdt)
         self.dys32 = z(NT * B, max(self.ncomb, 1))
@@ -102,6 +120,7 @@ class TrunkEngine:
         self._sn_arrays = []
         for t in range(NT):
             ent = [(c.weight_orig, c.weight_u, c.weight_v, self.sigma[i][t:t + 1], self.u[i][t], self.v[i][t]) for i, c in enumerate(convs)]
+            ent += [(f.weight_orig, f.weight_u, f.weight_v, self.fsigma[i][t:t + 1], self.fu[i][t], self.fv[i][t]) for i, f in enumerate(self.fcs)]
             ent += [(h.module.weight_orig, h.module.weight_u, h.module.weight_v, self.hsigma[h.name][t:t + 1], self.hu[h.name][t], self.hv[h.name][t])
                     for h in heads if h.sn]
             self._sn_arrays.append(ops.sn_layers(ent))
@@ -116,12 +135,21 @@ class TrunkEngine:
         ops.pack_strided(dt, self.convs[0].weight_orig, self.l0p.wp_fwd, self.W[0], self.k0, self.l0p.Kpad_fwd, 1, self.k0, 0, 1)
         for i in range(self.L - 1):
             self.mid[i].pack(self.convs[i + 1].weight_orig)
+        for i, f in enumerate(self.fcs):
+            if i == 0:
+                # Linear over the NCHW-flattened map: forward panel [N][(kh,kw,ci)] via the k=hk conv view, backward panel [n'][co] with
+                # n' = t*C + ci  <-  master column f = ci*T + t
+                T = self.hk * self.hk
+                ops.pack_fwd(ops.make_conv(self.B, self.hk, self.hk, self.W[-1], self.fN[0], self.hk, 1, 0), dt, f.weight_orig, self.frec[0].wp_fwd)
+                ops.pack_strided(dt, f.weight_orig, self.frec[0].wp_bwd, self.Kc, self.fN[0], ops.round_up(self.fN[0], ops.bk(dt)), self.W[-1], 1, T, self.Kc)
+            else:
+                self.frec[i].pack(f.weight_orig)
         kpad = self.head_rec.Kpad_fwd
         for h in self.heads:
             if not h.compute:
                 continue
             w = h.module.weight_orig if h.sn else h.module.weight
-            c = ops.make_conv(self.B, self.hk, self.hk, self.W[-1], h.N, self.hk, 1, 0)
+            c = ops.make_conv(self.B, self.head_hk, self.head_hk, self.head_C, h.N, self.head_hk, 1, 0)
             ops.pack_fwd(c, dt, w, self.head_rec.wp_fwd[h.off * kpad:])
 
     def rows(self, i):
@@ -150,6 +178,10 @@ class TrunkEngine:
                 ops.bn_fwd_train(dt, self._sl(self.a[i], t0), self._sl(self.y[i], t0), self.rows(i), self.W[i], bn.weight, bn.bias, bn.eps, bn.momentum,
                                  bn.running_mean, bn.running_var, bn.num_batches_tracked, self.mean[i][t0], self.invstd[i][t0], self.ws.small, ACT_NONE)
         x = self._inp(self.L, t0)
+        for i, f in enumerate(self.fcs):
+            ops.conv_fwd(g["fc"][i], dt, x, self.frec[i].wp_fwd, self.fa[i][t0 * B:],
+                         ops.epilogue(bias=f.bias, sigma=self.fsigma[i][t0:], sigma_rows=B, act=ACT_LRELU, slope=self.slope))
+            x = self.fa[i][t0 * B:]
         kpad = self.head_rec.Kpad_fwd
         for h in self.heads:
             if not h.compute:
@@ -175,6 +207,9 @@ class TrunkEngine:
                 for i, c in enumerate(self.convs):
                     self.u[i][t].copy_(c.weight_u)
                     self.v[i][t].copy_(c.weight_v)
+                for i, f in enumerate(self.fcs):
+                    self.fu[i][t].copy_(f.weight_u)
+                    self.fv[i][t].copy_(f.weight_v)
                 for h in self.heads:
                     if h.sn:
                         self.hu[h.name][t].copy_(h.module.weight_u)
@@ -202,21 +237,41 @@ class TrunkEngine:
             out = self.outs[h.name][t0 * B:]
             ops.head_prep_sn(dt, dout, h.N, out, h.N, h.module.bias, rows, h.N, self.hsigma[h.name][t0:] if h.sn else None, B, dys_t, 32, h.off,
                              gof(h.name + ".bias") if (need_wgrad and h.grad) else None, self.hcoef[h.name] if h.sn else None, dys32, self.ncomb)
-        x = self._inp(L, t0)
+        nf = len(self.fcs)
+        x = self.fa[-1][t0 * B:] if nf else self._inp(L, t0)
         if need_wgrad:
             ns = ops.conv_wgrad(g["headw"], dt, x, dys_t, ws.slab)
-            tk = self.hk * self.hk
+            tk = self.head_hk * self.head_hk
             for h in gheads:
                 if not h.grad:
                     continue
                 slab = ws.slab[h.off * self.K:]
                 if h.sn:
-                    ops.wgrad_reduce_rank1(slab, ns, 32, h.N, self.W[-1], tk, gof(h.name + ".weight_orig"), T, self.hcoef[h.name],
+                    ops.wgrad_reduce_rank1(slab, ns, 32, h.N, self.head_C, tk, gof(h.name + ".weight_orig"), T, self.hcoef[h.name],
                                            self.hu[h.name][t0:], self.hv[h.name][t0:])
                 else:
-                    ops.wgrad_reduce(slab, ns, 32, h.N, self.W[-1], tk, gof(h.name + ".weight"))
+                    ops.wgrad_reduce(slab, ns, 32, h.N, self.head_C, tk, gof(h.name + ".weight"))
         last = L - 1
-        if self.bns[last] is not None:
+        if nf:
+            ops.dense_small_bwd(dt, dys32, self.head_rec.wp_fwd, self.fa[-1][t0 * B:], self.fdz[-1][t0 * B:], rows, self.K, kpad, self.ncomb,
+                                ACT_LRELU, self.slope, self.fsigma[-1][t0:], B)
+            for i in range(nf - 1, -1, -1):
+                f, nm = self.fcs[i], self.fc_names[i]
+                xin = self.fa[i - 1][t0 * B:] if i > 0 else self._inp(L, t0)
+                if need_wgrad:
+                    ops.bias_grad_sn(dt, self.fdz[i][t0 * B:], self.fa[i][t0 * B:], f.bias, rows, self.fN[i], B, self.fsigma[i][t0:], self.slope, ws.small,
+                                     gof(nm + ".bias"), self.fcoef[i])
+                    ns = ops.conv_wgrad(g["fc"][i], dt, xin, self.fdz[i][t0 * B:], ws.slab)
+                    C, tk = (self.W[-1], self.hk * self.hk) if i == 0 else (self.fK[i], 1)
+                    ops.wgrad_reduce_rank1(ws.slab, ns, self.fN[i], self.fN[i], C, tk, gof(nm + ".weight_orig"), T, self.fcoef[i], self.fu[i][t0:], self.fv[i][t0:])
+                if i > 0:
+                    ops.conv_bwd_data(g["fc"][i], dt, self.fdz[i][t0 * B:], self.frec[i].wp_bwd, self.fdz[i - 1][t0 * B:],
+                                      ops.epilogue(sigma=self.fsigma[i - 1][t0:], sigma_rows=B, mask=self.fa[i - 1][t0 * B:], mask_act=ACT_LRELU, mask_slope=self.slope))
+                else:
+                    ops.conv_bwd_data(g["fc"][0], dt, self.fdz[0][t0 * B:], self.frec[0].wp_bwd, self._sl(self.dz[last], t0),
+                                      ops.epilogue(sigma=self.sigma[last][t0:], sigma_rows=B, mask=self._sl(self.a[last], t0), mask_act=ACT_LRELU,
+                                                   mask_slope=self.slope))
+        elif self.bns[last] is not None:
             ops.dense_small_bwd(dt, dys32, self.head_rec.wp_fwd, None, self._sl(self.dyb[last], t0), rows, self.K, kpad, self.ncomb)
         else:
             ops.dense_small_bwd(dt, dys32, self.head_rec.wp_fwd, self._sl(self.a[last], t0), self._sl(self.dz[last], t0), rows, self.K, kpad, self.ncomb,

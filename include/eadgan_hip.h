@@ -232,6 +232,15 @@ int eg_theta_rpqmnxy(const float* code, int ldc, int B, float* theta, eg_stream_
 int eg_loss_affine_rpqmnxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc,
                            const float* mlp, float scale, float* loss, float* d_real, float* d_trans, float* pred_out,
                            float* ws /* B floats */, eg_stream_t s);
+/* dSprites variants (dSprites/utils_rp.py:38-59,94-147, utils_pxy.py:69-87, rp.py:225-232,375-377) */
+int eg_theta_rp(const float* code, int ldc, int B, float* theta, eg_stream_t s);                 /* rows 0,1 of R Z(p,p) T */
+int eg_theta_pxy_align_inv(const float* code, int ldc, int B, float* theta, eg_stream_t s);      /* rows 0,1 of inverse(T(x,y)) */
+int eg_loss_affine_rp(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc, float scale,
+                      float* loss, float* d_real, float* d_trans, float* pred_out, eg_stream_t s);
+int eg_loss_mutual_info(const float* o, int ld, int c0, int n, int B, const float* tgt, int ldt, int t0, int target_logits,
+                        float scale, float* loss, float* dout, eg_stream_t s);
+int eg_add_f32(float* out, const float* a, const float* b, size_t n, eg_stream_t s);
+int eg_u8_to_f32(const unsigned char* x, float* y, size_t n, eg_stream_t s);            /* uint8 sprites -> float (rp.py:369-370) */
 int eg_loss_affine_rpqxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc,
                          float scale, float* loss, float* d_real, float* d_trans, float* pred_out, eg_stream_t s);
 

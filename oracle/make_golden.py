@@ -17,6 +17,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import ref_harness as rh            # noqa: E402
 from oracle import celeba_oracle as co          # noqa: E402
 from oracle import mnist_oracle as mo           # noqa: E402
+from oracle import dsprites_oracle as do        # noqa: E402
 
 GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
@@ -140,7 +141,34 @@ def make_mnist_affine(B=16, seed=5, mlp_seed=123):
     print("mnist affine golden written")
 
 
-MAKERS = {"celeba": make_celeba, "celeba_affine": make_celeba_affine, "mnist": make_mnist, "mnist_affine": make_mnist_affine}
+def make_dsprites(B=8, steps=3, seed=0, pxy_seed=321):
+    """dSprites/rp.py loop (:365-482) on synthetic uint8 sprites; encoder_pxy_50000.pt is a seeded stand-in in the temp cwd."""
+    torch.set_num_threads(8)
+    sprites = do.synthetic_sprites(B * steps, seed=99).view(steps, B, 64, 64)
+    out = {"B": np.array(B), "steps": np.array(steps), "seed": np.array(seed), "sprite_seed": np.array(99), "pxy_seed": np.array(pxy_seed)}
+    names = ("d_loss", "g_loss", "info_loss", "affine_loss", "relative_cat_loss")
+    pxy = do.make_encoder_pxy(pxy_seed)
+    real_save = torch.save
+
+    def prereq(tmp):
+        real_save(pxy, os.path.join(tmp, "encoder_pxy_50000.pt"))
+
+    for n in (1, steps):
+        batches = [sprites[i].clone() for i in range(n)]
+        g, recs = rh.run_script_loop("dSprites/rp.py", rh.dsprites_opt(B), batches, names, seed, prereq=prereq)
+        if n == 1:
+            probe_state("G1", g["generator"].state_dict(), out)
+            probe_state("D1", g["discriminator"].state_dict(), out)
+            probe_state("E1", g["encoder"].state_dict(), out)
+            probe_grads("gG1", g["generator"], out)
+            probe_grads("gE1", g["encoder"], out)
+    for k in names:
+        out[k] = np.array([r[k] for r in recs], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, f"dsprites_b{B}_s{steps}.npz"), **out)
+    print("dsprites golden:", {k: out[k] for k in names})
+
+
+MAKERS = {"dsprites": make_dsprites, "celeba": make_celeba, "celeba_affine": make_celeba_affine, "mnist": make_mnist, "mnist_affine": make_mnist_affine}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

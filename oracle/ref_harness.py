@@ -177,3 +177,9 @@ def mnist_opt(batch_size):
     """argparse defaults of MNIST/EAD-GAN_rpqmnxy.py:35-48 with n_epochs=1."""
     return argparse.Namespace(n_epochs=1, batch_size=batch_size, lr=0.0001, b1=0.5, b2=0.999, n_cpu=8, latent_dim=62, code_dim=7,
                               n_classes=10, img_size=32, channels=1, sample_interval=4000)
+
+
+def dsprites_opt(batch_size):
+    """argparse defaults of dSprites/rp.py:40-51 with n_epochs=1."""
+    return argparse.Namespace(n_epochs=1, batch_size=batch_size, lr=0.0001, b1=0.5, b2=0.999, n_cpu=8, latent_dim=200, code_dim=4, n_classes=3,
+                              img_size=64, channels=1, sample_interval=1000)

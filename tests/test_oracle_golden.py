@@ -98,3 +98,25 @@ def test_mnist_affine_functions_match_reference():
     (pred * torch.tensor(gold["w"])).sum().backward()
     np.testing.assert_allclose(rc.grad.numpy(), gold["d_real"], rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(tc.grad.numpy(), gold["d_trans"], rtol=1e-3, atol=1e-4)
+
+
+def test_dsprites_step_matches_reference():
+    from oracle import dsprites_oracle as do
+    gold = np.load(os.path.join(GOLDEN, "dsprites_b8_s3.npz"))
+    B, steps, seed = int(gold["B"]), int(gold["steps"]), int(gold["seed"])
+    torch.set_num_threads(8)
+    orc = do.DspritesOracle(seed=seed, pxy=do.make_encoder_pxy(int(gold["pxy_seed"])))
+    rng = np.random.RandomState(seed)
+    sprites = do.synthetic_sprites(B * steps, seed=int(gold["sprite_seed"])).view(steps, B, 64, 64)
+    names = ("d_loss", "g_loss", "info_loss", "affine_loss", "relative_cat_loss")
+    for i in range(steps):
+        out = orc.train_step(sprites[i], *do.draw_step_inputs(rng, B))
+        tol = (3e-6, 1e-3, 1e-2)[i]
+        for k in names:
+            assert abs(out[k] - gold[k][i]) < tol, (i, k, out[k], gold[k][i])
+        if i == 0:
+            check_probes("gG1", {k: v.grad for k, v in orc.G.items() if getattr(v, "grad", None) is not None}, gold, 1e-2, 1e-9, noise_floor=1e-8)
+            check_probes("gE1", {k: v.grad for k, v in orc.E.items() if getattr(v, "grad", None) is not None}, gold, 1e-2, 1e-9, noise_floor=1e-8)
+            check_probes("G1", orc.G, gold, 2e-3, 3e-4)
+            check_probes("D1", orc.D, gold, 2e-3, 3e-4)
+            check_probes("E1", orc.E, gold, 2e-3, 3e-4)
