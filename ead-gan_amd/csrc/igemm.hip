@@ -741,6 +741,29 @@ __global__ void pack_strided_kernel(const float* __restrict__ w, T* __restrict__
     }
 }
 
+// same with a decomposed column index: + (k / k_div) * s_khi + (k % k_div) * s_klo
+template <typename T>
+__global__ void pack_strided2_kernel(const float* __restrict__ w, T* __restrict__ wp, int N, int K, int Kpad, int n_div, long long s_hi,
+                                     long long s_lo, int k_div, long long s_khi, long long s_klo) {
+    const long long total = (long long)N * Kpad;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / Kpad), kk = (int)(i % Kpad);
+        float v = 0.f;
+        if (kk < K) v = w[(n / n_div) * s_hi + (n % n_div) * s_lo + (kk / k_div) * s_khi + (kk % k_div) * s_klo];
+        Elt<T>::st(wp + i, v);
+    }
+}
+extern "C" int eg_pack_strided2(int dtype, const float* w, void* wp, int N, int K, int Kpad, int n_div, long long s_hi, long long s_lo, int k_div,
+                                long long s_khi, long long s_klo, eg_stream_t s) {
+    EG_REQUIRE(w && wp && N > 0 && K > 0 && Kpad >= K && n_div > 0 && k_div > 0, "eg_pack_strided2: bad argument");
+    const long long total = (long long)N * Kpad;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (dtype == EG_F32) hipLaunchKernelGGL(pack_strided2_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (float*)wp, N, K, Kpad, n_div, s_hi, s_lo, k_div, s_khi, s_klo);
+    else hipLaunchKernelGGL(pack_strided2_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)wp, N, K, Kpad, n_div, s_hi, s_lo, k_div, s_khi, s_klo);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int eg_pack_strided(int dtype, const float* w, void* wp, int N, int K, int Kpad, int n_div, long long s_hi, long long s_lo,
                                long long s_k, eg_stream_t s) {
     EG_REQUIRE(w && wp && N > 0 && K > 0 && Kpad >= K && n_div > 0, "eg_pack_strided: bad argument");

@@ -1,0 +1,532 @@
+"""dSprites 64x64 stage-2 path of EAD-GAN on MI355X: drop-in ``Encoder_pxy`` / ``Discriminator`` / ``Generator`` / ``Encoder`` /
+``transformation_2D`` / ``mutual_info_loss`` / ``to_categorical`` (dSprites/rp.py:61-232), ``get_matrix`` / ``get_matrix_D`` /
+``affine_regularzier`` (dSprites/utils_rp.py), ``get_matrix_pxy_align`` (dSprites/utils_pxy.py:69-87) and the fused train-loop
+entry :class:`DspritesTrainer` (loop body rp.py:365-482).  torch modules are parameter containers only.
+"""
+from __future__ import annotations
+
+import argparse
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.utils import spectral_norm
+
+from . import ops
+from .celeba import _HipModule, _require_cuda, transformation_2D      # noqa: F401
+from .engine import ConvRec, Workspace, parse_dtype
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, EG_F32, OUT_NCHW_F32
+from .trunk import Head, TrunkEngine
+
+opt = argparse.Namespace(n_epochs=100, batch_size=128, lr=0.0001, b1=0.5, b2=0.999, n_cpu=8, latent_dim=200, code_dim=4, n_classes=3,
+                         img_size=64, channels=1, sample_interval=1000)           # argparse defaults rp.py:40-51
+TRUNK = (32, 32, 64, 64)
+
+
+def to_categorical(y, num_columns, device=None):
+    y = torch.as_tensor(np.asarray(y), dtype=torch.int64, device=device)
+    return torch.nn.functional.one_hot(y, num_columns).to(torch.float32)
+
+
+def _trunk(ch, sn, slope):
+    f = spectral_norm if sn else (lambda m: m)
+    return nn.Sequential(f(nn.Conv2d(ch, 32, 4, 2, 1)), nn.LeakyReLU(slope, inplace=True), f(nn.Conv2d(32, 32, 4, 2, 1)), nn.LeakyReLU(slope, inplace=True),
+                         f(nn.Conv2d(32, 64, 4, 2, 1)), nn.LeakyReLU(slope, inplace=True), f(nn.Conv2d(64, 64, 4, 2, 1)), nn.LeakyReLU(slope, inplace=True))
+
+
+# ================================================================================================
+# Encoder_pxy: frozen alignment encoder (forward only; its gradients are dead work in the reference)
+# ================================================================================================
+class _PxyEngine:
+    def __init__(self, mod: "Encoder_pxy", B, dtype):
+        self.mod, self.B, self.dtype = mod, B, dtype
+        dev = next(mod.parameters()).device
+        tdt = ops.torch_dtype(dtype)
+        self.ws = ws = Workspace.get(dev)
+        C, S = mod.channels, mod.img_size
+        self.C, self.S = C, S
+        self.k0 = C * 16
+        self.kp = ops.round_up(self.k0, 8)
+        self.l0 = ConvRec(dtype, B, S // 2, S // 2, self.kp, TRUNK[0], 1, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
+        self.mid = [ConvRec(dtype, B, S >> (i + 1), S >> (i + 1), TRUNK[i], TRUNK[i + 1], 4, 2, 1, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
+                    for i in range(3)]
+        self.nout = mod.fc1.weight.shape[0]
+        self.head = ConvRec(dtype, B, 4, 4, TRUNK[3], self.nout, 4, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
+        self.patches = torch.zeros(B * (S // 2) ** 2, self.kp, device=dev, dtype=tdt)
+        self.a = [torch.empty(B, S >> (i + 1), S >> (i + 1), TRUNK[i], device=dev, dtype=tdt) for i in range(4)]
+        self.out = torch.empty(B, self.nout, device=dev, dtype=torch.float32)
+        self.repack()
+
+    def repack(self):
+        cb = self.mod.conv_block
+        ops.pack_strided(self.dtype, cb[0].weight, self.l0.wp_fwd, TRUNK[0], self.k0, self.l0.Kpad_fwd, 1, self.k0, 0, 1)
+        for i in range(3):
+            self.mid[i].pack(cb[2 * (i + 1)].weight)
+        self.head.pack(self.mod.fc1.weight)          # Linear over the NCHW-flattened 4x4x64 map == 4x4 conv
+
+    def forward(self, img):
+        dt, B, cb = self.dtype, self.B, self.mod.conv_block
+        ops.im2col_img(dt, img, self.patches, B, self.C, self.S, self.S, 4, 2, 1, self.kp)
+        ops.conv_fwd(self.l0.c, dt, self.patches, self.l0.wp_fwd, self.a[0], ops.epilogue(bias=cb[0].bias, act=ACT_LRELU, slope=0.1))
+        for i in range(3):
+            ops.conv_fwd(self.mid[i].c, dt, self.a[i], self.mid[i].wp_fwd, self.a[i + 1], ops.epilogue(bias=cb[2 * (i + 1)].bias, act=ACT_LRELU, slope=0.1))
+        ops.dense_small_fwd(dt, self.a[3], self.head.wp_fwd, self.mod.fc1.bias, self.out, B, 16 * TRUNK[3], self.head.Kpad_fwd, self.nout)
+        return self.out
+
+
+class Encoder_pxy(_HipModule):
+    """Drop-in for rp.py:61-87 (inference only on this path: the reference loads ``encoder_pxy_50000.pt`` and freezes it)."""
+
+    def __init__(self, img_size=None, channels=None, n_out=3, dtype="f32"):
+        super().__init__()
+        g = lambda v, name: getattr(opt, name) if v is None else v
+        self.img_size, self.channels = g(img_size, "img_size"), g(channels, "channels")
+        self.conv_block = _trunk(self.channels, False, 0.1)
+        self.fc1 = nn.Linear(1024, n_out)
+        self._init_engine_state(dtype)
+
+    @property
+    def arena(self):                 # frozen: parameters stay where they are, no gradient arena
+        return None
+
+    def engine(self, B) -> _PxyEngine:
+        key = (B, self.compute_dtype)
+        if key not in self._engines:
+            _require_cuda(next(self.parameters()))
+            self._engines[key] = _PxyEngine(self, B, self.compute_dtype)
+        return self._engines[key]
+
+    def forward(self, img):
+        _require_cuda(img)
+        return self.engine(img.shape[0]).forward(img.float().contiguous()).clone()
+
+
+# ================================================================================================
+# Discriminator / Encoder (spectrally-normalised trunks with hidden FC layers)
+# ================================================================================================
+class _TrunkModule(_HipModule):
+    NT = 3
+
+    def _convs(self):
+        cb = self.conv_block
+        return [cb[i] for i in (0, 2, 4, 6)], [f"conv_block.{i}" for i in (0, 2, 4, 6)]
+
+    def engine(self, B) -> TrunkEngine:
+        self.arena
+        key = (B, self.compute_dtype)
+        if key not in self._engines:
+            convs, names = self._convs()
+            fcs, fnames = self._fcs()
+            self._engines[key] = TrunkEngine(self, convs, names, [None] * 4, [None] * 4, self._heads(), self.channels, self.img_size, 4, 0.2, B,
+                                             self.compute_dtype, self.NT, fcs=fcs, fc_names=fnames)
+        return self._engines[key]
+
+
+class Discriminator(_TrunkModule):
+    """Drop-in for rp.py:90-119: SN trunk -> SN-Linear(1024,128)+LeakyReLU -> Linear(128,1) -> sigmoid."""
+
+    def __init__(self, img_size=None, channels=None, dtype="f32"):
+        super().__init__()
+        g = lambda v, name: getattr(opt, name) if v is None else v
+        self.img_size, self.channels = g(img_size, "img_size"), g(channels, "channels")
+        self.conv_block = _trunk(self.channels, True, 0.2)
+        self.fc1 = nn.Sequential(spectral_norm(nn.Linear(1024, 128)), nn.LeakyReLU(0.2, inplace=True))
+        self.fc2 = nn.Linear(128, 1)
+        self._init_engine_state(dtype)
+        self._next_tape = 0
+
+    def _fcs(self):
+        return [self.fc1[0]], ["fc1.0"]
+
+    def _heads(self):
+        return [Head("fc2", self.fc2, sn=False)]
+
+    def forward(self, img):
+        from .mnist import _TrunkFn
+        _require_cuda(img)
+        eng = self.engine(img.shape[0])
+        t = self._next_tape
+        self._next_tape = (t + 1) % self.NT
+        (logit,) = _TrunkFn.apply(eng, t, self.training, ("fc2",), img.float().contiguous(), *list(self.parameters()))
+        return torch.sigmoid(logit)
+
+
+class Encoder(_TrunkModule):
+    """Drop-in for rp.py:160-194: SN trunk -> 2 x (SN-Linear + LeakyReLU) -> softmax(SN-Linear(128,n_classes)), SN-Linear(128,code_dim)."""
+
+    def __init__(self, code_dim=None, n_classes=None, img_size=None, channels=None, dtype="f32"):
+        super().__init__()
+        g = lambda v, name: getattr(opt, name) if v is None else v
+        self.code_dim, self.n_classes = g(code_dim, "code_dim"), g(n_classes, "n_classes")
+        self.img_size, self.channels = g(img_size, "img_size"), g(channels, "channels")
+        self.conv_block = _trunk(self.channels, True, 0.2)
+        self.fc1 = nn.Sequential(spectral_norm(nn.Linear(1024, 128)), nn.LeakyReLU(0.2, inplace=True))
+        self.fc2 = nn.Sequential(spectral_norm(nn.Linear(128, 128)), nn.LeakyReLU(0.2, inplace=True))
+        self.cat_layer = nn.Sequential(spectral_norm(nn.Linear(128, self.n_classes)), nn.Softmax(dim=1))
+        self.cont_layer = nn.Sequential(spectral_norm(nn.Linear(128, self.code_dim)))
+        self._init_engine_state(dtype)
+        self._next_tape = 0
+
+    def _fcs(self):
+        return [self.fc1[0], self.fc2[0]], ["fc1.0", "fc2.0"]
+
+    def _heads(self):
+        return [Head("cat_layer.0", self.cat_layer[0], sn=True), Head("cont_layer.0", self.cont_layer[0], sn=True)]
+
+    def forward(self, img):
+        from .mnist import _TrunkFn
+        _require_cuda(img)
+        eng = self.engine(img.shape[0])
+        t = self._next_tape
+        self._next_tape = (t + 1) % self.NT
+        cat, cont = _TrunkFn.apply(eng, t, self.training, ("cat_layer.0", "cont_layer.0"), img.float().contiguous(), *list(self.parameters()))
+        return torch.softmax(cat, dim=1), cont
+
+
+# ================================================================================================
+# Generator: Linear(7,128)+ReLU -> Linear(128,1024)+ReLU -> view[B,64,4,4] -> 3 x (ConvT 4x4 s2 + BN + ReLU) -> ConvT(64,1) -> sigmoid
+# ================================================================================================
+class _GenEngine:
+    def __init__(self, gen: "Generator", B, dtype):
+        self.gen, self.B, self.dtype = gen, B, dtype
+        dev = gen.arena.flat.device
+        tdt = ops.torch_dtype(dtype)
+        self.ws = ws = Workspace.get(dev)
+        self.cin = gen.n_classes + gen.code_dim
+        self.cpad = ops.round_up(self.cin, 8)
+        self.CH = gen.channels
+        self.f1 = ConvRec(dtype, B, 1, 1, self.cpad, 128, 1, 1, 0, device=dev, want_bwd=False, ws=ws)
+        self.f2 = ConvRec(dtype, B, 1, 1, 128, 1024, 1, 1, 0, device=dev, ws=ws)
+        self.mid = [ConvRec(dtype, B, 8 << i, 8 << i, 64, 64, 4, 2, 1, device=dev, ws=ws) for i in range(3)]
+        self.l4 = ConvRec(dtype, B, 64, 64, self.CH, 64, 4, 2, 1, device=dev, want_fwd=False, want_wgrad=False, ws=ws)
+        self.k0 = self.CH * 16
+        self.kp = ops.round_up(self.k0, 8)
+        self.l4p = ConvRec(dtype, B, 32, 32, self.kp, 64, 1, 1, 0, device=dev, want_bwd=False, ws=ws)
+        e = lambda *s, dt=tdt: torch.empty(s, device=dev, dtype=dt)
+        f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
+        self.inp = e(B, self.cpad)
+        self.a1 = e(B, 128)
+        self.bias2_perm, self.gb2_perm = f(1024), f(1024)
+        self.h = e(B, 4, 4, 64)
+        self.z = [e(B, 8 << i, 8 << i, 64) for i in range(3)]
+        self.a = [torch.empty_like(t) for t in self.z]
+        self.mean = [f(64) for _ in range(3)]
+        self.invstd = [f(64) for _ in range(3)]
+        self.img = f(B, self.CH, 64, 64)
+        self.dimg_z = torch.empty_like(self.img)
+        self.patches = torch.zeros(B * 32 * 32, self.kp, device=dev, dtype=tdt)
+        self.da = [torch.empty_like(t) for t in self.z]
+        self.dz = [torch.empty_like(t) for t in self.z]
+        self.dh = torch.empty_like(self.h)
+        self.dz1 = torch.empty_like(self.a1)
+        for i in range(3):
+            ws.need_small(ops.bn_ws_floats(B * (8 << i) ** 2, 64))
+        ws.need_small(ops.bias_grad_ws_floats(B, 1024))
+        ws.need_small(B * self.CH)
+        ws.need_sums(128)
+        self.repack()
+
+    def repack(self):
+        dt, g = self.dtype, self.gen
+        cb = g.conv_block
+        w1, w2 = g.fc1[0].weight, g.fc2[0].weight
+        ops.pack_strided(dt, w1, self.f1.wp_fwd, 128, self.cin, self.f1.Kpad_fwd, 1, self.cin, 0, 1)
+        # fc2 rows in NHWC order n' = hw*64 + c  <-  master row f = c*16 + hw (view [B,64,4,4])
+        ops.pack_strided(dt, w2, self.f2.wp_fwd, 1024, 128, self.f2.Kpad_fwd, 64, 128, 16 * 128, 1)
+        # backward panel [k][n'] = W2[f(n')][k]
+        ops.pack_strided2(dt, w2, self.f2.wp_bwd, 128, 1024, ops.round_up(1024, ops.bk(dt)), 1, 1, 0, 64, 128, 16 * 128)
+        ops.pack_strided(EG_F32, g.fc2[0].bias, self.bias2_perm, 1024, 1, 1, 64, 1, 16, 0)
+        for i, idx in enumerate((0, 3, 6)):
+            self.mid[i].pack(cb[idx].weight)
+        self.l4.pack(cb[9].weight)
+        ops.pack_strided(dt, cb[9].weight, self.l4p.wp_fwd, 64, self.k0, self.l4p.Kpad_fwd, 1, self.k0, 0, 1)
+
+    def forward(self, labels, code):
+        """z_c = cat(one-hot labels, code)  (rp.py:404-405)"""
+        dt, B, g, ws = self.dtype, self.B, self.gen, self.ws
+        cb = g.conv_block
+        ops.concat_cast(dt, labels, code, None, self.inp, B, self.cpad)
+        ops.conv_fwd(self.f1.c, dt, self.inp, self.f1.wp_fwd, self.a1, ops.epilogue(bias=g.fc1[0].bias, act=ACT_RELU))
+        ops.conv_fwd(self.f2.c, dt, self.a1, self.f2.wp_fwd, self.h, ops.epilogue(bias=self.bias2_perm, act=ACT_RELU))
+        x = self.h
+        for i, idx in enumerate((0, 3, 6)):
+            r = self.mid[i]
+            ops.conv_bwd_data(r.c, dt, x, r.wp_bwd, self.z[i], ops.epilogue(bias=cb[idx].bias))
+            bn = cb[idx + 1]
+            ops.bn_fwd_train(dt, self.z[i], self.a[i], B * (8 << i) ** 2, 64, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                             bn.num_batches_tracked, self.mean[i], self.invstd[i], ws.small, ACT_RELU)
+            x = self.a[i]
+        ops.conv_bwd_data(self.l4.c, dt, x, self.l4.wp_bwd, self.img, ops.epilogue(bias=cb[9].bias, act=ACT_SIGMOID, out_mode=OUT_NCHW_F32))
+        return self.img
+
+    def backward(self, dimg, grad):
+        dt, B, g, ws = self.dtype, self.B, self.gen, self.ws
+        cb = g.conv_block
+        gof = lambda name: g.arena.grad_of(name, grad)
+        ops.act_grad_mul_bias_nchw(dimg, self.img, self.dimg_z, B, self.CH, 64 * 64, ACT_SIGMOID, 0.0, ws.small, gof("conv_block.9.bias"))
+        ops.im2col_img(dt, self.dimg_z, self.patches, B, self.CH, 64, 64, 4, 2, 1, self.kp)
+        ns = ops.conv_wgrad(self.l4p.c, dt, self.patches, self.a[2], ws.slab)
+        ops.wgrad_reduce_perm(ws.slab, ns, 64, 64, self.kp, 1, gof("conv_block.9.weight"), 0, 0, self.k0)
+        ops.conv_fwd(self.l4p.c, dt, self.patches, self.l4p.wp_fwd, self.da[2], None)
+        for i, idx in ((2, 6), (1, 3), (0, 0)):
+            r = self.mid[i]
+            bn = cb[idx + 1]
+            M = B * (8 << i) ** 2
+            ops.bn_bwd(dt, self.z[i], self.da[i], self.dz[i], M, 64, bn.weight, bn.bias, self.mean[i], self.invstd[i], ACT_RELU, 0.0,
+                       gof(f"conv_block.{idx + 1}.weight"), gof(f"conv_block.{idx + 1}.bias"), ws.sums, ws.small)
+            x_in = self.a[i - 1] if i > 0 else self.h
+            ns = ops.conv_wgrad(r.c, dt, self.dz[i], x_in, ws.slab)
+            ops.wgrad_reduce(ws.slab, ns, 64, 64, 64, 16, gof(f"conv_block.{idx}.weight"))
+            ops.bias_grad(dt, self.dz[i], M, 64, ws.small, gof(f"conv_block.{idx}.bias"))
+            if i > 0:
+                ops.conv_fwd(r.c, dt, self.dz[i], r.wp_fwd, self.da[i - 1], None)
+            else:                                    # into the ReLU output of fc2: mask fused into the epilogue
+                ops.conv_fwd(r.c, dt, self.dz[i], r.wp_fwd, self.dh, ops.epilogue(mask=self.h, mask_act=ACT_RELU))
+        # fc2: dW[f][k] = sum_b dh[b][n'(f)] a1[b][k]
+        ns = ops.conv_wgrad(self.f2.c, dt, self.a1, self.dh, ws.slab)
+        ops.wgrad_reduce_perm(ws.slab, ns, 1024, 1024, 128, 1, gof("fc2.0.weight"), 64, 16, 0)
+        ops.fill_f32(self.gb2_perm)
+        ops.bias_grad(dt, self.dh, B, 1024, ws.small, self.gb2_perm)
+        ops.gather_add(gof("fc2.0.bias"), self.gb2_perm, 1024, 16, 1, 64)
+        ops.conv_bwd_data(self.f2.c, dt, self.dh, self.f2.wp_bwd, self.dz1, ops.epilogue(mask=self.a1, mask_act=ACT_RELU))
+        # fc1
+        ns = ops.conv_wgrad(self.f1.c, dt, self.inp, self.dz1, ws.slab)
+        ops.wgrad_reduce_perm(ws.slab, ns, 128, 128, self.cpad, 1, gof("fc1.0.weight"), 0, 0, self.cin)
+        ops.bias_grad(dt, self.dz1, B, 128, ws.small, gof("fc1.0.bias"))
+
+
+class Generator(_HipModule):
+    """Drop-in for rp.py:123-157; ``forward(z_c)`` with z_c = cat(one-hot label, code)."""
+
+    def __init__(self, code_dim=None, n_classes=None, channels=None, dtype="f32"):
+        super().__init__()
+        g = lambda v, name: getattr(opt, name) if v is None else v
+        self.code_dim, self.n_classes, self.channels = g(code_dim, "code_dim"), g(n_classes, "n_classes"), g(channels, "channels")
+        self.img_size = 64
+        self.conv_block = nn.Sequential(
+            nn.ConvTranspose2d(64, 64, 4, 2, 1), nn.BatchNorm2d(64), nn.ReLU(), nn.ConvTranspose2d(64, 64, 4, 2, 1), nn.BatchNorm2d(64), nn.ReLU(),
+            nn.ConvTranspose2d(64, 64, 4, 2, 1), nn.BatchNorm2d(64), nn.ReLU(), nn.ConvTranspose2d(64, self.channels, 4, 2, 1))
+        self.fc1 = nn.Sequential(nn.Linear(self.n_classes + self.code_dim, 128), nn.ReLU())
+        self.fc2 = nn.Sequential(nn.Linear(128, 64 * 4 * 4), nn.ReLU())
+        self._init_engine_state(dtype)
+
+    def engine(self, B) -> _GenEngine:
+        self.arena
+        key = (B, self.compute_dtype)
+        if key not in self._engines:
+            self._engines[key] = _GenEngine(self, B, self.compute_dtype)
+        return self._engines[key]
+
+    def forward(self, z_c):
+        _require_cuda(z_c)
+        if not self.training:
+            raise NotImplementedError("eval-mode generator (running-stat BN) is outside the training hot path")
+        z_c = z_c.float().contiguous()
+        eng = self.engine(z_c.shape[0])
+        return _GenFn.apply(eng, z_c[:, :self.n_classes].contiguous(), z_c[:, self.n_classes:].contiguous(), *list(self.parameters()))
+
+
+class _GenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, labels, code, *params):
+        ctx.eng = eng
+        return eng.forward(labels, code).clone()
+
+    @staticmethod
+    def backward(ctx, dimg):
+        eng = ctx.eng
+        scratch = torch.zeros_like(eng.gen.arena.grad)
+        eng.backward(dimg.contiguous(), scratch)
+        grads = [scratch[off:off + k].view(p.shape) for p, (off, k) in zip(eng.gen.parameters(), eng.gen.arena.slices.values())]
+        return (None, None, None, *grads)
+
+
+# ================================================================================================
+# affine utilities / losses
+# ================================================================================================
+def _theta_to_A(theta):
+    B = theta.shape[0]
+    A = torch.zeros(B, 3, 3, device=theta.device, dtype=torch.float32)
+    A[:, :2] = theta
+    A[:, 2, 2] = 1.0
+    return A
+
+
+def get_matrix(code_input_raw):
+    """[B,>=4] codes -> [B,3,3] = R(theta) Z(p,p) T(x,y)  (utils_rp.py:94-115)."""
+    _require_cuda(code_input_raw)
+    c = code_input_raw.float().contiguous()
+    theta = torch.empty(c.shape[0], 2, 3, device=c.device)
+    ops.theta_rp(c, c.shape[1], c.shape[0], theta)
+    return _theta_to_A(theta)
+
+
+get_matrix_D = get_matrix        # identical formulas (utils_rp.py:38-59)
+
+
+def get_matrix_pxy_align(code_input_raw):
+    """translation-only alignment matrix T(.1 c1, .1 c2)  (utils_pxy.py:69-87)."""
+    _require_cuda(code_input_raw)
+    c = code_input_raw.float().contiguous()
+    theta = torch.empty(c.shape[0], 2, 3, device=c.device)
+    ops.theta_pxy_align_inv(c, c.shape[1], c.shape[0], theta)
+    theta[:, :, 2] = -theta[:, :, 2]             # the kernel produces the inverse the loop actually uses (rp.py:376)
+    return _theta_to_A(theta)
+
+
+class _AffineRegFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, real_code, trans_code):
+        B, ld = real_code.shape
+        pred = torch.empty(B, 4, device=real_code.device)
+        ops.loss_affine_rp(real_code, trans_code, ld, 0, B, torch.zeros(B, 4, device=real_code.device), 4, 1.0, None, None, None, pred)
+        ctx.save_for_backward(real_code, trans_code, pred)
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        real_code, trans_code, pred = ctx.saved_tensors
+        B, ld = real_code.shape
+        tgt = (pred - dpred.float() * (4.0 * B / 2.0)).contiguous()
+        d_real, d_trans = torch.empty_like(real_code), torch.empty_like(trans_code)
+        ops.loss_affine_rp(real_code, trans_code, ld, 0, B, tgt, 4, 1.0, None, d_real, d_trans, None)
+        return d_real, d_trans
+
+
+def affine_regularzier(real_code, trans_code):
+    """closed-form relative-transform recovery over the first 4 codes (utils_rp.py:118-147)."""
+    _require_cuda(real_code)
+    return _AffineRegFn.apply(real_code.float().contiguous(), trans_code.float().contiguous())
+
+
+def mutual_info_loss(c_given_x, c):
+    """rp.py:225-232 on probabilities (eager torch ops on [B,n] tensors; the fused trainer uses eg_loss_mutual_info on logits)."""
+    eps = 1e-8
+    return torch.mean(-torch.sum(torch.log(c_given_x + eps) * c, dim=1)) + torch.mean(-torch.sum(torch.log(c + eps) * c, dim=1))
+
+
+# ================================================================================================
+# fused train-loop entry
+# ================================================================================================
+class DspritesTrainer:
+    """One call == one iteration of dSprites/rp.py:365-482: D step (Adam lr 2e-4), then the joint info + affine + adversarial-G +
+    relative-category step over G+E (Adam lr 1e-4).  optimizer_G of the reference is never stepped and is not created.
+    Dead work removed: Encoder_pxy backward, the second (identical) alignment pass, D weight gradients in the joint step."""
+
+    def __init__(self, encoder_pxy, generator, discriminator, encoder, batch_size, dtype="f32", allreduce=None, lrs=(2e-4, 1e-4), betas=(0.5, 0.999)):
+        self.P, self.G, self.D, self.E, self.B = encoder_pxy, generator, discriminator, encoder, batch_size
+        dt = parse_dtype(dtype)
+        for m in (encoder_pxy, generator, discriminator, encoder):
+            m.set_compute_dtype(dt)
+        B = batch_size
+        self.pe, self.ge, self.de, self.ee = encoder_pxy.engine(B), generator.engine(B), discriminator.engine(B), encoder.engine(B)
+        dev = generator.arena.flat.device
+        self.allreduce, self.lr, self.betas = allreduce, lrs, betas
+        ga, da, ea = generator.arena, discriminator.arena, encoder.arena
+        z = lambda *n: torch.zeros(*n, device=dev, dtype=torch.float32)
+        self.mD, self.vD = z(da.numel), z(da.numel)
+        self.miG, self.viG, self.miE, self.viE = z(ga.numel), z(ga.numel), z(ea.numel), z(ea.numel)
+        self.steps = torch.zeros(2, device=dev, dtype=torch.int32)
+        self.losses = z(8)                                    # d, g, info, affine, relative_cat
+        C = generator.channels
+        self.nc, self.cd = generator.n_classes, generator.code_dim
+        self.img = z(B, C, 64, 64)
+        self.theta = z(B, 2, 3)
+        self.align, self.trans1, self.trans2 = z(B, C, 64, 64), z(B, C, 64, 64), z(B, C, 64, 64)
+        self.dimg = z(B, C, 64, 64)
+        self.dout_d = z(2 * B, 1)
+        self.d_cat, self.d_cont = z(3 * B, self.nc), z(3 * B, self.cd)
+        self.code1, self.code2 = z(B, self.cd), z(B, self.cd)
+        self.onehot1, self.onehot2 = z(B, self.nc), z(B, self.nc)
+        self.graph = None
+
+    def _adam(self, arena, m, v, lr, slot, tick):
+        ops.adam_step(arena.flat, arena.grad, m, v, arena.numel, lr, self.betas[0], self.betas[1], 1e-8, self.steps[slot:slot + 1], tick)
+
+    def _step_body(self):
+        B, nc, cd = self.B, self.nc, self.cd
+        pe, ge, de, ee = self.pe, self.ge, self.de, self.ee
+        ga, da, ea = self.G.arena, self.D.arena, self.E.arena
+        C = self.G.channels
+        L = self.losses
+        ops.fill_f32(L)
+        # alignment (rp.py:374-377): align = warp(img, inverse(T(x,y))[:, :2])
+        pcode = pe.forward(self.img)
+        ops.theta_pxy_align_inv(pcode, pcode.shape[1], B, self.theta)
+        ops.warp_affine(self.img, self.theta, self.align, B, C, 64, 64)
+        ops.theta_rp(self.code1, cd, B, self.theta)
+        ops.warp_affine(self.align, self.theta, self.trans1, B, C, 64, 64)                   # :396-400
+        # ---- D step (:404-419): D(trans) then D(gen.detach()) ----
+        gen = ge.forward(self.onehot1, self.code1)
+        ops.fill_f32(da.grad)
+        out = de.forward([self.trans1, gen])["fc2"]
+        ops.loss_bce_sigmoid(out[:B], 1, 0, B, 1.0, 0.5, L[0:1], self.dout_d[:B])
+        ops.loss_bce_sigmoid(out[B:], 1, 0, B, 0.0, 0.5, L[0:1], self.dout_d[B:])
+        de.backward(0, 2, {"fc2": self.dout_d}, da.grad)
+        if self.allreduce is not None:
+            self.allreduce(da.grad)
+        self._adam(da, self.mD, self.vD, self.lr[0], 0, True)
+        de.repack()
+        # ---- joint step (:424-482) ----
+        ops.fill_f32(ga.grad)
+        ops.fill_f32(ea.grad)
+        gen = ge.forward(self.onehot2, self.code2)
+        ops.theta_rp(self.code2, cd, B, self.theta)
+        ops.warp_affine(self.align, self.theta, self.trans2, B, C, 64, 64)
+        eo = ee.forward([gen, self.align, self.trans2])
+        cat, cont = eo["cat_layer.0"], eo["cont_layer.0"]
+        g_fake = de.forward([gen])["fc2"]
+        ops.loss_bce_sigmoid(g_fake, 1, 0, B, 1.0, 1.0, L[1:2], self.dout_d[:B])
+        dimg_d = de.backward(0, 1, {"fc2": self.dout_d[:B]}, da.grad, need_wgrad=False, need_dimg=True)
+        ops.fill_f32(self.d_cat)
+        ops.loss_mutual_info(cat[:B], nc, 0, nc, B, self.onehot2, nc, 0, False, 1.0, L[2:3], self.d_cat[:B])
+        ops.loss_mse(cont[:B], cd, 0, cd, B, self.code2, cd, 0.0, 1.0, L[2:3], self.d_cont[:B])
+        ops.loss_affine_rp(cont[B:2 * B], cont[2 * B:], cd, 0, B, self.code2, cd, 1.0, L[3:4], self.d_cont[B:2 * B], self.d_cont[2 * B:])
+        ops.loss_mutual_info(cat[2 * B:], nc, 0, nc, B, cat[B:2 * B], nc, 0, True, 1.0, L[4:5], self.d_cat[2 * B:])
+        dimg_e = ee.backward(0, 3, {"cat_layer.0": self.d_cat, "cont_layer.0": self.d_cont}, ea.grad, need_dimg=True)
+        ops.add_f32(self.dimg, dimg_e, dimg_d)
+        pending = self.allreduce.start(ea.grad) if (self.allreduce is not None and hasattr(self.allreduce, "start")) else None
+        ge.backward(self.dimg, ga.grad)
+        if self.allreduce is not None:
+            self.allreduce(ga.grad)
+            if pending is not None:
+                self.allreduce.finish(pending)
+            elif not hasattr(self.allreduce, "start"):
+                self.allreduce(ea.grad)
+        self._adam(ga, self.miG, self.viG, self.lr[1], 1, True)
+        self._adam(ea, self.miE, self.viE, self.lr[1], 1, False)
+        ge.repack()
+        ee.repack()
+
+    def load_inputs(self, img_u8, code1, labels1, code2, labels2):
+        """img_u8: uint8 [B,64,64] sprites (or float [B,C,64,64]); codes [B,code_dim]; labels int64 [B]."""
+        if img_u8.dtype == torch.uint8:
+            ops.u8_to_f32(img_u8.contiguous(), self.img)
+        else:
+            self.img.copy_(img_u8.reshape(self.img.shape))
+        self.code1.copy_(code1)
+        self.code2.copy_(code2)
+        for oh, lab in ((self.onehot1, labels1), (self.onehot2, labels2)):
+            oh.zero_()
+            oh.scatter_(1, lab.view(-1, 1), 1.0)
+
+    def capture(self, warmup=False):
+        if warmup:
+            self._step_body()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._step_body()
+        return self
+
+    def step_resident(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._step_body()
+        return self.losses
+
+    def train_step(self, img_u8, code1, labels1, code2, labels2):
+        self.load_inputs(img_u8, code1, labels1, code2, labels2)
+        l = self.step_resident().tolist()
+        return dict(d_loss=l[0], g_loss=l[1], info_loss=l[2], affine_loss=l[3], relative_cat_loss=l[4])

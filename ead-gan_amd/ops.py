@@ -70,6 +70,10 @@ def pack_strided(dtype, w, wp, N, K, Kpad, n_div, s_hi, s_lo, s_k):
     lib().call("eg_pack_strided", dtype, _p(w), _p(wp), N, K, Kpad, n_div, s_hi, s_lo, s_k, _stream())
 
 
+def pack_strided2(dtype, w, wp, N, K, Kpad, n_div, s_hi, s_lo, k_div, s_khi, s_klo):
+    lib().call("eg_pack_strided2", dtype, _p(w), _p(wp), N, K, Kpad, n_div, s_hi, s_lo, k_div, s_khi, s_klo, _stream())
+
+
 # Optional launch recorder (bench.py's roofline pass): when set to a list, every implicit-GEMM launch is bracketed by HIP
 # events on the launch stream and appends (kernel label, algorithmic FLOPs, start event, end event, shape string).
 # Never set on the training path.

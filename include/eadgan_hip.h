@@ -124,6 +124,10 @@ int eg_wgrad_reduce_rank1(const float* slab, int nsplit, int n_slab, int n_rows,
 int eg_pack_strided(int dtype, const float* w, void* wp, int N, int K, int Kpad, int n_div, long long s_hi,
                     long long s_lo, long long s_k, eg_stream_t s);
 
+/* wp[n][k] = w[(n / n_div) * s_hi + (n % n_div) * s_lo + (k / k_div) * s_khi + (k % k_div) * s_klo]  (row AND column permuted) */
+int eg_pack_strided2(int dtype, const float* w, void* wp, int N, int K, int Kpad, int n_div, long long s_hi, long long s_lo,
+                     int k_div, long long s_khi, long long s_klo, eg_stream_t s);
+
 /* --- image-side (1..4 channel, NCHW fp32) convolution and its weight gradient ---------------------
  * first Discriminator/Encoder conv (celebA/EAD-GAN_celebA.py:110, dSprites/rp.py:95, MNIST/EAD-GAN_rpqmnxy.py:107)
  * and input gradient / weight gradient of the Generator's last ConvTranspose2d (celebA/EAD-GAN_celebA.py:90) */
