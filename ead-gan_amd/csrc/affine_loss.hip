@@ -462,3 +462,83 @@ extern "C" int eg_loss_mutual_info(const float* o, int ld, int c0, int n, int B,
     EG_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// colored dSprites (colored_dSprites/rp_color.py:368-394,415-424; utils_rp_color.py:38-75,100-139; utils_pxy.py:48-57)
+// ------------------------------------------------------------------------------------------------------------------------
+// out[b][c][hw] = sprite_u8[b][hw] * gain[b][c]
+__global__ void u8_colorize_kernel(const unsigned char* __restrict__ sp, const float* __restrict__ gain, float* __restrict__ out, int B, int C, int HW) {
+    const size_t n = (size_t)B * C * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int hw = (int)(i % HW);
+        const size_t bc = i / HW;
+        const int b = (int)(bc / C);
+        out[i] = (float)sp[(size_t)b * HW + hw] * gain[bc];
+    }
+}
+extern "C" int eg_u8_colorize(const unsigned char* sprites, const float* gain, float* out, int B, int C, int HW, eg_stream_t s) {
+    EG_REQUIRE(sprites && gain && out, "eg_u8_colorize: null pointer");
+    const size_t n = (size_t)B * C * HW;
+    hipLaunchKernelGGL(u8_colorize_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)s, sprites, gain, out, B, C, HW);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// out[b][c][hw] = in[b][c][hw] * g  or  / g,  g = code[b][c0 + c] * factor + 1
+__global__ void color_scale_kernel(const float* __restrict__ in, const float* __restrict__ code, int ldc, int c0, float factor, int divide,
+                                   float* __restrict__ out, int B, int C, int HW) {
+    const size_t n = (size_t)B * C * HW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t bc = i / HW;
+        const int b = (int)(bc / C), c = (int)(bc % C);
+        const float g = code[(size_t)b * ldc + c0 + c] * factor + 1.f;
+        out[i] = divide ? in[i] / g : in[i] * g;
+    }
+}
+extern "C" int eg_color_scale(const float* in, const float* code, int ldc, int c0, float factor, int divide, float* out, int B, int C, int HW,
+                              eg_stream_t s) {
+    EG_REQUIRE(in && code && out, "eg_color_scale: null pointer");
+    const size_t n = (size_t)B * C * HW;
+    hipLaunchKernelGGL(color_scale_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, (hipStream_t)s, in, code, ldc, c0, factor, divide, out, B, C, HW);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// affine (4 codes, as dSprites) + colour (3 codes): relative gain = (t*.5+1)/(r*.5+1) -> latent (g-1)/.5 ; MSE over 7 values
+__global__ void affine_reg_rp_color_kernel(const float* __restrict__ o_real, const float* __restrict__ o_trans, int ld, int c0, int B,
+                                           const float* __restrict__ code, int ldc, float scale, float* loss, float* __restrict__ d_real,
+                                           float* __restrict__ d_trans, float* __restrict__ pred_out) {
+    __shared__ float sm[16];
+    float acc = 0.f;
+    const float gs = 2.f * scale / (float)(B * 7);
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        Dual<14> rc[7], tc[7], out[7];
+        for (int i = 0; i < 7; ++i) {
+            rc[i] = dvar<14>(o_real[(size_t)b * ld + c0 + i], i);
+            tc[i] = dvar<14>(o_trans[(size_t)b * ld + c0 + i], 7 + i);
+        }
+        regularizer_rp<Dual<14>>(rc, tc, out);
+        for (int j = 0; j < 3; ++j) out[4 + j] = ((tc[4 + j] * 0.5f + 1.f) / (rc[4 + j] * 0.5f + 1.f) - 1.f) / 0.5f;
+        float gr[14];
+        for (int i = 0; i < 14; ++i) gr[i] = 0.f;
+        for (int j = 0; j < 7; ++j) {
+            const float d = out[j].v - code[(size_t)b * ldc + j];
+            acc += d * d;
+            if (pred_out) pred_out[(size_t)b * 7 + j] = out[j].v;
+            for (int i = 0; i < 14; ++i) gr[i] += gs * d * out[j].d[i];
+        }
+        if (d_real && d_trans) {
+            for (int j = 0; j < ld; ++j) { d_real[(size_t)b * ld + j] = 0.f; d_trans[(size_t)b * ld + j] = 0.f; }
+            for (int i = 0; i < 7; ++i) { d_real[(size_t)b * ld + c0 + i] = gr[i]; d_trans[(size_t)b * ld + c0 + i] = gr[7 + i]; }
+        }
+    }
+    const float tot = block_sum(acc, sm);
+    if (threadIdx.x == 0 && loss) loss[0] += scale * tot / (float)(B * 7);
+}
+extern "C" int eg_loss_affine_rp_color(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc, float scale,
+                                       float* loss, float* d_real, float* d_trans, float* pred_out, eg_stream_t s) {
+    EG_REQUIRE(o_real && o_trans && code && B > 0, "eg_loss_affine_rp_color: bad argument");
+    hipLaunchKernelGGL(affine_reg_rp_color_kernel, dim3(1), dim3(128), 0, (hipStream_t)s, o_real, o_trans, ld, c0, B, code, ldc, scale, loss, d_real, d_trans, pred_out);
+    EG_LAUNCH_CHECK();
+    return 0;
+}

@@ -450,12 +450,8 @@ class DspritesTrainer:
         C = self.G.channels
         L = self.losses
         ops.fill_f32(L)
-        # alignment (rp.py:374-377): align = warp(img, inverse(T(x,y))[:, :2])
-        pcode = pe.forward(self.img)
-        ops.theta_pxy_align_inv(pcode, pcode.shape[1], B, self.theta)
-        ops.warp_affine(self.img, self.theta, self.align, B, C, 64, 64)
-        ops.theta_rp(self.code1, cd, B, self.theta)
-        ops.warp_affine(self.align, self.theta, self.trans1, B, C, 64, 64)                   # :396-400
+        self._align()                                                                        # :374-377
+        self._transform(self.code1, self.trans1)                                             # :396-400
         # ---- D step (:404-419): D(trans) then D(gen.detach()) ----
         gen = ge.forward(self.onehot1, self.code1)
         ops.fill_f32(da.grad)
@@ -471,8 +467,7 @@ class DspritesTrainer:
         ops.fill_f32(ga.grad)
         ops.fill_f32(ea.grad)
         gen = ge.forward(self.onehot2, self.code2)
-        ops.theta_rp(self.code2, cd, B, self.theta)
-        ops.warp_affine(self.align, self.theta, self.trans2, B, C, 64, 64)
+        self._transform(self.code2, self.trans2)
         eo = ee.forward([gen, self.align, self.trans2])
         cat, cont = eo["cat_layer.0"], eo["cont_layer.0"]
         g_fake = de.forward([gen])["fc2"]
@@ -481,7 +476,7 @@ class DspritesTrainer:
         ops.fill_f32(self.d_cat)
         ops.loss_mutual_info(cat[:B], nc, 0, nc, B, self.onehot2, nc, 0, False, 1.0, L[2:3], self.d_cat[:B])
         ops.loss_mse(cont[:B], cd, 0, cd, B, self.code2, cd, 0.0, 1.0, L[2:3], self.d_cont[:B])
-        ops.loss_affine_rp(cont[B:2 * B], cont[2 * B:], cd, 0, B, self.code2, cd, 1.0, L[3:4], self.d_cont[B:2 * B], self.d_cont[2 * B:])
+        self._affine_loss(cont[B:2 * B], cont[2 * B:], L[3:4], self.d_cont[B:2 * B], self.d_cont[2 * B:])
         ops.loss_mutual_info(cat[2 * B:], nc, 0, nc, B, cat[B:2 * B], nc, 0, True, 1.0, L[4:5], self.d_cat[2 * B:])
         dimg_e = ee.backward(0, 3, {"cat_layer.0": self.d_cat, "cont_layer.0": self.d_cont}, ea.grad, need_dimg=True)
         ops.add_f32(self.dimg, dimg_e, dimg_d)
@@ -497,6 +492,22 @@ class DspritesTrainer:
         self._adam(ea, self.miE, self.viE, self.lr[1], 1, False)
         ge.repack()
         ee.repack()
+
+    # -- dataset-specific pieces (overridden by the colored variant) -------------------------------------------------
+    def _align(self):
+        """align = warp(img, inverse(T(x,y))[:, :2]) with (p,x,y) from the frozen Encoder_pxy."""
+        B, C = self.B, self.G.channels
+        pcode = self.pe.forward(self.img)
+        ops.theta_pxy_align_inv(pcode, pcode.shape[1], B, self.theta)
+        ops.warp_affine(self.img, self.theta, self.align, B, C, 64, 64)
+
+    def _transform(self, code, out):
+        B, C = self.B, self.G.channels
+        ops.theta_rp(code, self.cd, B, self.theta)
+        ops.warp_affine(self.align, self.theta, out, B, C, 64, 64)
+
+    def _affine_loss(self, cont_align, cont_trans, loss, d_align, d_trans):
+        ops.loss_affine_rp(cont_align, cont_trans, self.cd, 0, self.B, self.code2, self.cd, 1.0, loss, d_align, d_trans)
 
     def load_inputs(self, img_u8, code1, labels1, code2, labels2):
         """img_u8: uint8 [B,64,64] sprites (or float [B,C,64,64]); codes [B,code_dim]; labels int64 [B]."""

@@ -347,6 +347,18 @@ def loss_mutual_info(o, ld, c0, n, B, tgt, ldt, t0, target_logits, scale, loss, 
     lib().call("eg_loss_mutual_info", _p(o), ld, c0, n, B, _p(tgt), ldt, t0, int(target_logits), scale, _p(loss), _p(dout), _stream())
 
 
+def u8_colorize(sprites, gain, out, B, C, HW):
+    lib().call("eg_u8_colorize", _p(sprites), _p(gain), _p(out), B, C, HW, _stream())
+
+
+def color_scale(inp, code, ldc, c0, factor, divide, out, B, C, HW):
+    lib().call("eg_color_scale", _p(inp), _p(code), ldc, c0, factor, int(divide), _p(out), B, C, HW, _stream())
+
+
+def loss_affine_rp_color(o_real, o_trans, ld, c0, B, code, ldc, scale, loss, d_real, d_trans, pred_out=None):
+    lib().call("eg_loss_affine_rp_color", _p(o_real), _p(o_trans), ld, c0, B, _p(code), ldc, scale, _p(loss), _p(d_real), _p(d_trans), _p(pred_out), _stream())
+
+
 def add_f32(out, a, b):
     lib().call("eg_add_f32", _p(out), _p(a), _p(b), out.numel(), _stream())
 

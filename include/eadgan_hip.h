@@ -243,6 +243,12 @@ int eg_loss_affine_rp(const float* o_real, const float* o_trans, int ld, int c0,
                       float* loss, float* d_real, float* d_trans, float* pred_out, eg_stream_t s);
 int eg_loss_mutual_info(const float* o, int ld, int c0, int n, int B, const float* tgt, int ldt, int t0, int target_logits,
                         float scale, float* loss, float* dout, eg_stream_t s);
+/* colored dSprites (colored_dSprites/rp_color.py:368-394,415-424; utils_rp_color.py:38-75,100-139) */
+int eg_u8_colorize(const unsigned char* sprites, const float* gain, float* out, int B, int C, int HW, eg_stream_t s);
+int eg_color_scale(const float* in, const float* code, int ldc, int c0, float factor, int divide, float* out, int B, int C, int HW,
+                   eg_stream_t s);
+int eg_loss_affine_rp_color(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc, float scale,
+                            float* loss, float* d_real, float* d_trans, float* pred_out, eg_stream_t s);
 int eg_add_f32(float* out, const float* a, const float* b, size_t n, eg_stream_t s);
 int eg_u8_to_f32(const unsigned char* x, float* y, size_t n, eg_stream_t s);            /* uint8 sprites -> float (rp.py:369-370) */
 int eg_loss_affine_rpqxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc,

@@ -60,11 +60,11 @@ def _to_dict(m):
     return d
 
 
-def init_state(seed=0):
+def init_state(seed=0, ch=CH, code=CODE, pxy_out=3):
     """(E, D, G) in the reference's construction order encoder_pxy, encoder, discriminator, generator (rp.py:253-256); the
     encoder_pxy constructor consumes the RNG first and is then overwritten from its checkpoint."""
     torch.manual_seed(seed)
-    P, E, D, G = _containers()
+    P, E, D, G = _containers(ch=ch, code=code, pxy_out=pxy_out)
     return _to_dict(E), _to_dict(D), _to_dict(G)
 
 
@@ -218,3 +218,64 @@ def synthetic_sprites(B, seed=99):
     for b in range(B):
         img[b, cy[b] - hw[b, 0]:cy[b] + hw[b, 0], cx[b] - hw[b, 1]:cx[b] + hw[b, 1]] = 1
     return img
+
+
+# ---- colored dSprites (colored_dSprites/rp_color.py:363-516, utils_rp_color.py:24-139, utils_pxy.py:48-57,92-110) -----------------
+def affine_color_regularzier(real_code, trans_code):
+    aff = affine_regularzier(real_code, trans_code)
+    rel = (trans_code[:, 4:7] * 0.5 + 1) / (real_code[:, 4:7] * 0.5 + 1)
+    return torch.cat((aff, (rel - 1) / 0.5), dim=1).float()
+
+
+class ColoredOracle:
+    """3-channel variant: code = 4 affine + 3 RGB gains (c*.5+1); sprites are coloured with U(.5,1) gains (first np draw of the
+    iteration); the frozen Encoder_pxy emits 6 codes (p,x,y + 3 gains c*.1+1) and the aligned image is divided by those gains;
+    all Adams use lr 2e-4 (rp_color.py:42,274-280)."""
+
+    def __init__(self, seed=0, pxy=None, lrs=(2e-4, 2e-4)):
+        self.E, self.D, self.G = init_state(seed, ch=3, code=7, pxy_out=6)
+        self.P = pxy if pxy is not None else make_encoder_pxy(ch=3, pxy_out=6)
+        self.opt_D = torch.optim.Adam(trainable(self.D), lr=lrs[0], betas=(0.5, 0.999))
+        self.opt_info = torch.optim.Adam(trainable(self.G) + trainable(self.E), lr=lrs[1], betas=(0.5, 0.999))
+
+    def train_step(self, img_u8, gains, code1, labels1, code2, labels2):
+        E, D, G, P = self.E, self.D, self.G, self.P
+        img = (img_u8.unsqueeze(1).repeat(1, 3, 1, 1) * gains.double()[:, :, None, None]).float()
+        B = img.shape[0]
+        valid, fake = torch.ones(B, 1), torch.zeros(B, 1)
+        with torch.no_grad():
+            pcode = encoder_pxy_forward(P, img)
+            align = warp(img, torch.inverse(get_matrix_pxy_align(pcode))[:, 0:2]) / (pcode[:, 3:] * 0.1 + 1)[:, :, None, None]
+        col = lambda c: (c[:, 4:] * 0.5 + 1)[:, :, None, None]
+        trans = warp(align, get_matrix(code1[:, :4])[:, 0:2]) * col(code1)
+        gen = generator_forward(G, torch.cat((F.one_hot(labels1, NCLS).float(), code1), dim=1))
+        d_real = discriminator_forward(D, trans)
+        d_fake = discriminator_forward(D, gen.detach())
+        d_loss = (F.binary_cross_entropy(d_fake, fake) + F.binary_cross_entropy(d_real, valid)) / 2
+        self.opt_D.zero_grad()
+        d_loss.backward()
+        self.opt_D.step()
+        onehot2 = F.one_hot(labels2, NCLS).float()
+        gen = generator_forward(G, torch.cat((onehot2, code2), dim=1))
+        rec_cat, rec_cont = encoder_forward(E, gen)
+        g_loss = F.binary_cross_entropy(discriminator_forward(D, gen), valid)
+        info_loss = mutual_info_loss(rec_cat, onehot2) + F.mse_loss(rec_cont, code2)
+        trans2 = warp(align, get_matrix(code2[:, :4])[:, 0:2]) * col(code2)
+        align_cat, align_cont = encoder_forward(E, align)
+        trans_cat, trans_cont = encoder_forward(E, trans2)
+        affine_loss = F.mse_loss(affine_color_regularzier(align_cont, trans_cont), code2)
+        relative_cat_loss = mutual_info_loss(trans_cat, align_cat.detach())
+        total = info_loss + affine_loss + relative_cat_loss + g_loss
+        self.opt_info.zero_grad()
+        for v in trainable(D):
+            v.grad = None
+        total.backward()
+        self.opt_info.step()
+        return {k: float(v.detach()) for k, v in dict(d_loss=d_loss, g_loss=g_loss, info_loss=info_loss, affine_loss=affine_loss,
+                                                     relative_cat_loss=relative_cat_loss).items()}
+
+
+def draw_colored_inputs(rng: np.random.RandomState, B: int):
+    """rp_color.py:372-378 draws the colour gains first, then the dSprites sequence with code_dim 7."""
+    gains = torch.tensor(rng.uniform(0.5, 1, [B, 3, 1, 1]).reshape(B, 3), dtype=torch.float64)
+    return (gains,) + draw_step_inputs(rng, B, code_dim=7)

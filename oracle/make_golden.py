@@ -168,7 +168,33 @@ def make_dsprites(B=8, steps=3, seed=0, pxy_seed=321):
     print("dsprites golden:", {k: out[k] for k in names})
 
 
-MAKERS = {"dsprites": make_dsprites, "celeba": make_celeba, "celeba_affine": make_celeba_affine, "mnist": make_mnist, "mnist_affine": make_mnist_affine}
+def make_colored(B=8, steps=3, seed=0, pxy_seed=654):
+    """colored_dSprites/rp_color.py loop (:365-516); encoder_pxy_color_50000.pt is a seeded stand-in."""
+    torch.set_num_threads(8)
+    sprites = do.synthetic_sprites(B * steps, seed=99).view(steps, B, 64, 64)
+    out = {"B": np.array(B), "steps": np.array(steps), "seed": np.array(seed), "sprite_seed": np.array(99), "pxy_seed": np.array(pxy_seed)}
+    names = ("d_loss", "g_loss", "cat_loss", "cont_loss", "affine_color_loss", "relative_cat_loss")
+    pxy = do.make_encoder_pxy(pxy_seed, ch=3, pxy_out=6)
+    real_save = torch.save
+
+    def prereq(tmp):
+        real_save(pxy, os.path.join(tmp, "encoder_pxy_color_50000.pt"))
+
+    for n in (1, steps):
+        batches = [sprites[i].clone() for i in range(n)]
+        g, recs = rh.run_script_loop("colored_dSprites/rp_color.py", rh.colored_opt(B), batches, names, seed, prereq=prereq)
+        if n == 1:
+            probe_state("G1", g["generator"].state_dict(), out)
+            probe_state("E1", g["encoder"].state_dict(), out)
+            probe_grads("gG1", g["generator"], out)
+            probe_grads("gE1", g["encoder"], out)
+    for k in names:
+        out[k] = np.array([r[k] for r in recs], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, f"colored_b{B}_s{steps}.npz"), **out)
+    print("colored golden:", {k: out[k] for k in names})
+
+
+MAKERS = {"colored": make_colored, "dsprites": make_dsprites, "celeba": make_celeba, "celeba_affine": make_celeba_affine, "mnist": make_mnist, "mnist_affine": make_mnist_affine}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

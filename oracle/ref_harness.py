@@ -183,3 +183,9 @@ def dsprites_opt(batch_size):
     """argparse defaults of dSprites/rp.py:40-51 with n_epochs=1."""
     return argparse.Namespace(n_epochs=1, batch_size=batch_size, lr=0.0001, b1=0.5, b2=0.999, n_cpu=8, latent_dim=200, code_dim=4, n_classes=3,
                               img_size=64, channels=1, sample_interval=1000)
+
+
+def colored_opt(batch_size):
+    """argparse defaults of colored_dSprites/rp_color.py:40-51 with n_epochs=1."""
+    return argparse.Namespace(n_epochs=1, batch_size=batch_size, lr=0.0002, b1=0.5, b2=0.999, n_cpu=8, latent_dim=200, code_dim=7, n_classes=3,
+                              img_size=64, channels=3, sample_interval=1000)

@@ -1,0 +1,99 @@
+"""colored-dSprites hot path on the MI355X vs the CPU oracle (oracle/dsprites_oracle.py: ColoredOracle, pinned to the reference by
+tests/golden/colored_b8_s3.npz)."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import dsprites_oracle as do
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+eg = None
+NAMES = ("d_loss", "g_loss", "info_loss", "affine_loss", "relative_cat_loss")
+PRE_BN_BIAS = ("conv_block.0.bias", "conv_block.3.bias", "conv_block.6.bias")
+
+
+def setup_module(module):
+    global eg
+    eg = importlib.import_module("ead-gan_amd")
+    torch.set_num_threads(16)
+
+
+def rel_err(a, b):
+    a, b = a.detach().float().cpu().flatten(), b.detach().float().cpu().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def build(seed, dtype, lrs=(2e-4, 2e-4), pxy_seed=654):
+    pxy = do.make_encoder_pxy(pxy_seed, ch=3, pxy_out=6)
+    orc = do.ColoredOracle(seed=seed, pxy=pxy, lrs=lrs)
+    c = eg.colored
+    P, G, D, E = c.Encoder_pxy(dtype=dtype).to(DEV), c.Generator(dtype=dtype).to(DEV), c.Discriminator(dtype=dtype).to(DEV), c.Encoder(dtype=dtype).to(DEV)
+    for m, ref in ((P, pxy), (G, orc.G), (D, orc.D), (E, orc.E)):
+        assert list(m.state_dict().keys()) == list(ref.keys())
+        m.load_state_dict({k: v.detach() for k, v in ref.items()})
+    return orc, P, G, D, E
+
+
+def run_steps(dtype, B, steps, seed=0, lrs=(2e-4, 2e-4)):
+    orc, P, G, D, E = build(seed, dtype, lrs)
+    tr = eg.colored.ColoredTrainer(P, G, D, E, B, dtype=dtype, lrs=lrs)
+    rng = np.random.RandomState(seed)
+    sprites = do.synthetic_sprites(B * steps, seed=99).view(steps, B, 64, 64)
+    got, want = [], []
+    for i in range(steps):
+        inp = do.draw_colored_inputs(rng, B)
+        got.append(tr.train_step(sprites[i].to(DEV), *[t.to(DEV) for t in inp]))
+        want.append(orc.train_step(sprites[i], *inp))
+    return orc, G, D, E, tr, got, want
+
+
+def test_affine_color_regularizer():
+    g = torch.Generator().manual_seed(4)
+    rc = (torch.rand(16, 7, generator=g) * 2 - 1).requires_grad_(True)
+    tc = (torch.rand(16, 7, generator=g) * 2 - 1).requires_grad_(True)
+    w = torch.randn(16, 7, generator=g)
+    want = do.affine_color_regularzier(rc, tc)
+    (want * w).sum().backward()
+    rcd, tcd = rc.detach().to(DEV).requires_grad_(True), tc.detach().to(DEV).requires_grad_(True)
+    got = eg.colored.affine_color_regularzier(rcd, tcd)
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=2e-4, atol=2e-5)
+    (got * w.to(DEV)).sum().backward()
+    np.testing.assert_allclose(rcd.grad.cpu().numpy(), rc.grad.numpy(), rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(tcd.grad.cpu().numpy(), tc.grad.numpy(), rtol=2e-3, atol=2e-4)
+
+
+def test_train_step_fp32_and_golden():
+    gold = np.load(os.path.join(GOLDEN, "colored_b8_s3.npz"))
+    B, steps, seed = int(gold["B"]), int(gold["steps"]), int(gold["seed"])
+    orc, G, D, E, tr, got, want = run_steps("f32", B, steps, seed=seed)
+    for k in NAMES:
+        t0 = 2e-5 if k == "d_loss" else 3e-4
+        assert abs(got[0][k] - want[0][k]) < t0, (k, got[0][k], want[0][k])
+    assert abs(got[0]["d_loss"] - gold["d_loss"][0]) < 2e-5 and abs(got[0]["g_loss"] - gold["g_loss"][0]) < 3e-4
+    assert abs(got[0]["info_loss"] - (gold["cat_loss"][0] + gold["cont_loss"][0])) < 3e-4
+    assert abs(got[0]["affine_loss"] - gold["affine_color_loss"][0]) < 3e-4
+    for i in (1, 2):
+        assert abs(got[i]["d_loss"] - gold["d_loss"][i]) < 5e-2 and abs(got[i]["affine_loss"] - gold["affine_color_loss"][i]) < 5e-2
+
+
+def test_train_step_gradients_lr0_fp32():
+    orc, G, D, E, tr, got, want = run_steps("f32", 8, 1, seed=3, lrs=(0.0, 0.0))
+    for k in NAMES:
+        assert abs(got[0][k] - want[0][k]) < 2e-5, (k, got[0][k], want[0][k])
+    for mod, ref in ((G, orc.G), (E, orc.E)):
+        for k, p in mod.named_parameters():
+            if k in PRE_BN_BIAS:
+                continue
+            assert rel_err(p.grad, ref[k].grad) < 2e-2, k
+
+
+def test_train_step_bf16_tracks_oracle():
+    orc, G, D, E, tr, got, want = run_steps("bf16", 16, 2)
+    for i in range(2):
+        for k in NAMES:
+            assert abs(got[i][k] - want[i][k]) < 5e-2 * max(1.0, abs(want[i][k])), (i, k, got[i][k], want[i][k])

@@ -120,3 +120,23 @@ def test_dsprites_step_matches_reference():
             check_probes("G1", orc.G, gold, 2e-3, 3e-4)
             check_probes("D1", orc.D, gold, 2e-3, 3e-4)
             check_probes("E1", orc.E, gold, 2e-3, 3e-4)
+
+
+def test_colored_dsprites_step_matches_reference():
+    from oracle import dsprites_oracle as do
+    gold = np.load(os.path.join(GOLDEN, "colored_b8_s3.npz"))
+    B, steps, seed = int(gold["B"]), int(gold["steps"]), int(gold["seed"])
+    torch.set_num_threads(8)
+    orc = do.ColoredOracle(seed=seed, pxy=do.make_encoder_pxy(int(gold["pxy_seed"]), ch=3, pxy_out=6))
+    rng = np.random.RandomState(seed)
+    sprites = do.synthetic_sprites(B * steps, seed=int(gold["sprite_seed"])).view(steps, B, 64, 64)
+    for i in range(steps):
+        out = orc.train_step(sprites[i], *do.draw_colored_inputs(rng, B))
+        tol = (3e-6, 1e-3, 1e-2)[i]
+        assert abs(out["d_loss"] - gold["d_loss"][i]) < tol and abs(out["g_loss"] - gold["g_loss"][i]) < tol
+        assert abs(out["info_loss"] - (gold["cat_loss"][i] + gold["cont_loss"][i])) < tol
+        assert abs(out["affine_loss"] - gold["affine_color_loss"][i]) < tol
+        assert abs(out["relative_cat_loss"] - gold["relative_cat_loss"][i]) < tol
+        if i == 0:
+            check_probes("gG1", {k: v.grad for k, v in orc.G.items() if getattr(v, "grad", None) is not None}, gold, 1e-2, 1e-9, noise_floor=1e-8)
+            check_probes("gE1", {k: v.grad for k, v in orc.E.items() if getattr(v, "grad", None) is not None}, gold, 1e-2, 1e-9, noise_floor=1e-8)
