@@ -45,8 +45,9 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="initialise a process group and run the all-reduce hooks even with one rank "
                                                               "(rehearses the N>1 code path, incl. RCCL capture into the hipGraph, on one GPU)")
     ap.add_argument("--igemm-dma", type=int, default=2, help="LDS-DMA staged NT kernel variant for large launches (0 off, 1 = 256x128x3, 2 = 128x128x2 [default], 3 = 128x128x3)")
-    ap.add_argument("--workload", default="celeba", choices=["celeba", "mnist"],
-                    help="celeba = the headline metric (default); mnist = BASELINE config[1] (MNIST 32x32, use --batch 256 --dtype f32)")
+    ap.add_argument("--workload", default="celeba", choices=["celeba", "mnist", "dsprites", "colored"],
+                    help="celeba = the headline metric (default); mnist = BASELINE config[1] (use --batch 256 --dtype f32); "
+                         "dsprites = config[2] (--batch 128); colored = config[4] (--batch 512)")
     return ap.parse_args()
 
 
@@ -151,6 +152,53 @@ def main_mnist(a, eg, rank, world, local, dev):
                           "final_losses": [round(x, 4) for x in tr.losses.tolist()[:3]]}), flush=True)
 
 
+def main_sprites(a, eg, rank, world, local, dev):
+    """secondary lines: dSprites/rp.py (0.485 GFLOP/img) and colored_dSprites/rp_color.py (0.533 GFLOP/img) iterations."""
+    from oracle import dsprites_oracle as do        # only for the seeded stand-in of the frozen Encoder_pxy checkpoint / synthetic sprites
+    B, color = a.batch, a.workload == "colored"
+    mod = eg.colored if color else eg.dsprites
+    torch.manual_seed(0)
+    P, G, D, E = mod.Encoder_pxy(dtype=a.dtype).to(dev), mod.Generator(dtype=a.dtype).to(dev), mod.Discriminator(dtype=a.dtype).to(dev), mod.Encoder(dtype=a.dtype).to(dev)
+    P.load_state_dict(do.make_encoder_pxy(654 if color else 321, ch=3 if color else 1, pxy_out=6 if color else 3))
+    ar = eg.dp.GradAllReduce(world) if world > 1 else None
+    tr = (mod.ColoredTrainer if color else mod.DspritesTrainer)(P, G, D, E, B, dtype=a.dtype, allreduce=ar)
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    sprites = do.synthetic_sprites(B, seed=7 + rank).to(dev)
+    cd = 7 if color else 4
+    mk = lambda: (torch.rand((B, cd), device=dev, generator=g) * 2 - 1, torch.randint(0, 3, (B,), device=dev, generator=g))
+    c1, l1 = mk()
+    c2, l2 = mk()
+    if color:
+        tr.load_inputs(sprites, torch.rand((B, 3), device=dev, generator=g) * 0.5 + 0.5, c1, l1, c2, l2)
+    else:
+        tr.load_inputs(sprites, c1, l1, c2, l2)
+    tr.step_resident()
+    use_graph = not a.no_graph
+    if use_graph:
+        tr.capture()
+    for _ in range(max(a.warmup - 1, 0)):
+        tr.step_resident()
+    eg.dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.step_resident()
+    torch.cuda.synchronize()
+    eg.dp.barrier()
+    dt = eg.dp.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        ips = B * world * a.steps / dt
+        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        gf = 0.533 if color else 0.485
+        print(json.dumps({"metric": f"imgs/sec per train step, {'colored ' if color else ''}dSprites 64x64", "value": round(ips, 1), "unit": "imgs/s",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+                          "config": {"workload": f"EAD-GAN {'colored ' if color else ''}dSprites full train iteration (D step + joint info/affine/G step), batch {B}/GPU, "
+                                                 f"{'hipGraph replay' if use_graph else 'eager launches'}", "per_gpu_batch": B, "parallelism": f"dp{world}"},
+                          "whole_step_mfma_frac": round(ips / world * gf / 1e3 / peak, 5), "roofline": None, "cpu_baseline": None,
+                          "final_losses": [round(x, 4) for x in tr.losses.tolist()[:5]]}), flush=True)
+
+
 def main():
     a = parse()
     eg = importlib.import_module("ead-gan_amd")
@@ -168,6 +216,8 @@ def main():
     B = a.batch
     if a.workload == "mnist":
         return main_mnist(a, eg, rank, world, local, dev)
+    if a.workload in ("dsprites", "colored"):
+        return main_sprites(a, eg, rank, world, local, dev)
 
     torch.manual_seed(0)                                 # identical replicas on every rank
     G = eg.celeba.Generator(dtype=a.dtype).to(dev)
