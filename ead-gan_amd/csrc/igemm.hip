@@ -362,6 +362,73 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
                  : "memory");
 }
 
+// shared epilogue of the LDS-DMA kernels: fp32 tile through LDS (XOR-swizzled 16-byte chunks), then 16-byte vector stores with the
+// fused 1/sigma, bias, activation and activation-gradient mask.  Callers __syncthreads() before (the K loop's LDS is reused).
+template <typename T, int BM, int BN, int TM, int TN>
+__device__ __forceinline__ void nt_epilogue_lds(const NtParams& p, const NtPhase& ph, f32x4 (&acc)[TM][TN], char* smem, int m0, int n0, int wm,
+                                                int wn, int tid, int frow, int fq) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
+    constexpr int CH = BN / 4;
+    constexpr int SW = 31;
+    float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 16 + frow;
+        const int mrow = min(m0 + row, p.M - 1);
+        const float inv_sigma = p.sigma ? 1.f / p.sigma[p.sigma_rows ? mrow / p.sigma_rows : 0] : 1.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = (wn * TN + j) * 16 + fq * 4;
+            float4 v;
+            float* ve = reinterpret_cast<float*>(&v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[i][j][r] * inv_sigma;
+                const int n = n0 + nl + r;
+                if (p.bias && n < p.N) x += p.bias[p.bias_mod ? n % p.bias_mod : n];
+                ve[r] = eg_act(x, p.act, p.slope);
+            }
+            *reinterpret_cast<float4*>(ct + row * BN + (((nl >> 2) ^ (row & SW)) << 2)) = v;
+        }
+    }
+    __syncthreads();
+    constexpr int VPR = BN / VEC;
+    constexpr int RPP = 256 / VPR;
+    const int vc = tid % VPR, vr = tid / VPR;
+    const T* __restrict__ mask = reinterpret_cast<const T*>(p.mask);
+    const int n = n0 + vc * VEC;
+    if (n < p.N) {
+#pragma unroll 4
+        for (int row = vr; row < BM; row += RPP) {
+            const int m = m0 + row;
+            if (m >= p.M) break;
+            const int b = m >> (p.lOW + p.lOH);
+            const int y = ((m >> p.lOW) & OHm) * p.osy + ph.ooy;
+            const int x = (m & OWm) * p.osx + ph.oox;
+            const size_t o = (((size_t)b * p.DH + y) * p.DW + x) * p.N + n;
+            float f[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC / 4; ++q) {
+                const int chunk = (vc * (VEC / 4) + q) ^ (row & SW);
+                const float4 v = *reinterpret_cast<const float4*>(ct + row * BN + (chunk << 2));
+                f[q * 4 + 0] = v.x; f[q * 4 + 1] = v.y; f[q * 4 + 2] = v.z; f[q * 4 + 3] = v.w;
+            }
+            if (mask) {
+                const uint4 mv = *reinterpret_cast<const uint4*>(mask + o);
+                const T* me = reinterpret_cast<const T*>(&mv);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) f[q] *= eg_act_grad_from_out(Elt<T>::ld(me + q), p.mask_act, p.mask_slope);
+            }
+            uint4 ov;
+            T* oe = reinterpret_cast<T*>(&ov);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) Elt<T>::st(oe + q, f[q]);
+            *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.dst) + o) = ov;
+        }
+    }
+}
+
 #define EG_DMA_BN 128
 
 template <typename T, int BM, int NST>
@@ -466,78 +533,171 @@ __global__ __launch_bounds__(256) void igemm_nt_dma_kernel(const NtParams p) {
     }
     __syncthreads();
 
-    // ---- epilogue: fp32 tile through LDS (XOR-swizzled 16-byte chunks), 16-byte vector stores ----
-    constexpr int CH = BN / 4;
-    constexpr int SW = 31;
-    float* ct = reinterpret_cast<float*>(smem);
+    nt_epilogue_lds<T, BM, BN, TM, TN>(p, ph, acc, smem, m0, n0, wm, wn, tid, frow, fq);
+}
+
+// ------------------------------------------------------------------------------------------------
+// igemm_nt_buf: 128x128 tile, 2-stage LDS-DMA ring like igemm_nt_dma<.,128,2>, but the gather goes through buffer descriptors
+// (`buffer_load_dwordx4 ... offen lds`): the per-lane part of every address is a 32-bit byte offset that only changes when the
+// K loop moves to the next filter tap, the walk along the channels of a tap is the instruction's SGPR offset, and padded /
+// out-of-range rows carry an offset beyond num_records (the hardware range check returns zeros) -> no branches, no 64-bit
+// address math and no EXEC juggling in the K loop.  Needs C % BK == 0 (every lane of a K step sits in the same tap) and
+// tensors below 2 GiB; the dispatcher falls back to igemm_nt_dma otherwise.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u32x4_t eg_make_srd(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    u32x4_t r;
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
+    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+    r.z = __builtin_amdgcn_readfirstlane(bytes);
+    r.w = 0x00020000u;
+    return r;
+}
+
+// four 1-KiB LDS-DMA pieces (tile rows (j*4+wave)*8 .. +7, j = 0..3) from one descriptor: LDS bases lds, lds+4K, lds+8K, lds+12K
+__device__ __forceinline__ void eg_bufdma4(const u32x4_t srd, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned soff, unsigned lds) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %7\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %5, %6 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %3, %5, %6 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %4, %5, %6 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(srd), "s"(soff), "s"(lds)
+        : "memory", "scc");
+}
+
+#define EG_OOB 0x80000000u
+
+template <typename T>
+__global__ __launch_bounds__(256) void igemm_nt_buf_kernel(const NtParams p) {
+    constexpr int VEC = Elt<T>::VEC;
+    constexpr int BK = 8 * VEC;
+    constexpr int BM = 128, BN = 128;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int TM = 4, TN = 4;                  // waves 2 x 2, wave tile 64 x 64
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const NtPhase ph = p.ph[blockIdx.z];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
+    const int HU = p.H << p.up, WU = p.W << p.up;
+    const int rsub = lane >> 3, pos = lane & 7;
+    const int srcchunk = pos ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+
+    int a_pix0[4], a_y[4], a_x[4];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = (wm * TM + i) * 16 + frow;
-        const int mrow = min(m0 + row, p.M - 1);
-        const float inv_sigma = p.sigma ? 1.f / p.sigma[p.sigma_rows ? mrow / p.sigma_rows : 0] : 1.f;
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + (j * 4 + wave) * 8 + rsub;
+        const int b = m >> (p.lOW + p.lOH);
+        a_pix0[j] = (m < p.M) ? b * p.H * p.W : -1;
+        a_y[j] = ((m >> p.lOW) & OHm) * p.sy + ph.dy0;
+        a_x[j] = (m & OWm) * p.sx + ph.dx0;
+    }
+    const unsigned row_bytes = (unsigned)p.C * sizeof(T);
+    unsigned va[4], vb[4];
+    auto tap_offsets = [&](int ty, int tx) {
+        const int oy = ty * ph.dys, ox = tx * ph.dxs;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nl = (wn * TN + j) * 16 + fq * 4;
-            float4 v;
-            float* ve = reinterpret_cast<float*>(&v);
+        for (int j = 0; j < 4; ++j) {
+            const int iy = a_y[j] + oy, ix = a_x[j] + ox;
+            const bool ok = a_pix0[j] >= 0 && iy >= 0 && iy < HU && ix >= 0 && ix < WU;
+            const unsigned pix = (unsigned)(a_pix0[j] + (iy >> p.up) * p.W + (ix >> p.up));
+            va[j] = ok ? pix * row_bytes + (unsigned)srcchunk * 16u : EG_OOB;
+        }
+    };
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = acc[i][j][r] * inv_sigma;
-                const int n = n0 + nl + r;
-                if (p.bias && n < p.N) x += p.bias[p.bias_mod ? n % p.bias_mod : n];
-                ve[r] = eg_act(x, p.act, p.slope);
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + (j * 4 + wave) * 8 + rsub;
+        vb[j] = n < p.N ? (unsigned)n * (unsigned)ph.Kpad * (unsigned)sizeof(T) + (unsigned)srcchunk * 16u : EG_OOB;
+    }
+    const u32x4_t srdA = eg_make_srd(p.src, (unsigned)((size_t)p.B * p.H * p.W * p.C * sizeof(T)));
+    const u32x4_t srdB = eg_make_srd(reinterpret_cast<const T*>(p.wp) + ph.w_off, (unsigned)((size_t)p.N * ph.Kpad * sizeof(T)));
+    const int nk = ph.Kpad / BK;
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)wave * 1024u;
+    // wave-uniform walk over (tap, channel block)
+    int ty = 0, tx = 0;
+    unsigned kc_bytes = 0;
+    tap_offsets(0, 0);
+    auto issue = [&](int kt, int stage) {
+        const unsigned sa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)stage * STAGE);
+        eg_bufdma4(srdA, va[0], va[1], va[2], va[3], kc_bytes, sa);
+        eg_bufdma4(srdB, vb[0], vb[1], vb[2], vb[3], (unsigned)kt * 128u, sa + BM * 128);
+        kc_bytes += 128u;
+        if (kc_bytes >= row_bytes) {               // next tap (uniform branch)
+            kc_bytes = 0;
+            if (++tx == ph.TW) { tx = 0; ++ty; }
+            if (ty < ph.TH) tap_offsets(ty, tx);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) va[j] = EG_OOB;     // K padding beyond the last tap
             }
-            *reinterpret_cast<float4*>(ct + row * BN + (((nl >> 2) ^ (row & SW)) << 2)) = v;
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    if (nk > 0) issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // everyone's stage kt landed; everyone finished reading stage kt-1
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const char* sa = smem + (kt & 1) * STAGE;
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 bfr[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(sb + lds_off((wn * TN + j) * 16 + frow, ks * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const uint4 af = *reinterpret_cast<const uint4*>(sa + lds_off((wm * TM + i) * 16 + frow, ks * 4 + fq));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) mfma_step<T>(af, bfr[j], acc[i][j]);
+            }
         }
     }
     __syncthreads();
-    constexpr int VPR = BN / VEC;
-    constexpr int RPP = 256 / VPR;
-    const int vc = tid % VPR, vr = tid / VPR;
-    const T* __restrict__ mask = reinterpret_cast<const T*>(p.mask);
-    const int n = n0 + vc * VEC;
-    if (n < p.N) {
-#pragma unroll 4
-        for (int row = vr; row < BM; row += RPP) {
-            const int m = m0 + row;
-            if (m >= p.M) break;
-            const int b = m >> (p.lOW + p.lOH);
-            const int y = ((m >> p.lOW) & OHm) * p.osy + ph.ooy;
-            const int x = (m & OWm) * p.osx + ph.oox;
-            const size_t o = (((size_t)b * p.DH + y) * p.DW + x) * p.N + n;
-            float f[VEC];
-#pragma unroll
-            for (int q = 0; q < VEC / 4; ++q) {
-                const int chunk = (vc * (VEC / 4) + q) ^ (row & SW);
-                const float4 v = *reinterpret_cast<const float4*>(ct + row * BN + (chunk << 2));
-                f[q * 4 + 0] = v.x; f[q * 4 + 1] = v.y; f[q * 4 + 2] = v.z; f[q * 4 + 3] = v.w;
-            }
-            if (mask) {
-                const uint4 mv = *reinterpret_cast<const uint4*>(mask + o);
-                const T* me = reinterpret_cast<const T*>(&mv);
-#pragma unroll
-                for (int q = 0; q < VEC; ++q) f[q] *= eg_act_grad_from_out(Elt<T>::ld(me + q), p.mask_act, p.mask_slope);
-            }
-            uint4 ov;
-            T* oe = reinterpret_cast<T*>(&ov);
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) Elt<T>::st(oe + q, f[q]);
-            *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.dst) + o) = ov;
-        }
-    }
+    nt_epilogue_lds<T, BM, BN, TM, TN>(p, ph, acc, smem, m0, n0, wm, wn, tid, frow, fq);
 }
 
 // 0: register-staged kernels only; 1: 256x128 / 3-stage DMA ring; 2: 128x128 / 2-stage DMA (default: +2 % whole-step, bit-exact);
-// 3: 128x128 / 3-stage DMA (1 block per CU).  Measured on CelebA B=128 bf16: 0 -> 14.55k img/s, 1 -> 12.8k, 2 -> 14.85k, 3 -> 13.1k.
-static int g_use_dma = 2;
+// 3: 128x128 / 3-stage DMA (1 block per CU); 4: igemm_nt_buf where eligible, else as 2.  Measured on CelebA B=128 bf16: 0 -> 14.55k img/s, 1 -> 12.8k, 2 -> 14.85k, 3 -> 13.1k.
+static int g_use_dma = 4;
 extern "C" int eg_set_igemm_dma(int on) { const int old = g_use_dma; g_use_dma = on; return old; }
+
+static bool buf_eligible(const NtParams& p, int nphase, int vec, size_t esize) {
+    if (g_use_dma != 4 || p.out_mode != EG_OUT_NHWC || (p.N % 128) != 0 || (p.C % (8 * vec)) != 0) return false;
+    if ((size_t)p.B * p.H * p.W * p.C * esize >= 0x7fffffffull) return false;
+    for (int i = 0; i < nphase; ++i)
+        if (p.ph[i].Kpad / (8 * vec) < 3 || (size_t)p.N * p.ph[i].Kpad * esize >= 0x7fffffffull) return false;
+    return (long long)cdiv(p.M, 128) * (p.N / 128) * nphase >= 512;
+}
 
 static bool dma_eligible(const NtParams& p, int nphase, int vec) {
     if (!g_use_dma || p.out_mode != EG_OUT_NHWC || (p.N % 128) != 0 || (p.N % vec) != 0) return false;
     for (int i = 0; i < nphase; ++i)
         if (p.ph[i].Kpad / (8 * vec) < 3) return false;
     const int bm = g_use_dma == 1 ? 256 : 128;
-    const long long need = g_use_dma == 1 ? 240 : (g_use_dma == 3 ? 256 : 512);
+    const long long need = g_use_dma == 1 ? 240 : (g_use_dma == 3 ? 256 : 512);   // mode 4 falls back to the 2-stage variant (512)
     return (long long)cdiv(p.M, bm) * (p.N / EG_DMA_BN) * nphase >= need;
 }
 
@@ -570,6 +730,16 @@ static void launch_nt_cfg(const NtParams& p, int nphase, hipStream_t st) {
 
 template <typename T>
 static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
+    if (buf_eligible(p, nphase, Elt<T>::VEC, sizeof(T))) {
+        static bool attr_set = false;
+        const size_t lds = 2 * (128 + 128) * 128;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_nt_buf_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((igemm_nt_buf_kernel<T>), dim3(cdiv(p.M, 128), p.N / 128, nphase), dim3(256), lds, st, p);
+        return;
+    }
     if (dma_eligible(p, nphase, Elt<T>::VEC)) {
         launch_nt_dma<T>(p, nphase, st);
         return;
@@ -584,11 +754,15 @@ static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
         launch_nt_cfg<T, 128, 128, 2, 2>(p, nphase, st);
 }
 
-/* which igemm_nt instantiation a (M, N, nphase) problem is dispatched to: returns BM*1000 + BN */
-extern "C" int eg_igemm_nt_tile(int M, int N, int nphase) {
-    if (g_use_dma == 1 && N % 128 == 0 && (long long)cdiv(M, 256) * (N / EG_DMA_BN) * nphase >= 240) return 256 * 1000 + 128;   // (K-depth check omitted: labels only)
-    if (g_use_dma == 3 && N % 128 == 0 && (long long)cdiv(M, 128) * (N / EG_DMA_BN) * nphase >= 256) return 128 * 1000 + 130;   // 130: 128x128, 3 DMA stages
-    if (g_use_dma == 2 && N % 128 == 0 && (long long)cdiv(M, 128) * (N / EG_DMA_BN) * nphase >= 512) return 128 * 1000 + 129;   // 129: label of the DMA-staged 128x128 variant
+/* which igemm_nt instantiation a problem is dispatched to (profiling labels only; same predicates as launch_nt): BM*1000 + BN, where
+ * BN 129 / 130 / 131 stand for the 128-wide LDS-DMA variants (2-stage, 3-stage, buffer-descriptor). */
+extern "C" int eg_igemm_nt_tile(int dtype, int M, int N, int C, int K, int nphase) {
+    const int vec = vec_of(dtype), bk = bk_of(dtype);
+    NtParams p{};
+    p.out_mode = EG_OUT_NHWC; p.M = M; p.N = N; p.C = C; p.B = 1; p.H = 1; p.W = 1;
+    for (int i = 0; i < nphase && i < 4; ++i) p.ph[i].Kpad = round_up(K, bk);
+    if (buf_eligible(p, nphase, vec, dtype == EG_F32 ? 4 : 2)) return 128 * 1000 + 131;
+    if (dma_eligible(p, nphase, vec)) return g_use_dma == 1 ? 256 * 1000 + 128 : (g_use_dma == 3 ? 128 * 1000 + 130 : 128 * 1000 + 129);
     if (N <= 16) return 128 * 1000 + 16;
     if (N <= 32) return 128 * 1000 + 32;
     if (N <= 64 || (long long)cdiv(M, 128) * cdiv(N, 128) * nphase < 512) return 128 * 1000 + 64;

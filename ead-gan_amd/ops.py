@@ -92,9 +92,12 @@ def _timed(kind, c, dtype, args):
     if kind == "tn":
         label = f"igemm_tn_kernel<{tname}>"
     else:
-        N, nph = (c.Cout, 1) if kind == "fwd" else (c.Cin, c.stride * c.stride)
-        tile = lib().query("eg_igemm_nt_tile", M, N, nph)
-        label = f"igemm_nt_kernel<{tname},{tile // 1000},{tile % 1000}>"
+        N, C, K, nph = (c.Cout, c.Cin, c.k * c.k * c.Cin, 1) if kind == "fwd" else \
+            (c.Cin, c.Cout, (c.k // c.stride) ** 2 * c.Cout, c.stride * c.stride)
+        tile = lib().query("eg_igemm_nt_tile", dtype, M, N, C, K, nph)
+        bm, bn = tile // 1000, tile % 1000
+        label = {129: f"igemm_nt_dma_kernel<{tname},{bm},2>", 130: f"igemm_nt_dma_kernel<{tname},{bm},3>",
+                 131: f"igemm_nt_buf_kernel<{tname}>"}.get(bn, f"igemm_nt_dma_kernel<{tname},256,3>" if bm == 256 else f"igemm_nt_kernel<{tname},{bm},{bn}>")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     lib().call(*args, _stream())

@@ -73,10 +73,12 @@ int eg_conv_fwd(const eg_conv* c, int dtype, const void* X, const void* wp_fwd, 
 /* dX = conv^T(dY, W)  (== ConvTranspose2d forward); dX has spatial dims (H<<up, W<<up) */
 int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, const void* wp_bwd, void* dX,
                      const eg_epilogue* ep, eg_stream_t s);
-/* tile (BM*1000+BN) of the igemm_nt instantiation a problem is dispatched to (profiling labels only) */
-int eg_igemm_nt_tile(int M, int N, int nphase);
+/* tile (BM*1000+BN) of the igemm_nt instantiation a problem (M rows, N columns, C gathered channels per tap, K per phase) is
+ * dispatched to; BN = 129 / 130 / 131 name the 128-wide LDS-DMA variants (2-stage, 3-stage, buffer-descriptor).  Profiling labels only. */
+int eg_igemm_nt_tile(int dtype, int M, int N, int C, int K, int nphase);
 /* LDS-DMA (global_load_lds) staged variants of the NT kernel for large launches: 0 = off (register staging only),
- * 1 = 256x128 tile / 3-stage ring, 2 = 128x128 tile / 2 stages (default), 3 = 128x128 / 3 stages.  Returns the previous
+ * 1 = 256x128 tile / 3-stage ring, 2 = 128x128 tile / 2 stages, 3 = 128x128 / 3 stages, 4 (default) = 128x128 / 2 stages gathered
+ * through buffer descriptors (`buffer_load ... lds`, scalar tap bookkeeping) where C is a multiple of the K tile, else as 2.  Returns the previous
  * setting.  All variants are bit-identical to the register-staged kernel; measurements in DESIGN.md section 4. */
 int eg_set_igemm_dma(int on);
 /* dW partial slabs: slab[split][Cout][k*k][Cin] fp32.  Returns the split count through *nsplit. */

@@ -418,8 +418,8 @@ def test_igemm_dma_variant_matches_register_staged_kernel(dtype):
     K order) and within tolerance of torch, for a padded stride-2 forward conv and a 4-phase backward-data."""
     lib = eg._lib.lib()
     g = torch.Generator().manual_seed(21)
-    # forward: B=64, 64x64x32 -> 32x32x128  (M = 65536 -> 256 tiles)
-    B, H, Cin, Cout = 64, 64, 32, 128
+    # forward: B=64, 64x64x64 -> 32x32x128  (M = 65536 -> 512 tiles of 128)
+    B, H, Cin, Cout = 64, 64, 64, 128
     x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
     w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.05
     b = torch.randn(Cout, generator=g)
@@ -428,15 +428,15 @@ def test_igemm_dma_variant_matches_register_staged_kernel(dtype):
     ops.pack_fwd(c, dtype, w.to(DEV), wp)
     xd = nhwc(x, dtype)
     outs = []
-    for on in (1, 2, 0):
+    for on in (1, 2, 3, 4, 0):
         lib.query("eg_set_igemm_dma", on)
-        assert lib.query("eg_igemm_nt_tile", B * 32 * 32, Cout, 1) == {1: 256128, 2: 128129, 0: 128128}[on]
+        assert lib.query("eg_igemm_nt_tile", dtype, B * 32 * 32, Cout, Cin, 16 * Cin, 1) == {1: 256128, 2: 128129, 3: 128130, 4: 128131, 0: 128128}[on]
         y = torch.zeros(B, 32, 32, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
         ops.conv_fwd(c, dtype, xd, wp, y, ops.epilogue(bias=b.to(DEV), act=ops.ACT_LRELU, slope=0.2))
         torch.cuda.synchronize()
         outs.append(y)
-    lib.query("eg_set_igemm_dma", 2)
-    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
+    lib.query("eg_set_igemm_dma", 4)
+    assert all(torch.equal(o, outs[-1]) for o in outs[:-1])
     want = F.leaky_relu(F.conv2d(x, rq(w, dtype), b, 2, 1), 0.2)
     rt, at = tol(dtype, Cin * 16)
     torch.testing.assert_close(nchw(outs[0]), want, rtol=rt, atol=at)
@@ -450,17 +450,44 @@ def test_igemm_dma_variant_matches_register_staged_kernel(dtype):
     ops.pack_bwd(c, dtype, w.to(DEV), wp)
     sig = torch.tensor([1.3, 0.7], device=DEV)
     outs = []
-    for on in (1, 2, 0):
+    for on in (1, 2, 3, 4, 0):
         lib.query("eg_set_igemm_dma", on)
         dx = torch.zeros(B, H, H, Cin, device=DEV, dtype=ops.torch_dtype(dtype))
         ops.conv_bwd_data(c, dtype, nhwc(dy, dtype), wp, dx,
                           ops.epilogue(sigma=sig, sigma_rows=8 * 32 * 32, mask=nhwc(a, dtype), mask_act=ops.ACT_LRELU, mask_slope=0.1))
         torch.cuda.synchronize()
         outs.append(dx)
-    lib.query("eg_set_igemm_dma", 2)
-    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
+    lib.query("eg_set_igemm_dma", 4)
+    assert all(torch.equal(o, outs[-1]) for o in outs[:-1])
     want = F.conv_transpose2d(dy, rq(w, dtype), None, 2, 1) * torch.where(a > 0, 1.0, 0.1)
     want[:8] /= 1.3
     want[8:] /= 0.7
     rt, at = tol(dtype, Cout * 4)
     torch.testing.assert_close(nchw(outs[0]), want, rtol=rt, atol=at)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_igemm_buf_variant_ragged_rows_and_k_padding(dtype):
+    """Buffer-descriptor LDS-DMA NT kernel on a launch whose last row tile is half empty (M = 1025*64) and whose 3x3 filter
+    leaves K = 9*64 unpadded but walks 9 taps with image borders on every side: bit-exact vs the register-staged kernel."""
+    lib = eg._lib.lib()
+    g = torch.Generator().manual_seed(22)
+    B, H, Cin, Cout = 1025, 8, 64, 128
+    x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    c = ops.make_conv(B, H, H, Cin, Cout, 3, 1, 1)
+    wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
+    ops.pack_fwd(c, dtype, w.to(DEV), wp)
+    xd = nhwc(x, dtype)
+    outs = []
+    for on in (4, 0):
+        lib.query("eg_set_igemm_dma", on)
+        y = torch.zeros(B, H, H, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
+        ops.conv_fwd(c, dtype, xd, wp, y, ops.epilogue())
+        torch.cuda.synchronize()
+        outs.append(y)
+    lib.query("eg_set_igemm_dma", 4)
+    assert torch.equal(outs[0], outs[1])
+    want = F.conv2d(x[:64], rq(w, dtype), None, 1, 1)
+    rt, at = tol(dtype, Cin * 9)
+    torch.testing.assert_close(nchw(outs[0][:64]), want, rtol=rt, atol=at)
