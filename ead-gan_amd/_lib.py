@@ -27,7 +27,8 @@ class EgConv(ctypes.Structure):
 class EgEpilogue(ctypes.Structure):
     _fields_ = [("bias", ctypes.c_void_p), ("bias_mod", ctypes.c_int), ("sigma", ctypes.c_void_p),
                 ("act", ctypes.c_int), ("slope", ctypes.c_float), ("mask", ctypes.c_void_p),
-                ("mask_act", ctypes.c_int), ("mask_slope", ctypes.c_float), ("out_mode", ctypes.c_int), ("sigma_rows", ctypes.c_int)]
+                ("mask_act", ctypes.c_int), ("mask_slope", ctypes.c_float), ("out_mode", ctypes.c_int), ("sigma_rows", ctypes.c_int),
+                ("splitk_ws", ctypes.c_void_p), ("splitk_ws_bytes", ctypes.c_size_t)]
 
 
 class EgSnLayer(ctypes.Structure):

@@ -7,6 +7,7 @@
 // Both run in fp32 (v_mfma_f32_16x16x4_f32, exact fp32) or bf16 (v_mfma_f32_16x16x32_bf16, fp32
 // accumulate).  K rows in LDS are always 128 bytes (32 fp32 / 64 bf16) and XOR-swizzled in 16-byte
 // chunks so that ds_read_b128 fragment reads are bank-conflict free without padding.
+#include <algorithm>
 #include <type_traits>
 
 #include "eg_common.h"
@@ -41,6 +42,9 @@ struct NtParams {
     int out_mode;
     int sigma_rows;
     int M;
+    float* part;      // split-K partial tiles [split][phase][Mpad][N] fp32 (nsplit > 1)
+    size_t part_bytes;
+    int nsplit;
     NtPhase ph[4];
 };
 
@@ -586,7 +590,9 @@ __global__ __launch_bounds__(256) void igemm_nt_buf_kernel(const NtParams p) {
     constexpr int TM = 4, TN = 4;                  // waves 2 x 2, wave tile 64 x 64
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const NtPhase ph = p.ph[blockIdx.z];
+    const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
+    const int phase = blockIdx.z / nsplit, split = blockIdx.z - phase * nsplit;
+    const NtPhase ph = p.ph[phase];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -624,17 +630,27 @@ __global__ __launch_bounds__(256) void igemm_nt_buf_kernel(const NtParams p) {
     }
     const u32x4_t srdA = eg_make_srd(p.src, (unsigned)((size_t)p.B * p.H * p.W * p.C * sizeof(T)));
     const u32x4_t srdB = eg_make_srd(reinterpret_cast<const T*>(p.wp) + ph.w_off, (unsigned)((size_t)p.N * ph.Kpad * sizeof(T)));
-    const int nk = ph.Kpad / BK;
+    // this block's K steps [kt0, kt0 + nk)
+    const int nk_all = ph.Kpad / BK;
+    const int per = (nk_all + nsplit - 1) / nsplit;
+    const int kt0 = split * per;
+    const int nk = min(per, nk_all - kt0);
 
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)wave * 1024u;
     // wave-uniform walk over (tap, channel block)
-    int ty = 0, tx = 0;
-    unsigned kc_bytes = 0;
-    tap_offsets(0, 0);
+    const int steps_per_tap = p.C / BK;
+    const int tap0 = kt0 / steps_per_tap;
+    int ty = tap0 / ph.TW, tx = tap0 - ty * ph.TW;
+    unsigned kc_bytes = (unsigned)(kt0 - tap0 * steps_per_tap) * 128u;
+    if (ty < ph.TH) tap_offsets(ty, tx);
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) va[j] = EG_OOB;
+    }
     auto issue = [&](int kt, int stage) {
         const unsigned sa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)stage * STAGE);
         eg_bufdma4(srdA, va[0], va[1], va[2], va[3], kc_bytes, sa);
-        eg_bufdma4(srdB, vb[0], vb[1], vb[2], vb[3], (unsigned)kt * 128u, sa + BM * 128);
+        eg_bufdma4(srdB, vb[0], vb[1], vb[2], vb[3], (unsigned)(kt0 + kt) * 128u, sa + BM * 128);
         kc_bytes += 128u;
         if (kc_bytes >= row_bytes) {               // next tap (uniform branch)
             kc_bytes = 0;
@@ -675,8 +691,70 @@ __global__ __launch_bounds__(256) void igemm_nt_buf_kernel(const NtParams p) {
             }
         }
     }
+    if (nsplit > 1) {
+        // raw fp32 partial tile; nt_splitk_epilogue_kernel sums the splits and applies the epilogue
+        const int nphase = gridDim.z / nsplit;
+        float* part = p.part + ((size_t)(split * nphase + phase) * (gridDim.x * BM) + m0) * p.N + n0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = (wm * TM + i) * 16 + frow;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                *reinterpret_cast<f32x4*>(part + (size_t)row * p.N + (wn * TN + j) * 16 + fq * 4) = acc[i][j];
+        }
+        return;
+    }
     __syncthreads();
     nt_epilogue_lds<T, BM, BN, TM, TN>(p, ph, acc, smem, m0, n0, wm, wn, tid, frow, fq);
+}
+
+// sum of the split-K partial tiles + the fused epilogue (1/sigma, bias, activation, activation-gradient mask), NHWC store
+template <typename T>
+__global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(const NtParams p, int nphase, int Mpad) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int vpr = p.N / VEC;
+    const long long total = (long long)nphase * p.M * vpr;
+    const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
+    const T* __restrict__ mask = reinterpret_cast<const T*>(p.mask);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int vc = (int)(i % vpr);
+        const long long r = i / vpr;
+        const int m = (int)(r % p.M), phase = (int)(r / p.M);
+        const int n = vc * VEC;
+        float f[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) f[q] = 0.f;
+        for (int sp = 0; sp < p.nsplit; ++sp) {
+            const float* src = p.part + ((size_t)(sp * nphase + phase) * Mpad + m) * p.N + n;
+#pragma unroll
+            for (int q = 0; q < VEC / 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+                f[4 * q] += v.x; f[4 * q + 1] += v.y; f[4 * q + 2] += v.z; f[4 * q + 3] += v.w;
+            }
+        }
+        const float inv_sigma = p.sigma ? 1.f / p.sigma[p.sigma_rows ? m / p.sigma_rows : 0] : 1.f;
+        const int b = m >> (p.lOW + p.lOH);
+        const int y = ((m >> p.lOW) & OHm) * p.osy + p.ph[phase].ooy;
+        const int x = (m & OWm) * p.osx + p.ph[phase].oox;
+        const size_t o = (((size_t)b * p.DH + y) * p.DW + x) * p.N + n;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            float v = f[q] * inv_sigma;
+            if (p.bias) v += p.bias[p.bias_mod ? (n + q) % p.bias_mod : n + q];
+            f[q] = eg_act(v, p.act, p.slope);
+        }
+        if (mask) {
+            const uint4 mv = *reinterpret_cast<const uint4*>(mask + o);
+            const T* me = reinterpret_cast<const T*>(&mv);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) f[q] *= eg_act_grad_from_out(Elt<T>::ld(me + q), p.mask_act, p.mask_slope);
+        }
+        uint4 ov;
+        T* oe = reinterpret_cast<T*>(&ov);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) Elt<T>::st(oe + q, f[q]);
+        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.dst) + o) = ov;
+    }
 }
 
 // 0: register-staged kernels only; 1: 256x128 / 3-stage DMA ring; 2: 128x128 / 2-stage DMA (default: +2 % whole-step, bit-exact);
@@ -684,13 +762,34 @@ __global__ __launch_bounds__(256) void igemm_nt_buf_kernel(const NtParams p) {
 static int g_use_dma = 4;
 extern "C" int eg_set_igemm_dma(int on) { const int old = g_use_dma; g_use_dma = on; return old; }
 
-static bool buf_eligible(const NtParams& p, int nphase, int vec, size_t esize) {
-    if (g_use_dma != 4 || p.out_mode != EG_OUT_NHWC || (p.N % 128) != 0 || (p.C % (8 * vec)) != 0) return false;
-    if ((size_t)p.B * p.H * p.W * p.C * esize >= 0x7fffffffull) return false;
-    for (int i = 0; i < nphase; ++i)
-        if (p.ph[i].Kpad / (8 * vec) < 3 || (size_t)p.N * p.ph[i].Kpad * esize >= 0x7fffffffull) return false;
-    return (long long)cdiv(p.M, 128) * (p.N / 128) * nphase >= 512;
+// tuning knobs of the buffer-descriptor kernel: launches with fewer 128x128 tiles than g_buf_min_tiles go to the register-staged
+// kernels; launches below g_splitk_target tiles are split along K (when the caller lent a workspace) to reach that many blocks.
+static int g_buf_min_tiles = 512, g_splitk_target = 512;
+extern "C" int eg_set_igemm_tuning(int buf_min_tiles, int splitk_target) {
+    if (buf_min_tiles > 0) g_buf_min_tiles = buf_min_tiles;
+    if (splitk_target >= 0) g_splitk_target = splitk_target;
+    return 0;
 }
+
+// 0: not eligible; 1: one block per tile; > 1: split-K factor
+static int buf_plan(const NtParams& p, int nphase, int vec, size_t esize, size_t ws_bytes) {
+    if (g_use_dma != 4 || p.out_mode != EG_OUT_NHWC || (p.N % 128) != 0 || (p.C % (8 * vec)) != 0) return 0;
+    if ((size_t)p.B * p.H * p.W * p.C * esize >= 0x7fffffffull) return 0;
+    int nk_min = 1 << 30;
+    for (int i = 0; i < nphase; ++i) {
+        if (p.ph[i].Kpad / (8 * vec) < 3 || (size_t)p.N * p.ph[i].Kpad * esize >= 0x7fffffffull) return 0;
+        nk_min = std::min(nk_min, p.ph[i].Kpad / (8 * vec));
+    }
+    const long long tiles = (long long)cdiv(p.M, 128) * (p.N / 128) * nphase;
+    if (tiles < g_splitk_target && ws_bytes > 0) {
+        int ns = 1;
+        while (tiles * ns < g_splitk_target && ns < 16 && nk_min / (ns * 2) >= 8) ns *= 2;
+        while (ns > 1 && (size_t)ns * nphase * cdiv(p.M, 128) * 128 * p.N * 4 > ws_bytes) ns /= 2;
+        if (ns > 1) return ns;
+    }
+    return tiles >= g_buf_min_tiles ? 1 : 0;
+}
+static bool buf_eligible(const NtParams& p, int nphase, int vec, size_t esize) { return buf_plan(p, nphase, vec, esize, 0) == 1; }
 
 static bool dma_eligible(const NtParams& p, int nphase, int vec) {
     if (!g_use_dma || p.out_mode != EG_OUT_NHWC || (p.N % 128) != 0 || (p.N % vec) != 0) return false;
@@ -730,14 +829,21 @@ static void launch_nt_cfg(const NtParams& p, int nphase, hipStream_t st) {
 
 template <typename T>
 static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
-    if (buf_eligible(p, nphase, Elt<T>::VEC, sizeof(T))) {
+    if (const int ns = buf_plan(p, nphase, Elt<T>::VEC, sizeof(T), p.part ? p.part_bytes : 0)) {
         static bool attr_set = false;
         const size_t lds = 2 * (128 + 128) * 128;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_nt_buf_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-        hipLaunchKernelGGL((igemm_nt_buf_kernel<T>), dim3(cdiv(p.M, 128), p.N / 128, nphase), dim3(256), lds, st, p);
+        NtParams q = p;
+        q.nsplit = ns;
+        hipLaunchKernelGGL((igemm_nt_buf_kernel<T>), dim3(cdiv(p.M, 128), p.N / 128, nphase * ns), dim3(256), lds, st, q);
+        if (ns > 1) {
+            const long long vecs = (long long)nphase * p.M * (p.N / Elt<T>::VEC);
+            const int blocks = (int)std::min<long long>((vecs + 255) / 256, 256 * 16);
+            hipLaunchKernelGGL((nt_splitk_epilogue_kernel<T>), dim3(blocks), dim3(256), 0, st, q, nphase, cdiv(p.M, 128) * 128);
+        }
         return;
     }
     if (dma_eligible(p, nphase, Elt<T>::VEC)) {
@@ -761,7 +867,7 @@ extern "C" int eg_igemm_nt_tile(int dtype, int M, int N, int C, int K, int nphas
     NtParams p{};
     p.out_mode = EG_OUT_NHWC; p.M = M; p.N = N; p.C = C; p.B = 1; p.H = 1; p.W = 1;
     for (int i = 0; i < nphase && i < 4; ++i) p.ph[i].Kpad = round_up(K, bk);
-    if (buf_eligible(p, nphase, vec, dtype == EG_F32 ? 4 : 2)) return 128 * 1000 + 131;
+    if (const int ns = buf_plan(p, nphase, vec, dtype == EG_F32 ? 4 : 2, (size_t)1 << 40)) return 128 * 1000 + (ns > 1 ? 132 : 131);
     if (dma_eligible(p, nphase, vec)) return g_use_dma == 1 ? 256 * 1000 + 128 : (g_use_dma == 3 ? 128 * 1000 + 130 : 128 * 1000 + 129);
     if (N <= 16) return 128 * 1000 + 16;
     if (N <= 32) return 128 * 1000 + 32;
@@ -780,6 +886,8 @@ static void fill_epilogue(NtParams& p, const eg_epilogue* ep) {
     p.mask_slope = ep ? ep->mask_slope : 0.f;
     p.out_mode = ep ? ep->out_mode : EG_OUT_NHWC;
     p.sigma_rows = ep ? ep->sigma_rows : 0;
+    p.part = ep ? reinterpret_cast<float*>(ep->splitk_ws) : nullptr;
+    p.part_bytes = ep ? ep->splitk_ws_bytes : 0;
 }
 
 extern "C" int eg_conv_fwd(const eg_conv* c, int dtype, const void* X, const void* wp_fwd, void* Y,
@@ -809,6 +917,18 @@ extern "C" int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, con
     if (dtype == EG_F32) launch_nt<float>(p, nphase, (hipStream_t)s); else launch_nt<bf16_t>(p, nphase, (hipStream_t)s);
     EG_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" size_t eg_conv_splitk_ws_bytes(const eg_conv* c, int dtype, int bwd) {
+    if (!c || check_conv(c, dtype, bwd ? NEED_COUT : NEED_CIN)) return 0;
+    NtParams p;
+    memset(&p, 0, sizeof(p));
+    int nphase = 1;
+    if (bwd) { if (geom_bwd(c, dtype, p, &nphase)) return 0; }
+    else geom_fwd(c, dtype, p);
+    p.out_mode = EG_OUT_NHWC;
+    const int ns = buf_plan(p, nphase, vec_of(dtype), dtype == EG_F32 ? 4 : 2, (size_t)1 << 40);
+    return ns > 1 ? (size_t)ns * nphase * cdiv(p.M, 128) * 128 * p.N * 4 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -42,6 +42,9 @@ class Arena:
         return (self.grad if arena_grad is None else arena_grad)[off:off + k]
 
 
+SPLITK_WS_BYTES = 72 << 20
+
+
 class Workspace:
     """Scratch shared by every engine on a device (calls are stream-ordered, so one copy suffices).
     Grown only while engines are being built -- never inside a training step."""
@@ -55,6 +58,9 @@ class Workspace:
         self.small = torch.empty(0, device=device, dtype=torch.float32)
         self.partials = torch.empty(max(2048, ops.sn_partials()), device=device, dtype=torch.float32)
         self.sums = torch.empty(0, device=device, dtype=torch.float32)
+        # split-K partial tiles of the NT kernel: the planner splits up to ~2x512 tiles of 128x128 fp32 (64 KiB each)
+        self.splitk = torch.empty(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)
+        ops.set_splitk_workspace(self.splitk)
 
     @classmethod
     def get(cls, device) -> "Workspace":

@@ -44,9 +44,23 @@ def make_conv(B, H, W, Cin, Cout, k, stride, pad, up=0) -> EgConv:
     return EgConv(B, H, W, Cin, Cout, k, stride, pad, up)
 
 
+# scratch lent to every conv launch for split-K (engine.Workspace owns and sizes it while engines are built)
+SPLITK_WS = {}
+
+
+def set_splitk_workspace(t):
+    SPLITK_WS[t.device.index] = t
+
+
+def conv_splitk_ws_bytes(c, dtype, bwd):
+    return lib().query("eg_conv_splitk_ws_bytes", ctypes.byref(c), dtype, int(bwd))
+
+
 def epilogue(bias=None, bias_mod=0, sigma=None, act=ACT_NONE, slope=0.0, mask=None, mask_act=ACT_NONE,
              mask_slope=0.0, out_mode=OUT_NHWC, sigma_rows=0) -> EgEpilogue:
-    return EgEpilogue(_p(bias), bias_mod, _p(sigma), act, slope, _p(mask), mask_act, mask_slope, out_mode, sigma_rows)
+    ws = SPLITK_WS.get(torch.cuda.current_device()) if SPLITK_WS else None
+    return EgEpilogue(_p(bias), bias_mod, _p(sigma), act, slope, _p(mask), mask_act, mask_slope, out_mode, sigma_rows,
+                      _p(ws), ws.numel() * ws.element_size() if ws is not None else 0)
 
 
 # ---- implicit-GEMM family ------------------------------------------------------------------------
@@ -106,6 +120,8 @@ def _timed(kind, c, dtype, args):
 
 
 def conv_fwd(c, dtype, X, wp, Y, ep=None):
+    if ep is None:
+        ep = epilogue()          # carries the split-K scratch
     args = ("eg_conv_fwd", ctypes.byref(c), dtype, _p(X), _p(wp), _p(Y), ctypes.byref(ep) if ep is not None else None)
     if RECORDER is not None:
         return _timed("fwd", c, dtype, args)
@@ -113,6 +129,8 @@ def conv_fwd(c, dtype, X, wp, Y, ep=None):
 
 
 def conv_bwd_data(c, dtype, dY, wp, dX, ep=None):
+    if ep is None:
+        ep = epilogue()
     args = ("eg_conv_bwd_data", ctypes.byref(c), dtype, _p(dY), _p(wp), _p(dX), ctypes.byref(ep) if ep is not None else None)
     if RECORDER is not None:
         return _timed("bwd", c, dtype, args)

@@ -57,6 +57,8 @@ typedef struct eg_epilogue {
     float mask_slope;
     int out_mode;
     int sigma_rows;
+    void* splitk_ws;          /* optional caller-owned scratch: lets small-M / deep-K launches split K across workgroups */
+    size_t splitk_ws_bytes;   /* (fp32 partial tiles, summed in a fixed order by a second launch); NULL / 0 = never split */
 } eg_epilogue;
 
 /* --- implicit-GEMM convolution family (MFMA) ---------------------------------------------------
@@ -81,6 +83,11 @@ int eg_igemm_nt_tile(int dtype, int M, int N, int C, int K, int nphase);
  * through buffer descriptors (`buffer_load ... lds`, scalar tap bookkeeping) where C is a multiple of the K tile, else as 2.  Returns the previous
  * setting.  All variants are bit-identical to the register-staged kernel; measurements in DESIGN.md section 4. */
 int eg_set_igemm_dma(int on);
+/* dispatch thresholds of the buffer-descriptor kernel, in 128x128 tiles per launch: below buf_min_tiles the register-staged kernels
+ * run; below splitk_target (and with eg_epilogue.splitk_ws lent) K is split to reach that many workgroups.  <= 0 / < 0 keep. */
+int eg_set_igemm_tuning(int buf_min_tiles, int splitk_target);
+/* bytes of eg_epilogue.splitk_ws that let eg_conv_fwd (bwd = 0) / eg_conv_bwd_data (bwd = 1) split as far as the policy wants */
+size_t eg_conv_splitk_ws_bytes(const eg_conv* c, int dtype, int bwd);
 /* dW partial slabs: slab[split][Cout][k*k][Cin] fp32.  Returns the split count through *nsplit. */
 size_t eg_conv_wgrad_ws_bytes(const eg_conv* c, int dtype);
 int eg_conv_wgrad(const eg_conv* c, int dtype, const void* X, const void* dY, float* slab, int* nsplit,

@@ -117,8 +117,9 @@ def spectral_weight(d, prefix, training=True):
     return w / sigma
 
 
-def generator_forward(G, noise, labels, code):
-    """EAD-GAN_celebA.py:95-102.  First ConvT has no BN and no activation (:76-78)."""
+def generator_forward(G, noise, labels, code, taps=None):
+    """EAD-GAN_celebA.py:95-102.  First ConvT has no BN and no activation (:76-78).  ``taps`` (a list) receives the three
+    post-ReLU activations (tests use their signs to tell rounding-induced ReLU flips from real gradient errors)."""
     x = torch.cat((noise, labels, code), -1)
     x = x.view(x.size(0), x.size(1), 1, 1)
     x = F.conv_transpose2d(x, G["conv_blocks.0.weight"], G["conv_blocks.0.bias"], 1, 0)
@@ -127,6 +128,8 @@ def generator_forward(G, noise, labels, code):
         x = F.conv_transpose2d(x, G[f"conv_blocks.{idx}.weight"], G[f"conv_blocks.{idx}.bias"], 2, 1)
         x = batchnorm_train(x, G, f"conv_blocks.{idx + 1}.")
         x = F.relu(x)
+        if taps is not None:
+            taps.append(x.detach())
         idx += 3
     x = F.conv_transpose2d(x, G[f"conv_blocks.{idx}.weight"], G[f"conv_blocks.{idx}.bias"], 2, 1)
     return torch.tanh(x)

@@ -130,10 +130,12 @@ def test_discriminator_three_forwards_then_backward_fp32():
     douts = [torch.randn(B, 19, generator=g) for _ in range(3)]
     leaves = [im.clone().requires_grad_(True) for im in imgs]
     total = 0
+    acts = [[] for _ in range(4)]
     for t in range(3):
         x = leaves[t]
         for i in range(4):
             x = F.leaky_relu(F.conv2d(x, co.spectral_weight(orc.D, f"main.{2 * i}."), orc.D[f"main.{2 * i}.bias"], 2, 1), 0.1)
+            acts[i].append(x.detach())
         total = total + (F.conv2d(x, orc.D["main.8.weight"], orc.D["main.8.bias"]).squeeze() * douts[t]).sum()
     total.backward()
     # (a) the three forwards batched into single launches (what the trainer does), one batched backward
@@ -141,10 +143,17 @@ def test_discriminator_three_forwards_then_backward_fp32():
     assert out.shape == (3 * B, 19)
     grad = torch.zeros_like(D.arena.grad)
     dimg = de.backward(0, 3, torch.cat(douts).to(DEV).contiguous(), grad, need_wgrad=True, need_dimg=True)
-    assert rel_err(dimg, leaves[0].grad) < 2e-4
+    # A LeakyReLU unit whose pre-activation is within fp32 rounding of 0 can land on the other side of 0 than in torch
+    # (different summation order); ONE such unit among the 4.7 M moves every upstream gradient by ~1.5e-3 (measured), so
+    # the tight bound is asserted when the activation signs agree and a per-flip allowance is added otherwise.
+    count_flips = lambda e: sum(int(((e.a[i].permute(0, 3, 1, 2).float().cpu() > 0) != (torch.cat(acts[i]) > 0)).sum()) for i in range(4))
+    flips = count_flips(de)
+    assert flips <= 3, flips
+    gtol = 2e-4 + 4e-3 * flips
+    assert rel_err(dimg, leaves[0].grad) < gtol
     for k in dict(D.named_parameters()):
         off, n = D.arena.slices[k]
-        assert rel_err(grad[off:off + n], orc.D[k].grad) < 2e-4, k
+        assert rel_err(grad[off:off + n], orc.D[k].grad) < gtol, (k, flips)
     for i in range(4):
         assert rel_err(D.state_dict()[f"main.{2 * i}.weight_u"], orc.D[f"main.{2 * i}.weight_u"]) < 1e-4
     # (b) same weights, tapes run one at a time (eager drop-in path) -> per-tape image gradients
@@ -152,11 +161,13 @@ def test_discriminator_three_forwards_then_backward_fp32():
     de2 = D2.engine(B)
     for t in range(3):
         de2.forward([imgs[t].to(DEV)], t)
+    flips2 = count_flips(de2)
+    assert flips2 <= 3, flips2
     grad2 = torch.zeros_like(D2.arena.grad)
     for t in (2, 1, 0):
         dimg = de2.backward(t, 1, douts[t].to(DEV).contiguous(), grad2, need_wgrad=True, need_dimg=True)
-        assert rel_err(dimg, leaves[t].grad) < 2e-4, t
-    assert rel_err(grad2, grad) < 1e-5
+        assert rel_err(dimg, leaves[t].grad) < 2e-4 + 4e-3 * flips2, t
+    assert rel_err(grad2, grad) < 1e-5 + 4e-3 * (flips + flips2)
 
 
 def test_generator_backward_from_given_image_gradient_fp32():
@@ -165,7 +176,8 @@ def test_generator_backward_from_given_image_gradient_fp32():
     rng = np.random.RandomState(3)
     z, code, labels = co.draw_step_inputs(rng, B)
     onehot = F.one_hot(labels, 10).float()
-    want = co.generator_forward(orc.G, z, onehot, code)
+    taps = []
+    want = co.generator_forward(orc.G, z, onehot, code, taps)
     dimg = torch.randn(want.shape, generator=torch.Generator().manual_seed(1)) * 1e-3
     want.backward(dimg)
     ge = G.engine(B)
@@ -173,11 +185,15 @@ def test_generator_backward_from_given_image_gradient_fp32():
     assert rel_err(got, want) < 2e-5
     grad = torch.zeros_like(G.arena.grad)
     ge.backward(dimg.to(DEV), grad)
+    # a BatchNorm output within fp32 rounding of 0 may take the other ReLU branch than in torch (summation order); one such
+    # unit among 1.8 M moves the upstream gradients by ~2e-3 (measured) -> tight bound when the masks agree, allowance per flip
+    flips = sum(int(((ge.a[i].permute(0, 3, 1, 2).float().cpu() > 0) != (taps[i] > 0)).sum()) for i in range(3))
+    assert flips <= 3, flips
     for k in dict(G.named_parameters()):
         if k in PRE_BN_BIAS:
             continue
         off, n = G.arena.slices[k]
-        assert rel_err(grad[off:off + n], orc.G[k].grad) < 1e-4, k
+        assert rel_err(grad[off:off + n], orc.G[k].grad) < 1e-4 + 4e-3 * flips, (k, flips)
 
 
 def test_train_step_gradients_fp32():

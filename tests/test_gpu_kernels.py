@@ -491,3 +491,69 @@ def test_igemm_buf_variant_ragged_rows_and_k_padding(dtype):
     want = F.conv2d(x[:64], rq(w, dtype), None, 1, 1)
     rt, at = tol(dtype, Cin * 9)
     torch.testing.assert_close(nchw(outs[0][:64]), want, rtol=rt, atol=at)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_igemm_splitk_small_m_deep_k(dtype):
+    """Few-row / deep-K launches (the last Discriminator conv: celebA/EAD-GAN_celebA.py:118) split K across workgroups into fp32
+    partial tiles that a second launch sums in a fixed order before the fused epilogue: forward (bias + LeakyReLU) and 4-phase
+    backward-data (1/sigma per tape + activation-gradient mask) against torch, and repeatable bit for bit."""
+    lib = eg._lib.lib()
+    ops.set_splitk_workspace(torch.empty(16 << 20, device=DEV, dtype=torch.float32))
+    g = torch.Generator().manual_seed(23)
+    B, H, Cin, Cout = 24, 8, 256, 256
+    c = ops.make_conv(B, H, H, Cin, Cout, 4, 2, 1)
+    assert ops.conv_splitk_ws_bytes(c, dtype, 0) > 0 and ops.conv_splitk_ws_bytes(c, dtype, 1) > 0
+    assert lib.query("eg_igemm_nt_tile", dtype, B * 16, Cout, Cin, 16 * Cin, 1) == 128132
+    x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
+    w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.03
+    b = torch.randn(Cout, generator=g)
+    wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
+    ops.pack_fwd(c, dtype, w.to(DEV), wp)
+    ys = []
+    for _ in range(2):
+        y = torch.zeros(B, 4, 4, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
+        ops.conv_fwd(c, dtype, nhwc(x, dtype), wp, y, ops.epilogue(bias=b.to(DEV), act=ops.ACT_LRELU, slope=0.2))
+        torch.cuda.synchronize()
+        ys.append(y)
+    assert torch.equal(ys[0], ys[1])
+    want = F.leaky_relu(F.conv2d(x, rq(w, dtype), b, 2, 1), 0.2)
+    rt, at = tol(dtype, Cin * 16)
+    torch.testing.assert_close(nchw(ys[0]), want, rtol=rt, atol=at)
+    # backward-data of the same layer, two tapes of 12 images
+    dy = rq(torch.randn(B, Cout, 4, 4, generator=g), dtype)
+    a = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
+    wpb = torch.empty(ops.pack_bwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
+    ops.pack_bwd(c, dtype, w.to(DEV), wpb)
+    sig = torch.tensor([1.3, 0.7], device=DEV)
+    dx = torch.zeros(B, H, H, Cin, device=DEV, dtype=ops.torch_dtype(dtype))
+    ops.conv_bwd_data(c, dtype, nhwc(dy, dtype), wpb, dx,
+                      ops.epilogue(sigma=sig, sigma_rows=12 * 16, mask=nhwc(a, dtype), mask_act=ops.ACT_LRELU, mask_slope=0.1))
+    torch.cuda.synchronize()
+    want = F.conv_transpose2d(dy, rq(w, dtype), None, 2, 1) * torch.where(a > 0, 1.0, 0.1)
+    want[:12] /= 1.3
+    want[12:] /= 0.7
+    rt, at = tol(dtype, Cout * 4)
+    torch.testing.assert_close(nchw(dx), want, rtol=rt, atol=at)
+    ops.SPLITK_WS.clear()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_igemm_splitk_range_starting_inside_a_tap(dtype):
+    """3x3 conv whose K split boundaries fall inside filter taps (9 taps x 256 channels, 4 splits of 9 (bf16) / 18 (fp32) K steps
+    against 4 / 8 steps per tap): the per-split start state (tap, channel offset) must be reconstructed exactly."""
+    ops.set_splitk_workspace(torch.empty(16 << 20, device=DEV, dtype=torch.float32))
+    g = torch.Generator().manual_seed(24)
+    B, H, Cin, Cout = 8, 8, 256, 128
+    c = ops.make_conv(B, H, H, Cin, Cout, 3, 1, 1)
+    assert ops.conv_splitk_ws_bytes(c, dtype, 0) > 0
+    x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.03
+    wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
+    ops.pack_fwd(c, dtype, w.to(DEV), wp)
+    y = torch.zeros(B, H, H, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
+    ops.conv_fwd(c, dtype, nhwc(x, dtype), wp, y, ops.epilogue())
+    torch.cuda.synchronize()
+    ops.SPLITK_WS.clear()
+    rt, at = tol(dtype, Cin * 9)
+    torch.testing.assert_close(nchw(y), F.conv2d(x, rq(w, dtype), None, 1, 1), rtol=rt, atol=at)
