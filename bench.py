@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--force-dist", action="store_true", help="initialise a process group and run the all-reduce hooks even with one rank "
                                                               "(rehearses the N>1 code path, incl. RCCL capture into the hipGraph, on one GPU)")
+    ap.add_argument("--igemm-tuning", default="", help="buf_min_tiles,splitk_target,big_min_tiles for eg_set_igemm_tuning (experiments)")
     ap.add_argument("--igemm-dma", type=int, default=4, help="LDS-DMA staged NT kernel variant for large launches (0 off, 1 = 256x128x3, 2 = 128x128x2, 3 = 128x128x3, 4 = buffer-descriptor 128x128x2 [default])")
     ap.add_argument("--workload", default="celeba", choices=["celeba", "mnist", "dsprites", "colored"],
                     help="celeba = the headline metric (default); mnist = BASELINE config[1] (use --batch 256 --dtype f32); "
@@ -212,6 +213,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
     eg._lib.lib().query("eg_set_igemm_dma", a.igemm_dma)
+    if a.igemm_tuning:
+        eg._lib.lib().query("eg_set_igemm_tuning", *[int(v) for v in a.igemm_tuning.split(",")])
     dev = torch.device("cuda", local)
     B = a.batch
     if a.workload == "mnist":

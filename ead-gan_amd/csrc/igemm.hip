@@ -52,6 +52,13 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline int bk_of(int dtype) { return dtype == EG_F32 ? 32 : 64; }
 static inline int vec_of(int dtype) { return dtype == EG_F32 ? 4 : 8; }
 
+// K extent of a packed weight panel row: K rounded up to the K tile.  (Skewing pitches that are multiples of 2 KiB by one extra tile
+// was tried against L2 channel aliasing of the 128-byte column slices: no effect on MI355X.)
+static int kpad_of(int K, int N, int dtype) {
+    (void)N;
+    return round_up(K > 0 ? K : 1, bk_of(dtype));
+}
+
 static int conv_out_dim(const eg_conv* c, int in) { return ((in << c->up) + 2 * c->pad - c->k) / c->stride + 1; }
 
 enum { NEED_CIN = 1, NEED_COUT = 2 };
@@ -77,7 +84,7 @@ static void geom_fwd(const eg_conv* c, int dtype, NtParams& p) {
     p.M = c->B * OH * OW;
     NtPhase& f = p.ph[0];
     f.TH = f.TW = c->k; f.dy0 = f.dx0 = -c->pad; f.dys = f.dxs = 1; f.ooy = f.oox = 0;
-    f.K = c->k * c->k * c->Cin; f.Kpad = round_up(f.K, bk_of(dtype)); f.w_off = 0;
+    f.K = c->k * c->k * c->Cin; f.Kpad = kpad_of(f.K, c->Cout, dtype); f.w_off = 0;
 }
 
 struct BwdAxis { int k0, T, d0; };   // first kernel index, tap count, source offset for tap 0 (then -1 per tap)
@@ -110,7 +117,7 @@ static int geom_bwd(const eg_conv* c, int dtype, NtParams& p, int* nphase) {
             const BwdAxis ay = bwd_axis(c, ry), ax = bwd_axis(c, rx);
             NtPhase& f = p.ph[n++];
             f.TH = ay.T; f.TW = ax.T; f.dy0 = ay.d0; f.dx0 = ax.d0; f.dys = f.dxs = -1; f.ooy = ry; f.oox = rx;
-            f.K = ay.T * ax.T * c->Cout; f.Kpad = round_up(f.K > 0 ? f.K : 1, bk_of(dtype)); f.w_off = off;
+            f.K = ay.T * ax.T * c->Cout; f.Kpad = kpad_of(f.K, c->Cin, dtype); f.w_off = off;
             off += (long long)c->Cin * f.Kpad;
         }
     *nphase = n;
@@ -366,42 +373,45 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
                  : "memory");
 }
 
-// shared epilogue of the LDS-DMA kernels: fp32 tile through LDS (XOR-swizzled 16-byte chunks), then 16-byte vector stores with the
-// fused 1/sigma, bias, activation and activation-gradient mask.  Callers __syncthreads() before (the K loop's LDS is reused).
-template <typename T, int BM, int BN, int TM, int TN>
-__device__ __forceinline__ void nt_epilogue_lds(const NtParams& p, const NtPhase& ph, f32x4 (&acc)[TM][TN], char* smem, int m0, int n0, int wm,
-                                                int wn, int tid, int frow, int fq) {
+// shared epilogue of the LDS-DMA kernels: a BM x BNW window of the fp32 tile goes through LDS (XOR-swizzled 16-byte chunks), then 16-byte
+// vector stores with the fused 1/sigma, bias, activation and activation-gradient mask.  Callers __syncthreads() before (the K loop's LDS
+// is reused).  row0 / col0: first row / first window column of the calling wave's accumulators (col0 < 0: wave outside the window);
+// nw0: global column of the window's first column; NT threads per workgroup.
+template <typename T, int BM, int BNW, int TM, int TN, int NT>
+__device__ __forceinline__ void nt_epilogue_lds(const NtParams& p, const NtPhase& ph, f32x4 (&acc)[TM][TN], char* smem, int m0, int nw0, int row0,
+                                                int col0, int tid, int frow, int fq) {
     constexpr int VEC = Elt<T>::VEC;
     const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
-    constexpr int CH = BN / 4;
     constexpr int SW = 31;
     float* ct = reinterpret_cast<float*>(smem);
+    if (col0 >= 0) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = (wm * TM + i) * 16 + frow;
-        const int mrow = min(m0 + row, p.M - 1);
-        const float inv_sigma = p.sigma ? 1.f / p.sigma[p.sigma_rows ? mrow / p.sigma_rows : 0] : 1.f;
+        for (int i = 0; i < TM; ++i) {
+            const int row = row0 + i * 16 + frow;
+            const int mrow = min(m0 + row, p.M - 1);
+            const float inv_sigma = p.sigma ? 1.f / p.sigma[p.sigma_rows ? mrow / p.sigma_rows : 0] : 1.f;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nl = (wn * TN + j) * 16 + fq * 4;
-            float4 v;
-            float* ve = reinterpret_cast<float*>(&v);
+            for (int j = 0; j < TN; ++j) {
+                const int nl = col0 + j * 16 + fq * 4;
+                float4 v;
+                float* ve = reinterpret_cast<float*>(&v);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = acc[i][j][r] * inv_sigma;
-                const int n = n0 + nl + r;
-                if (p.bias && n < p.N) x += p.bias[p.bias_mod ? n % p.bias_mod : n];
-                ve[r] = eg_act(x, p.act, p.slope);
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[i][j][r] * inv_sigma;
+                    const int n = nw0 + nl + r;
+                    if (p.bias && n < p.N) x += p.bias[p.bias_mod ? n % p.bias_mod : n];
+                    ve[r] = eg_act(x, p.act, p.slope);
+                }
+                *reinterpret_cast<float4*>(ct + row * BNW + (((nl >> 2) ^ (row & SW)) << 2)) = v;
             }
-            *reinterpret_cast<float4*>(ct + row * BN + (((nl >> 2) ^ (row & SW)) << 2)) = v;
         }
     }
     __syncthreads();
-    constexpr int VPR = BN / VEC;
-    constexpr int RPP = 256 / VPR;
+    constexpr int VPR = BNW / VEC;
+    constexpr int RPP = NT / VPR;
     const int vc = tid % VPR, vr = tid / VPR;
     const T* __restrict__ mask = reinterpret_cast<const T*>(p.mask);
-    const int n = n0 + vc * VEC;
+    const int n = nw0 + vc * VEC;
     if (n < p.N) {
 #pragma unroll 4
         for (int row = vr; row < BM; row += RPP) {
@@ -415,7 +425,7 @@ __device__ __forceinline__ void nt_epilogue_lds(const NtParams& p, const NtPhase
 #pragma unroll
             for (int q = 0; q < VEC / 4; ++q) {
                 const int chunk = (vc * (VEC / 4) + q) ^ (row & SW);
-                const float4 v = *reinterpret_cast<const float4*>(ct + row * BN + (chunk << 2));
+                const float4 v = *reinterpret_cast<const float4*>(ct + row * BNW + (chunk << 2));
                 f[q * 4 + 0] = v.x; f[q * 4 + 1] = v.y; f[q * 4 + 2] = v.z; f[q * 4 + 3] = v.w;
             }
             if (mask) {
@@ -537,7 +547,7 @@ __global__ __launch_bounds__(256) void igemm_nt_dma_kernel(const NtParams p) {
     }
     __syncthreads();
 
-    nt_epilogue_lds<T, BM, BN, TM, TN>(p, ph, acc, smem, m0, n0, wm, wn, tid, frow, fq);
+    nt_epilogue_lds<T, BM, BN, TM, TN, 256>(p, ph, acc, smem, m0, n0, wm * TM * 16, wn * TN * 16, tid, frow, fq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -705,7 +715,195 @@ __global__ __launch_bounds__(256) void igemm_nt_buf_kernel(const NtParams p) {
         return;
     }
     __syncthreads();
-    nt_epilogue_lds<T, BM, BN, TM, TN>(p, ph, acc, smem, m0, n0, wm, wn, tid, frow, fq);
+    nt_epilogue_lds<T, BM, BN, TM, TN, 256>(p, ph, acc, smem, m0, n0, wm * TM * 16, wn * TN * 16, tid, frow, fq);
+}
+
+// ------------------------------------------------------------------------------------------------
+// igemm_nt_big: the buffer-descriptor kernel on 256-row tiles with 8 waves (512 threads, one workgroup per CU).  The 128x128 kernel moves
+// 32 KiB from L2 into LDS per 2.1 MFLOP (64 FLOP/B) and saturates the L2 -> LDS path at ~600-700 TFLOP/s; 256x128 (3-stage ring, wave
+// tile 64x64) needs 85 FLOP/B and 256x256 (2 stages, wave tile 128x64) 128 FLOP/B.  DMA slot j of wave w covers tile rows (j*8+w)*8..+7.
+// ------------------------------------------------------------------------------------------------
+template <int STRIDE>
+__device__ __forceinline__ void eg_bufdma4s(const u32x4_t srd, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned soff, unsigned lds) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %7\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
+        "s_add_u32 m0, m0, %8\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %5, %6 offen lds\n\t"
+        "s_add_u32 m0, m0, %8\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %3, %5, %6 offen lds\n\t"
+        "s_add_u32 m0, m0, %8\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %4, %5, %6 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(srd), "s"(soff), "s"(lds), "i"(STRIDE)
+        : "memory", "scc");
+}
+template <int STRIDE>
+__device__ __forceinline__ void eg_bufdma2s(const u32x4_t srd, unsigned v0, unsigned v1, unsigned soff, unsigned lds) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+        "s_add_u32 m0, m0, %6\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(v0), "v"(v1), "s"(srd), "s"(soff), "s"(lds), "i"(STRIDE)
+        : "memory", "scc");
+}
+
+template <typename T, int BN, int WM, int NST>
+__global__ __launch_bounds__(512) void igemm_nt_big_kernel(const NtParams p) {
+    constexpr int VEC = Elt<T>::VEC;
+    constexpr int BK = 8 * VEC;
+    constexpr int BM = 256, WN = 64;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int WGN = BN / WN;                   // waves along N (2 or 4); WGM * WGN == 8
+    constexpr int B_SL = BN / 64;                  // B pieces per wave and stage (A: 4)
+    static_assert((BM / WM) * WGN == 8, "8 waves");
+    static_assert(NST == 2 || NST == 3, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
+    const int phase = blockIdx.z / nsplit, split = blockIdx.z - phase * nsplit;
+    const NtPhase ph = p.ph[phase];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
+    const int HU = p.H << p.up, WU = p.W << p.up;
+    const int rsub = lane >> 3, pos = lane & 7;
+    const int srcchunk = pos ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+
+    int a_pix0[4], a_y[4], a_x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + (j * 8 + wave) * 8 + rsub;
+        const int b = m >> (p.lOW + p.lOH);
+        a_pix0[j] = (m < p.M) ? b * p.H * p.W : -1;
+        a_y[j] = ((m >> p.lOW) & OHm) * p.sy + ph.dy0;
+        a_x[j] = (m & OWm) * p.sx + ph.dx0;
+    }
+    const unsigned row_bytes = (unsigned)p.C * sizeof(T);
+    unsigned va[4], vb[B_SL];
+    auto tap_offsets = [&](int ty, int tx) {
+        const int oy = ty * ph.dys, ox = tx * ph.dxs;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iy = a_y[j] + oy, ix = a_x[j] + ox;
+            const bool ok = a_pix0[j] >= 0 && iy >= 0 && iy < HU && ix >= 0 && ix < WU;
+            const unsigned pix = (unsigned)(a_pix0[j] + (iy >> p.up) * p.W + (ix >> p.up));
+            va[j] = ok ? pix * row_bytes + (unsigned)srcchunk * 16u : EG_OOB;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < B_SL; ++j) {
+        const int n = n0 + (j * 8 + wave) * 8 + rsub;
+        vb[j] = n < p.N ? (unsigned)n * (unsigned)ph.Kpad * (unsigned)sizeof(T) + (unsigned)srcchunk * 16u : EG_OOB;
+    }
+    const u32x4_t srdA = eg_make_srd(p.src, (unsigned)((size_t)p.B * p.H * p.W * p.C * sizeof(T)));
+    const u32x4_t srdB = eg_make_srd(reinterpret_cast<const T*>(p.wp) + ph.w_off, (unsigned)((size_t)p.N * ph.Kpad * sizeof(T)));
+    const int nk_all = ph.Kpad / BK;
+    const int per = (nk_all + nsplit - 1) / nsplit;
+    const int kt0 = split * per;
+    const int nk = min(per, nk_all - kt0);
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)wave * 1024u;
+    const int steps_per_tap = p.C / BK;
+    const int tap0 = kt0 / steps_per_tap;
+    int ty = tap0 / ph.TW, tx = tap0 - ty * ph.TW;
+    unsigned kc_bytes = (unsigned)(kt0 - tap0 * steps_per_tap) * 128u;
+    if (ty < ph.TH) tap_offsets(ty, tx);
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) va[j] = EG_OOB;
+    }
+    auto issue = [&](int kt, int stage) {
+        const unsigned sa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)stage * STAGE);
+        eg_bufdma4s<0x2000>(srdA, va[0], va[1], va[2], va[3], kc_bytes, sa);
+        if constexpr (B_SL == 4) eg_bufdma4s<0x2000>(srdB, vb[0], vb[1], vb[2], vb[3], (unsigned)(kt0 + kt) * 128u, sa + BM * 128);
+        else eg_bufdma2s<0x2000>(srdB, vb[0], vb[1], (unsigned)(kt0 + kt) * 128u, sa + BM * 128);
+        kc_bytes += 128u;
+        if (kc_bytes >= row_bytes) {               // next tap (uniform branch)
+            kc_bytes = 0;
+            if (++tx == ph.TW) { tx = 0; ++ty; }
+            if (ty < ph.TH) tap_offsets(ty, tx);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) va[j] = EG_OOB;
+            }
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    constexpr int AHEAD = NST - 1;
+#pragma unroll
+    for (int q = 0; q < AHEAD; ++q)
+        if (q < nk) issue(q, q);
+    int st_use = 0, st_fill = AHEAD % NST;
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt has landed once at most the pieces of the (AHEAD-1) younger stages are outstanding (4 + B_SL pieces per stage)
+        if (NST == 3 && kt + 1 < nk) {
+            if constexpr (B_SL == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // everyone's stage kt landed; everyone finished reading stage kt-1
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + AHEAD < nk) issue(kt + AHEAD, st_fill);
+        const char* sa = smem + st_use * STAGE;
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 bfr[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(sb + lds_off((wn * TN + j) * 16 + frow, ks * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const uint4 af = *reinterpret_cast<const uint4*>(sa + lds_off((wm * TM + i) * 16 + frow, ks * 4 + fq));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) mfma_step<T>(af, bfr[j], acc[i][j]);
+            }
+        }
+        st_use = st_use + 1 == NST ? 0 : st_use + 1;
+        st_fill = st_fill + 1 == NST ? 0 : st_fill + 1;
+    }
+    if (nsplit > 1) {
+        const int nphase = gridDim.z / nsplit;
+        float* part = p.part + ((size_t)(split * nphase + phase) * (gridDim.x * BM) + m0) * p.N + n0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = (wm * TM + i) * 16 + frow;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                *reinterpret_cast<f32x4*>(part + (size_t)row * p.N + (wn * TN + j) * 16 + fq * 4) = acc[i][j];
+        }
+        return;
+    }
+    __syncthreads();
+    if constexpr (BN == 128) {
+        nt_epilogue_lds<T, BM, 128, TM, TN, 512>(p, ph, acc, smem, m0, n0, wm * TM * 16, wn * TN * 16, tid, frow, fq);
+    } else {
+        // 256 x 256 fp32 does not fit the LDS: two 128-column windows
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int col0 = (wn >> 1) == h ? (wn & 1) * TN * 16 : -1;
+            nt_epilogue_lds<T, BM, 128, TM, TN, 512>(p, ph, acc, smem, m0, n0 + h * 128, wm * TM * 16, col0, tid, frow, fq);
+            __syncthreads();
+        }
+    }
 }
 
 // sum of the split-K partial tiles + the fused epilogue (1/sigma, bias, activation, activation-gradient mask), NHWC store
@@ -762,34 +960,42 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(const NtParams 
 static int g_use_dma = 4;
 extern "C" int eg_set_igemm_dma(int on) { const int old = g_use_dma; g_use_dma = on; return old; }
 
-// tuning knobs of the buffer-descriptor kernel: launches with fewer 128x128 tiles than g_buf_min_tiles go to the register-staged
-// kernels; launches below g_splitk_target tiles are split along K (when the caller lent a workspace) to reach that many blocks.
-static int g_buf_min_tiles = 512, g_splitk_target = 512;
-extern "C" int eg_set_igemm_tuning(int buf_min_tiles, int splitk_target) {
+// tuning knobs of the buffer-descriptor kernels (units: workgroups per launch).  128x128 kernel: launches with fewer tiles than
+// g_buf_min_tiles go to the register-staged kernels; launches below g_splitk_target tiles are split along K (when the caller lent a
+// workspace) to reach that many workgroups.  256-row kernel: taken when the launch has at least g_big_min_tiles of its tiles (0 = never).
+static int g_buf_min_tiles = 512, g_splitk_target = 512, g_big_min_tiles = 224;
+extern "C" int eg_set_igemm_tuning(int buf_min_tiles, int splitk_target, int big_min_tiles) {
     if (buf_min_tiles > 0) g_buf_min_tiles = buf_min_tiles;
     if (splitk_target >= 0) g_splitk_target = splitk_target;
+    if (big_min_tiles >= 0) g_big_min_tiles = big_min_tiles;
     return 0;
 }
 
-// 0: not eligible; 1: one block per tile; > 1: split-K factor
-static int buf_plan(const NtParams& p, int nphase, int vec, size_t esize, size_t ws_bytes) {
-    if (g_use_dma != 4 || p.out_mode != EG_OUT_NHWC || (p.N % 128) != 0 || (p.C % (8 * vec)) != 0) return 0;
-    if ((size_t)p.B * p.H * p.W * p.C * esize >= 0x7fffffffull) return 0;
+enum { NT_PLAN_NONE = 0, NT_PLAN_BUF128 = 1, NT_PLAN_BIG128 = 2, NT_PLAN_BIG256 = 3 };
+struct NtPlan { int kind, ns; };
+
+static NtPlan nt_plan(const NtParams& p, int nphase, int vec, size_t esize, size_t ws_bytes) {
+    const NtPlan none = {NT_PLAN_NONE, 1};
+    if (g_use_dma != 4 || p.out_mode != EG_OUT_NHWC || (p.N % 128) != 0 || (p.C % (8 * vec)) != 0) return none;
+    if ((size_t)p.B * p.H * p.W * p.C * esize >= 0x7fffffffull) return none;
     int nk_min = 1 << 30;
     for (int i = 0; i < nphase; ++i) {
-        if (p.ph[i].Kpad / (8 * vec) < 3 || (size_t)p.N * p.ph[i].Kpad * esize >= 0x7fffffffull) return 0;
+        if (p.ph[i].Kpad / (8 * vec) < 3 || (size_t)p.N * p.ph[i].Kpad * esize >= 0x7fffffffull) return none;
         nk_min = std::min(nk_min, p.ph[i].Kpad / (8 * vec));
+    }
+    if (g_big_min_tiles > 0) {
+        const int bn = (p.N % 256) == 0 ? 256 : 128;
+        if ((long long)cdiv(p.M, 256) * (p.N / bn) * nphase >= g_big_min_tiles) return {bn == 256 ? NT_PLAN_BIG256 : NT_PLAN_BIG128, 1};
     }
     const long long tiles = (long long)cdiv(p.M, 128) * (p.N / 128) * nphase;
     if (tiles < g_splitk_target && ws_bytes > 0) {
         int ns = 1;
         while (tiles * ns < g_splitk_target && ns < 16 && nk_min / (ns * 2) >= 8) ns *= 2;
         while (ns > 1 && (size_t)ns * nphase * cdiv(p.M, 128) * 128 * p.N * 4 > ws_bytes) ns /= 2;
-        if (ns > 1) return ns;
+        if (ns > 1) return {NT_PLAN_BUF128, ns};
     }
-    return tiles >= g_buf_min_tiles ? 1 : 0;
+    return tiles >= g_buf_min_tiles ? NtPlan{NT_PLAN_BUF128, 1} : none;
 }
-static bool buf_eligible(const NtParams& p, int nphase, int vec, size_t esize) { return buf_plan(p, nphase, vec, esize, 0) == 1; }
 
 static bool dma_eligible(const NtParams& p, int nphase, int vec) {
     if (!g_use_dma || p.out_mode != EG_OUT_NHWC || (p.N % 128) != 0 || (p.N % vec) != 0) return false;
@@ -829,7 +1035,25 @@ static void launch_nt_cfg(const NtParams& p, int nphase, hipStream_t st) {
 
 template <typename T>
 static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
-    if (const int ns = buf_plan(p, nphase, Elt<T>::VEC, sizeof(T), p.part ? p.part_bytes : 0)) {
+    const NtPlan plan = nt_plan(p, nphase, Elt<T>::VEC, sizeof(T), p.part ? p.part_bytes : 0);
+    if (plan.kind == NT_PLAN_BIG128 || plan.kind == NT_PLAN_BIG256) {
+        static bool attr_set[2] = {false, false};
+        const bool wide = plan.kind == NT_PLAN_BIG256;
+        const size_t lds = wide ? 2 * (256 + 256) * 128 : 3 * (256 + 128) * 128;
+        const void* fn = wide ? reinterpret_cast<const void*>(&igemm_nt_big_kernel<T, 256, 128, 2>) : reinterpret_cast<const void*>(&igemm_nt_big_kernel<T, 128, 64, 3>);
+        if (!attr_set[wide]) {
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set[wide] = true;
+        }
+        NtParams q = p;
+        q.nsplit = 1;
+        const dim3 grid(cdiv(p.M, 256), p.N / (wide ? 256 : 128), nphase);
+        if (wide) hipLaunchKernelGGL((igemm_nt_big_kernel<T, 256, 128, 2>), grid, dim3(512), lds, st, q);
+        else hipLaunchKernelGGL((igemm_nt_big_kernel<T, 128, 64, 3>), grid, dim3(512), lds, st, q);
+        return;
+    }
+    if (plan.kind == NT_PLAN_BUF128) {
+        const int ns = plan.ns;
         static bool attr_set = false;
         const size_t lds = 2 * (128 + 128) * 128;
         if (!attr_set) {
@@ -867,7 +1091,10 @@ extern "C" int eg_igemm_nt_tile(int dtype, int M, int N, int C, int K, int nphas
     NtParams p{};
     p.out_mode = EG_OUT_NHWC; p.M = M; p.N = N; p.C = C; p.B = 1; p.H = 1; p.W = 1;
     for (int i = 0; i < nphase && i < 4; ++i) p.ph[i].Kpad = round_up(K, bk);
-    if (const int ns = buf_plan(p, nphase, vec, dtype == EG_F32 ? 4 : 2, (size_t)1 << 40)) return 128 * 1000 + (ns > 1 ? 132 : 131);
+    const NtPlan plan = nt_plan(p, nphase, vec, dtype == EG_F32 ? 4 : 2, (size_t)1 << 40);
+    if (plan.kind == NT_PLAN_BIG128) return 256 * 1000 + 133;
+    if (plan.kind == NT_PLAN_BIG256) return 256 * 1000 + 134;
+    if (plan.kind == NT_PLAN_BUF128) return 128 * 1000 + (plan.ns > 1 ? 132 : 131);
     if (dma_eligible(p, nphase, vec)) return g_use_dma == 1 ? 256 * 1000 + 128 : (g_use_dma == 3 ? 128 * 1000 + 130 : 128 * 1000 + 129);
     if (N <= 16) return 128 * 1000 + 16;
     if (N <= 32) return 128 * 1000 + 32;
@@ -927,8 +1154,8 @@ extern "C" size_t eg_conv_splitk_ws_bytes(const eg_conv* c, int dtype, int bwd) 
     if (bwd) { if (geom_bwd(c, dtype, p, &nphase)) return 0; }
     else geom_fwd(c, dtype, p);
     p.out_mode = EG_OUT_NHWC;
-    const int ns = buf_plan(p, nphase, vec_of(dtype), dtype == EG_F32 ? 4 : 2, (size_t)1 << 40);
-    return ns > 1 ? (size_t)ns * nphase * cdiv(p.M, 128) * 128 * p.N * 4 : 0;
+    const NtPlan plan = nt_plan(p, nphase, vec_of(dtype), dtype == EG_F32 ? 4 : 2, (size_t)1 << 40);
+    return plan.ns > 1 ? (size_t)plan.ns * nphase * cdiv(p.M, 128) * 128 * p.N * 4 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -972,14 +1199,14 @@ static void launch_pack(const PackParams& p, int dtype, hipStream_t st) {
 }
 
 extern "C" size_t eg_pack_fwd_elems(const eg_conv* c, int dtype) {
-    return (size_t)c->Cout * round_up(c->k * c->k * c->Cin, bk_of(dtype));
+    return (size_t)c->Cout * kpad_of(c->k * c->k * c->Cin, c->Cout, dtype);
 }
 extern "C" size_t eg_pack_bwd_elems(const eg_conv* c, int dtype) {
     size_t tot = 0;
     for (int ry = 0; ry < c->stride; ++ry)
         for (int rx = 0; rx < c->stride; ++rx) {
             const int K = bwd_axis(c, ry).T * bwd_axis(c, rx).T * c->Cout;
-            tot += (size_t)c->Cin * round_up(K > 0 ? K : 1, bk_of(dtype));
+            tot += (size_t)c->Cin * kpad_of(K, c->Cin, dtype);
         }
     return tot;
 }
@@ -993,7 +1220,7 @@ extern "C" int eg_pack_fwd(const eg_conv* c, int dtype, const float* w, void* wp
     p.n_stride = (long long)c->Cin * c->k * c->k; p.c_stride = c->k * c->k;
     p.nphase = 1;
     p.ph[0].TH = p.ph[0].TW = c->k; p.ph[0].kh0 = p.ph[0].kw0 = 0;
-    p.ph[0].K = c->k * c->k * c->Cin; p.ph[0].Kpad = round_up(p.ph[0].K, bk_of(dtype)); p.ph[0].w_off = 0;
+    p.ph[0].K = c->k * c->k * c->Cin; p.ph[0].Kpad = kpad_of(p.ph[0].K, c->Cout, dtype); p.ph[0].w_off = 0;
     launch_pack(p, dtype, (hipStream_t)s);
     EG_LAUNCH_CHECK();
     return 0;
@@ -1013,7 +1240,7 @@ extern "C" int eg_pack_bwd(const eg_conv* c, int dtype, const float* w, void* wp
             const BwdAxis ay = bwd_axis(c, ry), ax = bwd_axis(c, rx);
             PackPhase& f = p.ph[n++];
             f.TH = ay.T; f.TW = ax.T > 0 ? ax.T : 1; f.kh0 = ay.k0; f.kw0 = ax.k0;
-            f.K = ay.T * ax.T * c->Cout; f.Kpad = round_up(f.K > 0 ? f.K : 1, bk_of(dtype)); f.w_off = off;
+            f.K = ay.T * ax.T * c->Cout; f.Kpad = kpad_of(f.K, c->Cin, dtype); f.w_off = off;
             off += (long long)c->Cin * f.Kpad;
         }
     p.nphase = n;

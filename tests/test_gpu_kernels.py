@@ -412,10 +412,20 @@ def test_spectral_norm_multi_layer_launch_matches_single():
         torch.testing.assert_close(sg, s1, rtol=1e-5, atol=1e-6)
 
 
+# (eg_set_igemm_dma mode, big_min_tiles) -> label of the kernel the forward case below must be dispatched to
+NT_VARIANTS = [((1, 0), 256128), ((2, 0), 128129), ((3, 0), 128130), ((4, 0), 128131), ((4, 224), 256133), ((0, 0), 128128)]
+
+
+def _set_variant(lib, mode, big):
+    lib.query("eg_set_igemm_dma", mode)
+    lib.query("eg_set_igemm_tuning", 512, 512, big)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_igemm_dma_variant_matches_register_staged_kernel(dtype):
-    """256x128 LDS-DMA variant of the NT kernel (large launches only): bit-exact vs the 128x128 register-staged kernel (same
-    K order) and within tolerance of torch, for a padded stride-2 forward conv and a 4-phase backward-data."""
+    """Every LDS-DMA variant of the NT kernel (global_load_lds 256x128 / 128x128 rings, buffer-descriptor 128x128, 256x128 and
+    256x256 tiles): bit-exact vs the 128x128 register-staged kernel (same K order) and within tolerance of torch, for a padded
+    stride-2 forward conv, a 4-phase backward-data and a 256-column forward."""
     lib = eg._lib.lib()
     g = torch.Generator().manual_seed(21)
     # forward: B=64, 64x64x64 -> 32x32x128  (M = 65536 -> 512 tiles of 128)
@@ -428,14 +438,14 @@ def test_igemm_dma_variant_matches_register_staged_kernel(dtype):
     ops.pack_fwd(c, dtype, w.to(DEV), wp)
     xd = nhwc(x, dtype)
     outs = []
-    for on in (1, 2, 3, 4, 0):
-        lib.query("eg_set_igemm_dma", on)
-        assert lib.query("eg_igemm_nt_tile", dtype, B * 32 * 32, Cout, Cin, 16 * Cin, 1) == {1: 256128, 2: 128129, 3: 128130, 4: 128131, 0: 128128}[on]
+    for (mode, big), label in NT_VARIANTS:
+        _set_variant(lib, mode, big)
+        assert lib.query("eg_igemm_nt_tile", dtype, B * 32 * 32, Cout, Cin, 16 * Cin, 1) == label
         y = torch.zeros(B, 32, 32, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
         ops.conv_fwd(c, dtype, xd, wp, y, ops.epilogue(bias=b.to(DEV), act=ops.ACT_LRELU, slope=0.2))
         torch.cuda.synchronize()
         outs.append(y)
-    lib.query("eg_set_igemm_dma", 4)
+    _set_variant(lib, 4, 224)
     assert all(torch.equal(o, outs[-1]) for o in outs[:-1])
     want = F.leaky_relu(F.conv2d(x, rq(w, dtype), b, 2, 1), 0.2)
     rt, at = tol(dtype, Cin * 16)
@@ -450,29 +460,50 @@ def test_igemm_dma_variant_matches_register_staged_kernel(dtype):
     ops.pack_bwd(c, dtype, w.to(DEV), wp)
     sig = torch.tensor([1.3, 0.7], device=DEV)
     outs = []
-    for on in (1, 2, 3, 4, 0):
-        lib.query("eg_set_igemm_dma", on)
+    for (mode, big), _ in NT_VARIANTS:
+        _set_variant(lib, mode, big)
         dx = torch.zeros(B, H, H, Cin, device=DEV, dtype=ops.torch_dtype(dtype))
         ops.conv_bwd_data(c, dtype, nhwc(dy, dtype), wp, dx,
                           ops.epilogue(sigma=sig, sigma_rows=8 * 32 * 32, mask=nhwc(a, dtype), mask_act=ops.ACT_LRELU, mask_slope=0.1))
         torch.cuda.synchronize()
         outs.append(dx)
-    lib.query("eg_set_igemm_dma", 4)
+    _set_variant(lib, 4, 224)
     assert all(torch.equal(o, outs[-1]) for o in outs[:-1])
     want = F.conv_transpose2d(dy, rq(w, dtype), None, 2, 1) * torch.where(a > 0, 1.0, 0.1)
     want[:8] /= 1.3
     want[8:] /= 0.7
     rt, at = tol(dtype, Cout * 4)
     torch.testing.assert_close(nchw(outs[0]), want, rtol=rt, atol=at)
+    # 256 output channels: the 256x256 tile (two epilogue windows) vs the register-staged kernel
+    B, H, Cin, Cout = 64, 32, 64, 256
+    x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
+    w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    c = ops.make_conv(B, H, H, Cin, Cout, 4, 2, 1)
+    wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
+    ops.pack_fwd(c, dtype, w.to(DEV), wp)
+    outs = []
+    for (mode, big), label in (((4, 32), 256134), ((0, 0), 128128)):
+        _set_variant(lib, mode, big)
+        assert lib.query("eg_igemm_nt_tile", dtype, B * 16 * 16, Cout, Cin, 16 * Cin, 1) == (label if mode else 128064)
+        y = torch.zeros(B, 16, 16, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
+        ops.conv_fwd(c, dtype, nhwc(x, dtype), wp, y, ops.epilogue(bias=b.to(DEV), act=ops.ACT_RELU))
+        torch.cuda.synchronize()
+        outs.append(y)
+    _set_variant(lib, 4, 224)
+    assert torch.equal(outs[0], outs[1])
+    rt, at = tol(dtype, Cin * 16)
+    torch.testing.assert_close(nchw(outs[0]), F.relu(F.conv2d(x, rq(w, dtype), b, 2, 1)), rtol=rt, atol=at)
 
 
+@pytest.mark.parametrize("big,Cout", [(0, 128), (224, 128), (224, 256)])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_igemm_buf_variant_ragged_rows_and_k_padding(dtype):
-    """Buffer-descriptor LDS-DMA NT kernel on a launch whose last row tile is half empty (M = 1025*64) and whose 3x3 filter
-    leaves K = 9*64 unpadded but walks 9 taps with image borders on every side: bit-exact vs the register-staged kernel."""
+def test_igemm_buf_variant_ragged_rows_and_k_padding(dtype, big, Cout):
+    """Buffer-descriptor LDS-DMA NT kernels (128x128, 256x128, 256x256) on a launch whose last row tile is almost empty
+    (M = 1025*64) and whose 3x3 filter walks 9 taps with image borders on every side: bit-exact vs the register-staged kernel."""
     lib = eg._lib.lib()
     g = torch.Generator().manual_seed(22)
-    B, H, Cin, Cout = 1025, 8, 64, 128
+    B, H, Cin = 1025, 8, 64
     x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
     c = ops.make_conv(B, H, H, Cin, Cout, 3, 1, 1)
@@ -480,13 +511,15 @@ def test_igemm_buf_variant_ragged_rows_and_k_padding(dtype):
     ops.pack_fwd(c, dtype, w.to(DEV), wp)
     xd = nhwc(x, dtype)
     outs = []
-    for on in (4, 0):
-        lib.query("eg_set_igemm_dma", on)
+    for mode in (4, 0):
+        _set_variant(lib, mode, big)
+        if mode:
+            assert lib.query("eg_igemm_nt_tile", dtype, B * 64, Cout, Cin, 9 * Cin, 1) == {(0, 128): 128131, (224, 128): 256133, (224, 256): 256134}[(big, Cout)]
         y = torch.zeros(B, H, H, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
         ops.conv_fwd(c, dtype, xd, wp, y, ops.epilogue())
         torch.cuda.synchronize()
         outs.append(y)
-    lib.query("eg_set_igemm_dma", 4)
+    _set_variant(lib, 4, 224)
     assert torch.equal(outs[0], outs[1])
     want = F.conv2d(x[:64], rq(w, dtype), None, 1, 1)
     rt, at = tol(dtype, Cin * 9)
