@@ -7,7 +7,9 @@
 // Both run in fp32 (v_mfma_f32_16x16x4_f32, exact fp32) or bf16 (v_mfma_f32_16x16x32_bf16, fp32
 // accumulate).  K rows in LDS are always 128 bytes (32 fp32 / 64 bf16) and XOR-swizzled in 16-byte
 // chunks so that ds_read_b128 fragment reads are bank-conflict free without padding.
+#include <stdlib.h>
 #include <algorithm>
+#include <vector>
 #include <type_traits>
 
 #include "eg_common.h"
@@ -443,6 +445,115 @@ __device__ __forceinline__ void nt_epilogue_lds(const NtParams& p, const NtPhase
     }
 }
 
+// Epilogue operands fetched ahead of the last K step (igemm_nt_buf): 1/sigma per accumulator row block, the bias of the lane's 4 x TN
+// columns and the activation-gradient mask vectors of the first PF store iterations -- their global-load latency (the epilogue's
+// critical path: ~40 % of a 16-step launch) overlaps the last MFMA block and the LDS staging.
+template <typename T, int TM, int TN, int PF>
+struct NtEpiPre {
+    float inv_sigma[TM];
+    float bias[TN][4];
+    uint4 mask[PF];
+};
+
+template <typename T, int BM, int BNW, int TM, int TN, int NT, int PF>
+__device__ __forceinline__ void nt_epi_prefetch(NtEpiPre<T, TM, TN, PF>& e, const NtParams& p, const NtPhase& ph, int m0, int nw0, int row0, int col0,
+                                                int tid, int frow, int fq) {
+    constexpr int VEC = Elt<T>::VEC;
+    constexpr int VPR = BNW / VEC, RPP = NT / VPR;
+    const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int mrow = min(m0 + row0 + i * 16 + frow, p.M - 1);
+        e.inv_sigma[i] = p.sigma ? p.sigma[p.sigma_rows ? mrow / p.sigma_rows : 0] : 1.f;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = nw0 + col0 + j * 16 + fq * 4 + r;
+            e.bias[j][r] = (p.bias && n < p.N) ? p.bias[p.bias_mod ? n % p.bias_mod : n] : 0.f;
+        }
+    const T* __restrict__ mask = reinterpret_cast<const T*>(p.mask);
+    const int vc = tid % VPR, vr = tid / VPR;
+    const int n = nw0 + vc * VEC;
+#pragma unroll
+    for (int it = 0; it < PF; ++it) {
+        const int m = m0 + vr + it * RPP;
+        e.mask[it] = make_uint4(0, 0, 0, 0);
+        if (mask && n < p.N && m < p.M) {
+            const int b = m >> (p.lOW + p.lOH);
+            const int y = ((m >> p.lOW) & OHm) * p.osy + ph.ooy;
+            const int x = (m & OWm) * p.osx + ph.oox;
+            e.mask[it] = *reinterpret_cast<const uint4*>(mask + (((size_t)b * p.DH + y) * p.DW + x) * p.N + n);
+        }
+    }
+}
+
+// nt_epilogue_lds with the operands of NtEpiPre (same arithmetic, same results)
+template <typename T, int BM, int BNW, int TM, int TN, int NT, int PF>
+__device__ __forceinline__ void nt_epilogue_lds_pre(const NtEpiPre<T, TM, TN, PF>& e, const NtParams& p, const NtPhase& ph, f32x4 (&acc)[TM][TN],
+                                                    char* smem, int m0, int nw0, int row0, int col0, int tid, int frow, int fq) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
+    constexpr int SW = 31;
+    float* ct = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = row0 + i * 16 + frow;
+        const float inv_sigma = p.sigma ? 1.f / e.inv_sigma[i] : 1.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = col0 + j * 16 + fq * 4;
+            float4 v;
+            float* ve = reinterpret_cast<float*>(&v);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[i][j][r] * inv_sigma;
+                if (p.bias && nw0 + nl + r < p.N) x += e.bias[j][r];
+                ve[r] = eg_act(x, p.act, p.slope);
+            }
+            *reinterpret_cast<float4*>(ct + row * BNW + (((nl >> 2) ^ (row & SW)) << 2)) = v;
+        }
+    }
+    __syncthreads();
+    constexpr int VPR = BNW / VEC;
+    constexpr int RPP = NT / VPR;
+    constexpr int NIT = BM / RPP;
+    const int vc = tid % VPR, vr = tid / VPR;
+    const T* __restrict__ mask = reinterpret_cast<const T*>(p.mask);
+    const int n = nw0 + vc * VEC;
+    if (n < p.N) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int row = vr + it * RPP;
+            const int m = m0 + row;
+            if (m >= p.M) break;
+            const int b = m >> (p.lOW + p.lOH);
+            const int y = ((m >> p.lOW) & OHm) * p.osy + ph.ooy;
+            const int x = (m & OWm) * p.osx + ph.oox;
+            const size_t o = (((size_t)b * p.DH + y) * p.DW + x) * p.N + n;
+            float f[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC / 4; ++q) {
+                const int chunk = (vc * (VEC / 4) + q) ^ (row & SW);
+                const float4 v = *reinterpret_cast<const float4*>(ct + row * BNW + (chunk << 2));
+                f[q * 4 + 0] = v.x; f[q * 4 + 1] = v.y; f[q * 4 + 2] = v.z; f[q * 4 + 3] = v.w;
+            }
+            if (mask) {
+                const uint4 mv = it < PF ? e.mask[it < PF ? it : 0] : *reinterpret_cast<const uint4*>(mask + o);
+                const T* me = reinterpret_cast<const T*>(&mv);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) f[q] *= eg_act_grad_from_out(Elt<T>::ld(me + q), p.mask_act, p.mask_slope);
+            }
+            uint4 ov;
+            T* oe = reinterpret_cast<T*>(&ov);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) Elt<T>::st(oe + q, f[q]);
+            *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.dst) + o) = ov;
+        }
+    }
+}
+
 #define EG_DMA_BN 128
 
 template <typename T, int BM, int NST>
@@ -589,10 +700,24 @@ __device__ __forceinline__ void eg_bufdma4(const u32x4_t srd, unsigned v0, unsig
         : "memory", "scc");
 }
 
+__device__ __forceinline__ void eg_bufdma1(const u32x4_t srd, unsigned v0, unsigned soff, unsigned lds) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(v0), "s"(srd), "s"(soff), "s"(lds)
+        : "memory");
+}
+
 #define EG_OOB 0x80000000u
 
-template <typename T>
-__global__ __launch_bounds__(256) void igemm_nt_buf_kernel(const NtParams p) {
+template <typename T, bool PROF = false>
+__global__ __launch_bounds__(256) void igemm_nt_buf_kernel(const NtParams p, unsigned long long* prof = nullptr) {
+    unsigned long long t_begin = 0, t_wait = 0, t_issue = 0, t_comp = 0, t0 = 0, t1 = 0;
+    if (PROF) t_begin = __builtin_amdgcn_s_memtime();
     constexpr int VEC = Elt<T>::VEC;
     constexpr int BK = 8 * VEC;
     constexpr int BM = 128, BN = 128;
@@ -680,13 +805,8 @@ __global__ __launch_bounds__(256) void igemm_nt_buf_kernel(const NtParams p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int frow = lane & 15, fq = lane >> 4;
-    if (nk > 0) issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                 // everyone's stage kt landed; everyone finished reading stage kt-1
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const char* sa = smem + (kt & 1) * STAGE;
+    auto compute = [&](int stage) {
+        const char* sa = smem + stage * STAGE;
         const char* sb = sa + BM * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -700,7 +820,28 @@ __global__ __launch_bounds__(256) void igemm_nt_buf_kernel(const NtParams p) {
                 for (int j = 0; j < TN; ++j) mfma_step<T>(af, bfr[j], acc[i][j]);
             }
         }
+    };
+    if (nk > 0) issue(0, 0);
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        if (PROF) t0 = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // everyone's stage kt landed; everyone finished reading stage kt-1
+        __builtin_amdgcn_sched_barrier(0);
+        if (PROF) { t1 = __builtin_amdgcn_s_memtime(); t_wait += t1 - t0; }
+        issue(kt + 1, (kt + 1) & 1);
+        if (PROF) { __builtin_amdgcn_sched_barrier(0); t0 = __builtin_amdgcn_s_memtime(); t_issue += t0 - t1; __builtin_amdgcn_sched_barrier(0); }
+        compute(kt & 1);
+        if (PROF) { __builtin_amdgcn_sched_barrier(0); t1 = __builtin_amdgcn_s_memtime(); t_comp += t1 - t0; __builtin_amdgcn_sched_barrier(0); }
     }
+    // last K step: nothing left to issue -> fetch the epilogue operands instead, their latency hides behind the MFMAs
+    constexpr int PF = 8;
+    NtEpiPre<T, TM, TN, PF> epi;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (nsplit == 1) nt_epi_prefetch<T, BM, BN, TM, TN, 256, PF>(epi, p, ph, m0, n0, wm * TM * 16, wn * TN * 16, tid, frow, fq);
+    if (nk > 0) compute((nk - 1) & 1);
+    if (PROF) t0 = __builtin_amdgcn_s_memtime();
     if (nsplit > 1) {
         // raw fp32 partial tile; nt_splitk_epilogue_kernel sums the splits and applies the epilogue
         const int nphase = gridDim.z / nsplit;
@@ -715,7 +856,224 @@ __global__ __launch_bounds__(256) void igemm_nt_buf_kernel(const NtParams p) {
         return;
     }
     __syncthreads();
-    nt_epilogue_lds<T, BM, BN, TM, TN, 256>(p, ph, acc, smem, m0, n0, wm * TM * 16, wn * TN * 16, tid, frow, fq);
+    nt_epilogue_lds_pre<T, BM, BN, TM, TN, 256, PF>(epi, p, ph, acc, smem, m0, n0, wm * TM * 16, wn * TN * 16, tid, frow, fq);
+    if (PROF && lane == 0) {
+        t1 = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = prof + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+        o[0] = t1 - t_begin; o[1] = t_wait; o[2] = t_issue; o[3] = t_comp; o[4] = t1 - t0; o[5] = t_begin; o[6] = t1; o[7] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// igemm_nt_pers: the 128x128 buffer-descriptor kernel as a persistent pipeline.  A workgroup walks tiles t = blockIdx.x, +gridDim.x, ...
+// with ONE continuous 2-stage LDS-DMA ring: the first K step of the next tile is in flight while the last step of the current tile is
+// computed, the epilogue operands (1/sigma, bias, activation-gradient mask in accumulator layout) are fetched during that last step,
+// and the results leave straight from the accumulators as 8/16-byte stores that nobody waits for -- no LDS staging, no barriers and no
+// idle MFMA pipe at tile seams (in igemm_nt_buf the epilogue of every workgroup ran at the same time and cost 15-45 % of a launch).
+// vmcnt discipline: the epilogue's TM*TN stores are the wave's youngest operations when the next step's DMA must have landed, so that
+// wait is vmcnt(TM*TN) (vmcnt(0) for ragged tiles, where waves may skip stores).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256, 2) void igemm_nt_pers_kernel(const NtParams p, int tiles_m, int tiles_n, int ntiles) {
+    constexpr int VEC = Elt<T>::VEC;
+    constexpr int BK = 8 * VEC;
+    constexpr int BM = 128, BN = 128;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int TM = 4, TN = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
+    const int HU = p.H << p.up, WU = p.W << p.up;
+    const int rsub = lane >> 3, pos = lane & 7;
+    const int srcchunk = pos ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
+    const int frow = lane & 15, fq = lane >> 4;
+    const unsigned row_bytes = (unsigned)p.C * sizeof(T);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)wave * 1024u;
+    const u32x4_t srdA = eg_make_srd(p.src, (unsigned)((size_t)p.B * p.H * p.W * p.C * sizeof(T)));
+
+    // ---- load side: the tile whose K steps are being issued ----
+    int lt = blockIdx.x, lkt = 0, lnk = 0;
+    int l_dys = 0, l_dxs = 0, l_TW = 1, l_TH = 0;
+    int a_pix0[4], a_y[4], a_x[4];
+    unsigned va[4], vb[4];
+    u32x4_t srdB = srdA;
+    int ty = 0, tx = 0;
+    unsigned kc_bytes = 0;
+    auto tap_offsets = [&]() {
+        const int oy = ty * l_dys, ox = tx * l_dxs;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iy = a_y[j] + oy, ix = a_x[j] + ox;
+            const bool ok = ty < l_TH && a_pix0[j] >= 0 && iy >= 0 && iy < HU && ix >= 0 && ix < WU;
+            const unsigned pix = (unsigned)(a_pix0[j] + (iy >> p.up) * p.W + (ix >> p.up));
+            va[j] = ok ? pix * row_bytes + (unsigned)srcchunk * 16u : EG_OOB;
+        }
+    };
+    auto setup_load = [&]() {
+        const int mt = lt % tiles_m, q = lt / tiles_m;
+        const int nt = q % tiles_n, phase = q / tiles_n;
+        const NtPhase& ph = p.ph[phase];
+        const int m0 = mt * BM, n0 = nt * BN;
+        l_dys = ph.dys; l_dxs = ph.dxs; l_TW = ph.TW; l_TH = ph.TH;
+        lnk = ph.Kpad / BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + (j * 4 + wave) * 8 + rsub;
+            const int b = m >> (p.lOW + p.lOH);
+            a_pix0[j] = (m < p.M) ? b * p.H * p.W : -1;
+            a_y[j] = ((m >> p.lOW) & OHm) * p.sy + ph.dy0;
+            a_x[j] = (m & OWm) * p.sx + ph.dx0;
+            const int n = n0 + (j * 4 + wave) * 8 + rsub;
+            vb[j] = n < p.N ? (unsigned)n * (unsigned)ph.Kpad * (unsigned)sizeof(T) + (unsigned)srcchunk * 16u : EG_OOB;
+        }
+        srdB = eg_make_srd(reinterpret_cast<const T*>(p.wp) + ph.w_off, (unsigned)((size_t)p.N * ph.Kpad * sizeof(T)));
+        ty = 0; tx = 0; kc_bytes = 0; lkt = 0;
+        tap_offsets();
+    };
+    // K step lkt of tile lt -> LDS stage: 8 pieces (A slots 0..3, B slots 0..3), issued in one burst right after the barrier (spreading
+    // them between the MFMA groups of the step was measured 8 % slower)
+    auto issue_piece = [&](int q, int stage) {
+        const unsigned sa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)stage * STAGE);
+        if (q < 4) eg_bufdma1(srdA, va[q], kc_bytes, sa + q * 0x1000);
+        else eg_bufdma1(srdB, vb[q - 4], (unsigned)lkt * 128u, sa + BM * 128 + (q - 4) * 0x1000);
+    };
+    auto issue_advance = [&]() {
+        ++lkt;
+        kc_bytes += 128u;
+        if (kc_bytes >= row_bytes) {               // next tap (uniform branch)
+            kc_bytes = 0;
+            if (++tx == l_TW) { tx = 0; ++ty; }
+            tap_offsets();
+        }
+    };
+
+    // ---- compute side: the tile whose accumulators are live ----
+    int ct = blockIdx.x, ckt = 0, cnk = 0, c_m0 = 0, c_n0 = 0, c_ooy = 0, c_oox = 0;
+    auto setup_comp = [&]() {
+        const int mt = ct % tiles_m, q = ct / tiles_m;
+        const int nt = q % tiles_n, phase = q / tiles_n;
+        c_m0 = mt * BM; c_n0 = nt * BN;
+        c_ooy = p.ph[phase].ooy; c_oox = p.ph[phase].oox;
+        cnk = p.ph[phase].Kpad / BK;
+        ckt = 0;
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (lt < ntiles) {
+        setup_load();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) issue_piece(q, 0);
+        issue_advance();
+    }
+    if (ct < ntiles) setup_comp();
+    unsigned g = 0;                                   // global K step: LDS stage = g & 1
+    bool stores_pending = false;
+    const T* __restrict__ maskp = reinterpret_cast<const T*>(p.mask);
+    typedef typename std::conditional<std::is_same<T, float>::value, uint4, uint2>::type OutVec;   // 4 outputs of one accumulator
+
+    while (ct < ntiles) {
+        if (stores_pending) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // everyone's stage g landed; everyone finished reading stage g-1
+        __builtin_amdgcn_sched_barrier(0);
+        stores_pending = false;
+        if (lkt == lnk) {                             // load side moves on to this workgroup's next tile
+            lt += gridDim.x;
+            if (lt < ntiles) setup_load();
+        }
+        if (lt < ntiles) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) issue_piece(q, (g + 1) & 1);
+            issue_advance();
+        }
+        const bool last = ckt + 1 == cnk;
+        // epilogue operands in accumulator layout, fetched under the last MFMA block of the tile
+        float e_sigma[TM], e_bias[TN][4];
+        OutVec e_mask[TM][TN];
+        size_t e_off[TM];
+        bool e_ok[TM];
+        if (last) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = c_m0 + (wm * TM + i) * 16 + frow;
+                e_ok[i] = m < p.M;
+                const int mc = min(m, p.M - 1);
+                e_sigma[i] = p.sigma ? p.sigma[p.sigma_rows ? mc / p.sigma_rows : 0] : 1.f;
+                const int b = mc >> (p.lOW + p.lOH);
+                const int y = ((mc >> p.lOW) & OHm) * p.osy + c_ooy;
+                const int x = (mc & OWm) * p.osx + c_oox;
+                e_off[i] = (((size_t)b * p.DH + y) * p.DW + x) * p.N + c_n0 + wn * 64 + fq * 4;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = c_n0 + (wn * TN + j) * 16 + fq * 4 + r;
+                    e_bias[j][r] = p.bias ? p.bias[p.bias_mod ? n % p.bias_mod : n] : 0.f;
+                }
+            if (maskp) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) e_mask[i][j] = *reinterpret_cast<const OutVec*>(maskp + e_off[i] + j * 16);
+            }
+        }
+        {
+            const char* sa = smem + (g & 1) * STAGE;
+            const char* sb = sa + BM * 128;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 bfr[TN];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(sb + lds_off((wn * TN + j) * 16 + frow, ks * 4 + fq));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const uint4 af = *reinterpret_cast<const uint4*>(sa + lds_off((wm * TM + i) * 16 + frow, ks * 4 + fq));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) mfma_step<T>(af, bfr[j], acc[i][j]);
+                }
+            }
+        }
+        ++g;
+        if (!last) { ++ckt; continue; }
+        // ---- epilogue straight from the accumulators: acc[i][j][r] = C[c_m0 + (wm*TM+i)*16 + frow][c_n0 + (wn*TN+j)*16 + fq*4 + r]
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float inv_sigma = p.sigma ? 1.f / e_sigma[i] : 1.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float f[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = acc[i][j][r] * inv_sigma;
+                    if (p.bias) x += e_bias[j][r];
+                    f[r] = eg_act(x, p.act, p.slope);
+                }
+                if (maskp) {
+                    const T* me = reinterpret_cast<const T*>(&e_mask[i][j]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) f[r] *= eg_act_grad_from_out(Elt<T>::ld(me + r), p.mask_act, p.mask_slope);
+                }
+                OutVec ov;
+                T* oe = reinterpret_cast<T*>(&ov);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Elt<T>::st(oe + r, f[r]);
+                if (e_ok[i]) *reinterpret_cast<OutVec*>(reinterpret_cast<T*>(p.dst) + e_off[i] + j * 16) = ov;
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        stores_pending = c_m0 + BM <= p.M;            // full tile: every wave issued exactly TM*TN stores
+        ct += gridDim.x;
+        if (ct < ntiles) setup_comp();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -963,15 +1321,16 @@ extern "C" int eg_set_igemm_dma(int on) { const int old = g_use_dma; g_use_dma =
 // tuning knobs of the buffer-descriptor kernels (units: workgroups per launch).  128x128 kernel: launches with fewer tiles than
 // g_buf_min_tiles go to the register-staged kernels; launches below g_splitk_target tiles are split along K (when the caller lent a
 // workspace) to reach that many workgroups.  256-row kernel: taken when the launch has at least g_big_min_tiles of its tiles (0 = never).
-static int g_buf_min_tiles = 512, g_splitk_target = 512, g_big_min_tiles = 224;
-extern "C" int eg_set_igemm_tuning(int buf_min_tiles, int splitk_target, int big_min_tiles) {
+static int g_buf_min_tiles = 512, g_splitk_target = 512, g_big_min_tiles = 0, g_persistent = 0;
+extern "C" int eg_set_igemm_tuning(int buf_min_tiles, int splitk_target, int big_min_tiles, int persistent) {
     if (buf_min_tiles > 0) g_buf_min_tiles = buf_min_tiles;
     if (splitk_target >= 0) g_splitk_target = splitk_target;
     if (big_min_tiles >= 0) g_big_min_tiles = big_min_tiles;
+    if (persistent >= 0) g_persistent = persistent;
     return 0;
 }
 
-enum { NT_PLAN_NONE = 0, NT_PLAN_BUF128 = 1, NT_PLAN_BIG128 = 2, NT_PLAN_BIG256 = 3 };
+enum { NT_PLAN_NONE = 0, NT_PLAN_BUF128 = 1, NT_PLAN_BIG128 = 2, NT_PLAN_BIG256 = 3, NT_PLAN_PERS = 4 };
 struct NtPlan { int kind, ns; };
 
 static NtPlan nt_plan(const NtParams& p, int nphase, int vec, size_t esize, size_t ws_bytes) {
@@ -994,7 +1353,7 @@ static NtPlan nt_plan(const NtParams& p, int nphase, int vec, size_t esize, size
         while (ns > 1 && (size_t)ns * nphase * cdiv(p.M, 128) * 128 * p.N * 4 > ws_bytes) ns /= 2;
         if (ns > 1) return {NT_PLAN_BUF128, ns};
     }
-    return tiles >= g_buf_min_tiles ? NtPlan{NT_PLAN_BUF128, 1} : none;
+    return tiles >= g_buf_min_tiles ? NtPlan{g_persistent ? NT_PLAN_PERS : NT_PLAN_BUF128, 1} : none;
 }
 
 static bool dma_eligible(const NtParams& p, int nphase, int vec) {
@@ -1052,6 +1411,17 @@ static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
         else hipLaunchKernelGGL((igemm_nt_big_kernel<T, 128, 64, 3>), grid, dim3(512), lds, st, q);
         return;
     }
+    if (plan.kind == NT_PLAN_PERS) {
+        static bool attr_set = false;
+        const size_t lds = 2 * (128 + 128) * 128;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_nt_pers_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        const int tm = cdiv(p.M, 128), tn = p.N / 128, ntiles = tm * tn * nphase;
+        hipLaunchKernelGGL((igemm_nt_pers_kernel<T>), dim3(std::min(ntiles, 512)), dim3(256), lds, st, p, tm, tn, ntiles);
+        return;
+    }
     if (plan.kind == NT_PLAN_BUF128) {
         const int ns = plan.ns;
         static bool attr_set = false;
@@ -1062,6 +1432,27 @@ static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
         }
         NtParams q = p;
         q.nsplit = ns;
+        // diagnostic (EG_NT_PROF=1 in the environment): run the instrumented instantiation synchronously and print the per-wave averages of
+        // its phase timers (wait+barrier / LDS-DMA issue / ds_read+MFMA / epilogue) -- how DESIGN.md section 6's breakdown was measured
+        static const char* prof_env = getenv("EG_NT_PROF");
+        if (prof_env && ns == 1) {
+            const dim3 grid(cdiv(p.M, 128), p.N / 128, nphase);
+            const size_t nw = (size_t)grid.x * grid.y * grid.z * 4;
+            unsigned long long* dbuf = nullptr;
+            (void)hipMalloc(&dbuf, nw * 64);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_nt_buf_kernel<T, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((igemm_nt_buf_kernel<T, true>), grid, dim3(256), lds, st, q, dbuf);
+            (void)hipStreamSynchronize(st);
+            std::vector<unsigned long long> h(nw * 8);
+            (void)hipMemcpy(h.data(), dbuf, nw * 64, hipMemcpyDeviceToHost);
+            (void)hipFree(dbuf);
+            double tot = 0, wt = 0, is = 0, cp = 0, ep = 0;
+            for (size_t w = 0; w < nw; ++w) { tot += h[w * 8]; wt += h[w * 8 + 1]; is += h[w * 8 + 2]; cp += h[w * 8 + 3]; ep += h[w * 8 + 4]; }
+            const int nk = p.ph[0].Kpad / (8 * Elt<T>::VEC);
+            fprintf(stderr, "[nt_prof] grid %ux%ux%u nk %d | per wave (s_memtime ticks): total %.0f  wait+barrier %.0f (%.1f/step)  issue %.0f (%.1f/step)  compute %.0f (%.1f/step)  epilogue %.0f\n",
+                    grid.x, grid.y, grid.z, nk, tot / nw, wt / nw, wt / nw / nk, is / nw, is / nw / nk, cp / nw, cp / nw / nk, ep / nw);
+            return;
+        }
         hipLaunchKernelGGL((igemm_nt_buf_kernel<T>), dim3(cdiv(p.M, 128), p.N / 128, nphase * ns), dim3(256), lds, st, q);
         if (ns > 1) {
             const long long vecs = (long long)nphase * p.M * (p.N / Elt<T>::VEC);
@@ -1094,6 +1485,7 @@ extern "C" int eg_igemm_nt_tile(int dtype, int M, int N, int C, int K, int nphas
     const NtPlan plan = nt_plan(p, nphase, vec, dtype == EG_F32 ? 4 : 2, (size_t)1 << 40);
     if (plan.kind == NT_PLAN_BIG128) return 256 * 1000 + 133;
     if (plan.kind == NT_PLAN_BIG256) return 256 * 1000 + 134;
+    if (plan.kind == NT_PLAN_PERS) return 128 * 1000 + 135;
     if (plan.kind == NT_PLAN_BUF128) return 128 * 1000 + (plan.ns > 1 ? 132 : 131);
     if (dma_eligible(p, nphase, vec)) return g_use_dma == 1 ? 256 * 1000 + 128 : (g_use_dma == 3 ? 128 * 1000 + 130 : 128 * 1000 + 129);
     if (N <= 16) return 128 * 1000 + 16;

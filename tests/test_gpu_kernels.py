@@ -413,12 +413,13 @@ def test_spectral_norm_multi_layer_launch_matches_single():
 
 
 # (eg_set_igemm_dma mode, big_min_tiles) -> label of the kernel the forward case below must be dispatched to
-NT_VARIANTS = [((1, 0), 256128), ((2, 0), 128129), ((3, 0), 128130), ((4, 0), 128131), ((4, 224), 256133), ((0, 0), 128128)]
+NT_VARIANTS = [((1, 0), 256128), ((2, 0), 128129), ((3, 0), 128130), ((4, 0), 128131), ((4, -1), 128135), ((4, 224), 256133), ((0, 0), 128128)]
 
 
 def _set_variant(lib, mode, big):
+    """big < 0: the persistent 128x128 pipeline; otherwise one workgroup per tile (library default) and big_min_tiles = big"""
     lib.query("eg_set_igemm_dma", mode)
-    lib.query("eg_set_igemm_tuning", 512, 512, big)
+    lib.query("eg_set_igemm_tuning", 512, 512, max(big, 0), 1 if big < 0 else 0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -445,7 +446,7 @@ def test_igemm_dma_variant_matches_register_staged_kernel(dtype):
         ops.conv_fwd(c, dtype, xd, wp, y, ops.epilogue(bias=b.to(DEV), act=ops.ACT_LRELU, slope=0.2))
         torch.cuda.synchronize()
         outs.append(y)
-    _set_variant(lib, 4, 224)
+    _set_variant(lib, 4, 0)
     assert all(torch.equal(o, outs[-1]) for o in outs[:-1])
     want = F.leaky_relu(F.conv2d(x, rq(w, dtype), b, 2, 1), 0.2)
     rt, at = tol(dtype, Cin * 16)
@@ -467,7 +468,7 @@ def test_igemm_dma_variant_matches_register_staged_kernel(dtype):
                           ops.epilogue(sigma=sig, sigma_rows=8 * 32 * 32, mask=nhwc(a, dtype), mask_act=ops.ACT_LRELU, mask_slope=0.1))
         torch.cuda.synchronize()
         outs.append(dx)
-    _set_variant(lib, 4, 224)
+    _set_variant(lib, 4, 0)
     assert all(torch.equal(o, outs[-1]) for o in outs[:-1])
     want = F.conv_transpose2d(dy, rq(w, dtype), None, 2, 1) * torch.where(a > 0, 1.0, 0.1)
     want[:8] /= 1.3
@@ -490,13 +491,13 @@ def test_igemm_dma_variant_matches_register_staged_kernel(dtype):
         ops.conv_fwd(c, dtype, nhwc(x, dtype), wp, y, ops.epilogue(bias=b.to(DEV), act=ops.ACT_RELU))
         torch.cuda.synchronize()
         outs.append(y)
-    _set_variant(lib, 4, 224)
+    _set_variant(lib, 4, 0)
     assert torch.equal(outs[0], outs[1])
     rt, at = tol(dtype, Cin * 16)
     torch.testing.assert_close(nchw(outs[0]), F.relu(F.conv2d(x, rq(w, dtype), b, 2, 1)), rtol=rt, atol=at)
 
 
-@pytest.mark.parametrize("big,Cout", [(0, 128), (224, 128), (224, 256)])
+@pytest.mark.parametrize("big,Cout", [(0, 128), (-1, 128), (-1, 256), (224, 128), (224, 256)])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_igemm_buf_variant_ragged_rows_and_k_padding(dtype, big, Cout):
     """Buffer-descriptor LDS-DMA NT kernels (128x128, 256x128, 256x256) on a launch whose last row tile is almost empty
@@ -514,12 +515,12 @@ def test_igemm_buf_variant_ragged_rows_and_k_padding(dtype, big, Cout):
     for mode in (4, 0):
         _set_variant(lib, mode, big)
         if mode:
-            assert lib.query("eg_igemm_nt_tile", dtype, B * 64, Cout, Cin, 9 * Cin, 1) == {(0, 128): 128131, (224, 128): 256133, (224, 256): 256134}[(big, Cout)]
+            assert lib.query("eg_igemm_nt_tile", dtype, B * 64, Cout, Cin, 9 * Cin, 1) == {(0, 128): 128131, (-1, 128): 128135, (-1, 256): 128135, (224, 128): 256133, (224, 256): 256134}[(big, Cout)]
         y = torch.zeros(B, H, H, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
         ops.conv_fwd(c, dtype, xd, wp, y, ops.epilogue())
         torch.cuda.synchronize()
         outs.append(y)
-    _set_variant(lib, 4, 224)
+    _set_variant(lib, 4, 0)
     assert torch.equal(outs[0], outs[1])
     want = F.conv2d(x[:64], rq(w, dtype), None, 1, 1)
     rt, at = tol(dtype, Cin * 9)
