@@ -14,6 +14,9 @@
 
 #include "eg_common.h"
 
+// This file is compiled with -ffp-contract=off (Makefile): every NT variant must round the epilogue (acc / sigma + bias) alike -- the
+// variants are tested bit for bit against each other -- and clang contracts `a * b + c` depending on where the operands come from.
+
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -276,9 +279,9 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
                 float* ve = reinterpret_cast<float*>(&v);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float x = acc[i][j][r] * inv_sigma;
+                    float x = __fmul_rn(acc[i][j][r], inv_sigma);
                     const int n = n0 + nl + r;
-                    if (p.bias && n < p.N) x += p.bias[p.bias_mod ? n % p.bias_mod : n];
+                    if (p.bias && n < p.N) x = __fadd_rn(x, p.bias[p.bias_mod ? n % p.bias_mod : n]);
                     ve[r] = eg_act(x, p.act, p.slope);
                 }
                 *reinterpret_cast<float4*>(ct + row * BN + (((nl >> 2) ^ (row & SW)) << 2)) = v;
@@ -338,8 +341,8 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int n = n0 + (wn * TN + j) * 16 + fq * 4 + r;
                 if (n >= p.N) continue;
-                float v = acc[i][j][r] * inv_sigma;
-                if (p.bias) v += p.bias[p.bias_mod ? n % p.bias_mod : n];
+                float v = __fmul_rn(acc[i][j][r], inv_sigma);
+                if (p.bias) v = __fadd_rn(v, p.bias[p.bias_mod ? n % p.bias_mod : n]);
                 v = eg_act(v, p.act, p.slope);
                 if (p.out_mode == EG_OUT_NHWC) {
                     const size_t o = pix * p.N + n;
@@ -399,9 +402,9 @@ __device__ __forceinline__ void nt_epilogue_lds(const NtParams& p, const NtPhase
                 float* ve = reinterpret_cast<float*>(&v);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float x = acc[i][j][r] * inv_sigma;
+                    float x = __fmul_rn(acc[i][j][r], inv_sigma);
                     const int n = nw0 + nl + r;
-                    if (p.bias && n < p.N) x += p.bias[p.bias_mod ? n % p.bias_mod : n];
+                    if (p.bias && n < p.N) x = __fadd_rn(x, p.bias[p.bias_mod ? n % p.bias_mod : n]);
                     ve[r] = eg_act(x, p.act, p.slope);
                 }
                 *reinterpret_cast<float4*>(ct + row * BNW + (((nl >> 2) ^ (row & SW)) << 2)) = v;
@@ -508,8 +511,8 @@ __device__ __forceinline__ void nt_epilogue_lds_pre(const NtEpiPre<T, TM, TN, PF
             float* ve = reinterpret_cast<float*>(&v);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float x = acc[i][j][r] * inv_sigma;
-                if (p.bias && nw0 + nl + r < p.N) x += e.bias[j][r];
+                float x = __fmul_rn(acc[i][j][r], inv_sigma);
+                if (p.bias && nw0 + nl + r < p.N) x = __fadd_rn(x, e.bias[j][r]);
                 ve[r] = eg_act(x, p.act, p.slope);
             }
             *reinterpret_cast<float4*>(ct + row * BNW + (((nl >> 2) ^ (row & SW)) << 2)) = v;
@@ -937,7 +940,8 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_pers_kernel(const NtParams p,
     // them between the MFMA groups of the step was measured 8 % slower)
     auto issue_piece = [&](int q, int stage) {
         const unsigned sa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)stage * STAGE);
-        if (q < 4) eg_bufdma1(srdA, va[q], kc_bytes, sa + q * 0x1000);
+        // (single-tap launches whose row is not a whole number of K tiles: chunks past the end of the row read as zeros)
+        if (q < 4) eg_bufdma1(srdA, kc_bytes + (unsigned)srcchunk * 16u < row_bytes ? va[q] : EG_OOB, kc_bytes, sa + q * 0x1000);
         else eg_bufdma1(srdB, vb[q - 4], (unsigned)lkt * 128u, sa + BM * 128 + (q - 4) * 0x1000);
     };
     auto issue_advance = [&]() {
@@ -1053,8 +1057,8 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_pers_kernel(const NtParams p,
                 float f[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float x = acc[i][j][r] * inv_sigma;
-                    if (p.bias) x += e_bias[j][r];
+                    float x = __fmul_rn(acc[i][j][r], inv_sigma);
+                    if (p.bias) x = __fadd_rn(x, e_bias[j][r]);
                     f[r] = eg_act(x, p.act, p.slope);
                 }
                 if (maskp) {
@@ -1295,8 +1299,8 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(const NtParams 
         const size_t o = (((size_t)b * p.DH + y) * p.DW + x) * p.N + n;
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-            float v = f[q] * inv_sigma;
-            if (p.bias) v += p.bias[p.bias_mod ? (n + q) % p.bias_mod : n + q];
+            float v = __fmul_rn(f[q], inv_sigma);
+            if (p.bias) v = __fadd_rn(v, p.bias[p.bias_mod ? (n + q) % p.bias_mod : n + q]);
             f[q] = eg_act(v, p.act, p.slope);
         }
         if (mask) {
@@ -1335,18 +1339,26 @@ struct NtPlan { int kind, ns; };
 
 static NtPlan nt_plan(const NtParams& p, int nphase, int vec, size_t esize, size_t ws_bytes) {
     const NtPlan none = {NT_PLAN_NONE, 1};
-    if (g_use_dma != 4 || p.out_mode != EG_OUT_NHWC || (p.N % 128) != 0 || (p.C % (8 * vec)) != 0) return none;
+    if (g_use_dma != 4 || p.out_mode != EG_OUT_NHWC || (p.N % 128) != 0 || (p.C % vec) != 0) return none;
     if ((size_t)p.B * p.H * p.W * p.C * esize >= 0x7fffffffull) return none;
-    int nk_min = 1 << 30;
+    int nk_min = 1 << 30, nk_max = 0;
+    bool single_tap = true;
     for (int i = 0; i < nphase; ++i) {
-        if (p.ph[i].Kpad / (8 * vec) < 3 || (size_t)p.N * p.ph[i].Kpad * esize >= 0x7fffffffull) return none;
+        if ((size_t)p.N * p.ph[i].Kpad * esize >= 0x7fffffffull) return none;
         nk_min = std::min(nk_min, p.ph[i].Kpad / (8 * vec));
+        nk_max = std::max(nk_max, p.ph[i].Kpad / (8 * vec));
+        single_tap = single_tap && p.ph[i].TH * p.ph[i].TW == 1;
     }
+    const bool c_tiles = (p.C % (8 * vec)) == 0;     // every lane of a K step sits in the same filter tap
+    if (!c_tiles && !single_tap) return none;
+    const long long tiles = (long long)cdiv(p.M, 128) * (p.N / 128) * nphase;
+    // shallow launches (1-2 K steps: the image-side layers as 1x1 convolutions over patches) are all prologue and epilogue for a
+    // workgroup-per-tile kernel: only the persistent pipeline overlaps them
+    if (nk_max < 3 || !c_tiles) return tiles >= 128 ? NtPlan{NT_PLAN_PERS, 1} : none;
     if (g_big_min_tiles > 0) {
         const int bn = (p.N % 256) == 0 ? 256 : 128;
         if ((long long)cdiv(p.M, 256) * (p.N / bn) * nphase >= g_big_min_tiles) return {bn == 256 ? NT_PLAN_BIG256 : NT_PLAN_BIG128, 1};
     }
-    const long long tiles = (long long)cdiv(p.M, 128) * (p.N / 128) * nphase;
     if (tiles < g_splitk_target && ws_bytes > 0) {
         int ns = 1;
         while (tiles * ns < g_splitk_target && ns < 16 && nk_min / (ns * 2) >= 8) ns *= 2;
@@ -1481,7 +1493,7 @@ extern "C" int eg_igemm_nt_tile(int dtype, int M, int N, int C, int K, int nphas
     const int vec = vec_of(dtype), bk = bk_of(dtype);
     NtParams p{};
     p.out_mode = EG_OUT_NHWC; p.M = M; p.N = N; p.C = C; p.B = 1; p.H = 1; p.W = 1;
-    for (int i = 0; i < nphase && i < 4; ++i) p.ph[i].Kpad = round_up(K, bk);
+    for (int i = 0; i < nphase && i < 4; ++i) { p.ph[i].Kpad = round_up(K, bk); p.ph[i].TH = 1; p.ph[i].TW = std::max(1, K / std::max(C, 1)); }
     const NtPlan plan = nt_plan(p, nphase, vec, dtype == EG_F32 ? 4 : 2, (size_t)1 << 40);
     if (plan.kind == NT_PLAN_BIG128) return 256 * 1000 + 133;
     if (plan.kind == NT_PLAN_BIG256) return 256 * 1000 + 134;

@@ -591,3 +591,33 @@ def test_igemm_splitk_range_starting_inside_a_tap(dtype):
     ops.SPLITK_WS.clear()
     rt, at = tol(dtype, Cin * 9)
     torch.testing.assert_close(nchw(y), F.conv2d(x, rq(w, dtype), None, 1, 1), rtol=rt, atol=at)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_igemm_shallow_single_tap_runs_on_persistent_pipeline(dtype):
+    """The image-side layers run as 1x1 convolutions over 48-channel patch rows (K = 48: one K step in bf16, two in fp32, the row
+    is not a whole number of K tiles).  Such launches go to the persistent pipeline whatever the tuning says; bit-exact vs the
+    register-staged kernel, several tiles per workgroup, ragged last tile."""
+    lib = eg._lib.lib()
+    g = torch.Generator().manual_seed(25)
+    B, H, Cin, Cout = 131, 32, 48, 128          # M = 134144 -> 1048 tiles over 512 workgroups
+    x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1
+    b = torch.randn(Cout, generator=g)
+    sig = torch.tensor([0.9], device=DEV)
+    c = ops.make_conv(B, H, H, Cin, Cout, 1, 1, 0)
+    wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
+    ops.pack_fwd(c, dtype, w.to(DEV), wp)
+    outs = []
+    for mode in (4, 0):
+        _set_variant(lib, mode, 0)
+        if mode:
+            assert lib.query("eg_igemm_nt_tile", dtype, B * H * H, Cout, Cin, Cin, 1) == 128135
+        y = torch.zeros(B, H, H, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
+        ops.conv_fwd(c, dtype, nhwc(x, dtype), wp, y, ops.epilogue(bias=b.to(DEV), sigma=sig, act=ops.ACT_LRELU, slope=0.1))
+        torch.cuda.synchronize()
+        outs.append(y)
+    _set_variant(lib, 4, 0)
+    assert torch.equal(outs[0], outs[1])
+    rt, at = tol(dtype, Cin)
+    torch.testing.assert_close(nchw(outs[0][:16]), F.leaky_relu(F.conv2d(x[:16], rq(w, dtype) / 0.9, b), 0.1), rtol=rt, atol=at)
