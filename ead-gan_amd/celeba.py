@@ -17,7 +17,7 @@ import torch.nn as nn
 from torch.nn.utils import spectral_norm
 
 from . import ops
-from .engine import Arena, ConvRec, Workspace, parse_dtype
+from .engine import Arena, ConvRec, SideStream, Workspace, parse_dtype
 from .ops import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, EG_BF16, EG_F32, OUT_NCHW_F32)
 
 # module-level hyper-parameters, mirroring the reference's global ``opt`` (argparse defaults, :39-51)
@@ -116,17 +116,32 @@ class _GenEngine:
                           ops.epilogue(bias=self._p(10, "bias"), act=ACT_TANH, out_mode=OUT_NCHW_F32))
         return self.img
 
-    def backward(self, dimg, grad):
-        """Accumulates d(loss)/d(params) into the flat gradient tensor ``grad`` (arena layout)."""
+    def backward(self, dimg, grad, side=None):
+        """Accumulates d(loss)/d(params) into the flat gradient tensor ``grad`` (arena layout).  With ``side`` (an
+        engine.SideStream) the weight/bias-gradient work of every layer is enqueued there, behind a fork taken right after
+        the layer's output gradient exists; the caller joins before it reads ``grad``."""
         dt, B, W, ws, gen = self.dtype, self.B, G_WIDTHS, self.ws, self.gen
         gof = lambda name: gen.arena.grad_of(name, grad)
         C, S = gen.channels, self.img.shape[-1]
+        wsw = side.ws if side is not None else ws
+
+        def wgrad_side(fn):
+            if side is None:
+                fn()
+            else:
+                side.fork()
+                with side:
+                    fn()
+
         # tanh backward fused with the bias gradient of the last ConvTranspose2d
         ops.act_grad_mul_bias_nchw(dimg, self.img, self.dimg_z, B, C, S * S, ACT_TANH, 0.0, ws.small, gof("conv_blocks.10.bias"))
         # L4 = ConvTranspose2d(128 -> C): weight / input gradients as 1x1-conv GEMMs over im2col patches of d(img)
         ops.im2col_img(dt, self.dimg_z, self.patches, B, C, S, S, 4, 2, 1, self.kp)
-        ns = ops.conv_wgrad(self.l4p.c, dt, self.patches, self.a[2], ws.slab)
-        ops.wgrad_reduce(ws.slab, ns, W[3], W[3], self.kp, 1, gof("conv_blocks.10.weight"))
+
+        def l4_wgrad():
+            ns = ops.conv_wgrad(self.l4p.c, dt, self.patches, self.a[2], wsw.slab)
+            ops.wgrad_reduce(wsw.slab, ns, W[3], W[3], self.kp, 1, gof("conv_blocks.10.weight"))
+        wgrad_side(l4_wgrad)
         ops.conv_fwd(self.l4p.c, dt, self.patches, self.l4p.wp_fwd, self.da[2], None)
         # L3..L1
         for i, idx in ((2, 7), (1, 4), (0, 1)):
@@ -136,14 +151,20 @@ class _GenEngine:
             ops.bn_bwd(dt, self.z[i], self.da[i], self.dz[i], M, W[i + 1], bn.weight, bn.bias, self.mean[i], self.invstd[i], ACT_RELU, 0.0,
                        gof(f"conv_blocks.{idx + 1}.weight"), gof(f"conv_blocks.{idx + 1}.bias"), ws.sums, ws.small)
             x_in = self.a[i - 1] if i > 0 else self.h0
-            ns = ops.conv_wgrad(r.c, dt, self.dz[i], x_in, ws.slab)
-            ops.wgrad_reduce(ws.slab, ns, r.Cout, r.Cout, r.Cin, 16, gof(f"conv_blocks.{idx}.weight"))
-            ops.bias_grad(dt, self.dz[i], M, W[i + 1], ws.small, gof(f"conv_blocks.{idx}.bias"))
+
+            def mid_wgrad(i=i, idx=idx, r=r, M=M, x_in=x_in):
+                ns = ops.conv_wgrad(r.c, dt, self.dz[i], x_in, wsw.slab)
+                ops.wgrad_reduce(wsw.slab, ns, r.Cout, r.Cout, r.Cin, 16, gof(f"conv_blocks.{idx}.weight"))
+                ops.bias_grad(dt, self.dz[i], M, W[i + 1], wsw.small, gof(f"conv_blocks.{idx}.bias"))
+            wgrad_side(mid_wgrad)
             ops.conv_fwd(r.c, dt, self.dz[i], r.wp_fwd, self.da[i - 1] if i > 0 else self.dh0, None)
+
         # L0
-        ns = ops.conv_wgrad(self.l0w.c, dt, self.dh0, self.inp, ws.slab)
-        ops.wgrad_reduce(ws.slab, ns, self.cpad, self.cin, W[0], 16, gof("conv_blocks.0.weight"))
-        ops.bias_grad(dt, self.dh0, B * 16, W[0], ws.small, gof("conv_blocks.0.bias"))
+        def l0_wgrad():
+            ns = ops.conv_wgrad(self.l0w.c, dt, self.dh0, self.inp, wsw.slab)
+            ops.wgrad_reduce(wsw.slab, ns, self.cpad, self.cin, W[0], 16, gof("conv_blocks.0.weight"))
+            ops.bias_grad(dt, self.dh0, B * 16, W[0], wsw.small, gof("conv_blocks.0.bias"))
+        wgrad_side(l0_wgrad)
 
 
 class _HipModule(nn.Module):
@@ -347,19 +368,32 @@ class _DiscEngine:
         ops.dense_small_fwd(dt, sl(self.a[3], 3), self.head.wp_fwd, self._m(4).bias, out, T * B, K, self.head.Kpad_fwd, self.nout)
         return out
 
-    def backward(self, t0, T, dout, grad, need_wgrad=True, need_dimg=False):
+    def backward(self, t0, T, dout, grad, need_wgrad=True, need_dimg=False, side=None):
         """``dout``: d(loss)/d(head output) of tapes t0..t0+T-1, [T*B,19] fp32.  Accumulates into flat ``grad`` (arena
-        layout); returns d(loss)/d(img) of tape t0 when ``need_dimg``."""
+        layout); returns d(loss)/d(img) of tape t0 when ``need_dimg``.  With ``side`` (engine.SideStream) the weight- and
+        bias-gradient work is enqueued there (see _GenEngine.backward); the caller joins before it reads ``grad``."""
         dt, B, W, ws, disc = self.dtype, self.B, D_WIDTHS, self.ws, self.disc
         gof = lambda name: disc.arena.grad_of(name, grad)
         g = self.geo[T]
         sl = lambda buf: buf[t0 * (buf.shape[0] // self.NT):]
         K = 16 * W[3]
+        wsw = side.ws if side is not None else ws
+
+        def wgrad_side(fn):
+            if side is None:
+                fn()
+            else:
+                side.fork()
+                with side:
+                    fn()
+
         if need_wgrad:
-            ops.cast_pad(dt, dout, self.dout_t, T * B, self.nout, 32)
-            ns = ops.conv_wgrad(g["headw"], dt, sl(self.a[3]), self.dout_t, ws.slab)
-            ops.wgrad_reduce(ws.slab, ns, 32, self.nout, W[3], 16, gof("main.8.weight"))
-            ops.dense_small_bgrad(dout, gof("main.8.bias"), T * B, self.nout)
+            def head_wgrad():
+                ops.cast_pad(dt, dout, self.dout_t, T * B, self.nout, 32)
+                ns = ops.conv_wgrad(g["headw"], dt, sl(self.a[3]), self.dout_t, wsw.slab)
+                ops.wgrad_reduce(wsw.slab, ns, 32, self.nout, W[3], 16, gof("main.8.weight"))
+                ops.dense_small_bgrad(dout, gof("main.8.bias"), T * B, self.nout)
+            wgrad_side(head_wgrad)
         # dzs_3 = (W5^T dout) * lrelu'(a3) / sigma_3[tape]
         ops.dense_small_bwd(dt, dout, self.head.wp_fwd, sl(self.a[3]), sl(self.dz[3]), T * B, K, self.head.Kpad_fwd, self.nout, ACT_LRELU, LRELU_SLOPE,
                             self.sigma[3][t0:], B)
@@ -368,12 +402,14 @@ class _DiscEngine:
             geo = g["mid"][i - 1] if i > 0 else g["l1p"]
             x_in = sl(self.a[i - 1]) if i > 0 else sl(self.patches)
             if need_wgrad:
-                ops.bias_grad_sn(dt, sl(self.dz[i]), sl(self.a[i]), m.bias, T * self.rows(i), W[i], self.rows(i), self.sigma[i][t0:], LRELU_SLOPE,
-                                 ws.small, gof(f"main.{2 * i}.bias"), self.coef[i])
-                ns = ops.conv_wgrad(geo, dt, x_in, sl(self.dz[i]), ws.slab)
-                taps = 16 if i > 0 else 1
-                ops.wgrad_reduce_rank1(ws.slab, ns, W[i], W[i], self.cin[i], taps, gof(f"main.{2 * i}.weight_orig"), T, self.coef[i],
-                                       self.u[i][t0:], self.v[i][t0:])
+                def layer_wgrad(i=i, m=m, geo=geo, x_in=x_in):
+                    ops.bias_grad_sn(dt, sl(self.dz[i]), sl(self.a[i]), m.bias, T * self.rows(i), W[i], self.rows(i), self.sigma[i][t0:], LRELU_SLOPE,
+                                     wsw.small, gof(f"main.{2 * i}.bias"), self.coef[i])
+                    ns = ops.conv_wgrad(geo, dt, x_in, sl(self.dz[i]), wsw.slab)
+                    taps = 16 if i > 0 else 1
+                    ops.wgrad_reduce_rank1(wsw.slab, ns, W[i], W[i], self.cin[i], taps, gof(f"main.{2 * i}.weight_orig"), T, self.coef[i],
+                                           self.u[i][t0:], self.v[i][t0:])
+                wgrad_side(layer_wgrad)
             if i > 0:
                 # dzs_{i-1} = conv^T(dzs_i, W_i) * lrelu'(a_{i-1}) / sigma_{i-1}[tape]
                 ops.conv_bwd_data(geo, dt, sl(self.dz[i]), self.mid[i - 1].wp_bwd, sl(self.dz[i - 1]),
@@ -523,7 +559,7 @@ class CelebATrainer:
     ``allreduce``: optional callable(flat_grad_tensor) applied after each backward pass (data parallel)."""
 
     def __init__(self, generator: Generator, discriminator: Discriminator, batch_size: int, dtype="bf16", allreduce=None,
-                 lr_g=1e-3, lr_d=2e-4, lr_info=2e-4, betas=(0.5, 0.999), lambda_cat=1.0, lambda_con=1.0, lambda_affine=1.0):
+                 lr_g=1e-3, lr_d=2e-4, lr_info=2e-4, betas=(0.5, 0.999), lambda_cat=1.0, lambda_con=1.0, lambda_affine=1.0, overlap=True):
         self.G, self.D, self.B = generator, discriminator, batch_size
         dt = parse_dtype(dtype)
         generator.set_compute_dtype(dt)
@@ -554,6 +590,9 @@ class CelebATrainer:
         self.onehot = torch.empty(B, generator.n_classes, device=dev, dtype=torch.float32)
         self.labels = torch.empty(B, device=dev, dtype=torch.int64)
         self.graph = None
+        # weight-gradient chains and re-packing run on a second stream beside the backward-data chain (same arithmetic, same order
+        # inside every chain -> bit-identical results with and without)
+        self.side = SideStream(dev, Workspace.get(dev)) if overlap else None
 
     # -- the hot path ---------------------------------------------------------------------------------
     def _adam(self, arena, m, v, lr, slot, tick):
@@ -568,39 +607,57 @@ class CelebATrainer:
         # A = get_matrix(code[:, :5]); scaled = trans_2D(real, A[:, 0:2])           (:325-327)
         ops.theta_rpqxy(self.code, cd, B, self.theta)
         ops.warp_affine(self.real, self.theta, self.scaled, B, G.channels, G.img_size, G.img_size)
+        side = self.side
+
+        def on_side(fn):                                # fn's launches go to the side stream, behind everything enqueued so far
+            if side is None:
+                fn()
+            else:
+                side.fork()
+                with side:
+                    fn()
+
+        join = side.join if side is not None else (lambda: None)
         # ---- 1) generator adversarial step (:334-345) ----
         ops.fill_f32(ga.grad)
         gen = ge.forward(self.z, self.onehot, self.code)
         out = de.forward([gen])
         ops.loss_bce_sigmoid(out, 19, 0, B, 1.0, 1.0, self.losses[0:1], self.dout[:B])
         dimg = de.backward(0, 1, self.dout[:B], da.grad, need_wgrad=False, need_dimg=True)
-        ge.backward(dimg, ga.grad)
+        ge.backward(dimg, ga.grad, side)
+        join()
         if self.allreduce is not None:
             self.allreduce(ga.grad)
         self._adam(ga, self.mG, self.vG, self.lr[0], 0, True)
-        ge.repack()
+        on_side(ge.repack)                              # G's panels are next read in step 3
         # ---- 2) discriminator step (:353-366); gen is the (detached) output of step 1; D(scaled) then D(gen), batched ----
         ops.fill_f32(da.grad)
         out = de.forward([self.scaled, gen])
         ops.loss_bce_sigmoid(out[:B], 19, 0, B, 1.0, 0.5, self.losses[1:2], self.dout[:B])
         ops.loss_bce_sigmoid(out[B:], 19, 0, B, 0.0, 0.5, self.losses[1:2], self.dout[B:2 * B])
-        de.backward(0, 2, self.dout[:2 * B], da.grad)
+        de.backward(0, 2, self.dout[:2 * B], da.grad, side=side)
+        join()
         if self.allreduce is not None:
             self.allreduce(da.grad)
         self._adam(da, self.mD, self.vD, self.lr[1], 1, True)
-        de.repack()
+        on_side(de.repack)                              # beside the generator forward below
         # ---- 3) info + affine step (:375-401): D(gen), D(scaled), D(real) batched as tapes 0,1,2 ----
         ops.fill_f32(ga.grad)
         ops.fill_f32(da.grad)
         gen = ge.forward(self.z, self.onehot, self.code)
+        join()
         out = de.forward([gen, self.scaled, self.real])
         o_gen, o_trans, o_real = out[:B], out[B:2 * B], out[2 * B:]
         ops.loss_mse(o_gen, 19, 1, cd, B, self.code, cd, 0.0, lcon, self.losses[2:3], self.dout[:B])
         ops.loss_ce_softmaxed(o_gen, 19, cd + 1, nc, B, self.labels, lcat, self.losses[2:3], self.dout[:B])
         ops.loss_affine_rpqxy(o_real, o_trans, 19, 1, B, self.code, cd, laff, self.losses[2:3], self.dout[2 * B:], self.dout[B:2 * B])
-        dimg = de.backward(0, 3, self.dout, da.grad, need_dimg=True)
-        pending = self.allreduce.start(da.grad) if (self.allreduce is not None and hasattr(self.allreduce, "start")) else None
-        ge.backward(dimg, ga.grad)                      # overlaps with the D-gradient all-reduce
+        dimg = de.backward(0, 3, self.dout, da.grad, need_dimg=True, side=side)
+        pending = None
+        if self.allreduce is not None and hasattr(self.allreduce, "start"):
+            join()                                      # D's weight gradients are complete
+            pending = self.allreduce.start(da.grad)
+        ge.backward(dimg, ga.grad, side)                # beside D's weight-gradient chain / the D-gradient all-reduce
+        join()
         if self.allreduce is not None:
             self.allreduce(ga.grad)
             if pending is not None:
@@ -609,8 +666,9 @@ class CelebATrainer:
                 self.allreduce(da.grad)
         self._adam(ga, self.miG, self.viG, self.lr[2], 2, True)
         self._adam(da, self.miD, self.viD, self.lr[2], 2, False)
+        on_side(de.repack)
         ge.repack()
-        de.repack()
+        join()
 
     # -- public API -----------------------------------------------------------------------------------
     def import_adam_state(self, opt_G, opt_D, opt_info):

@@ -51,7 +51,7 @@ class Workspace:
 
     _per_device = {}
 
-    def __init__(self, device):
+    def __init__(self, device, splitk=True):
         self.device = device
         self.slab = torch.empty(0, device=device, dtype=torch.float32)
         self.gtmp = torch.empty(0, device=device, dtype=torch.float32)
@@ -59,8 +59,9 @@ class Workspace:
         self.partials = torch.empty(max(2048, ops.sn_partials()), device=device, dtype=torch.float32)
         self.sums = torch.empty(0, device=device, dtype=torch.float32)
         # split-K partial tiles of the NT kernel: the planner splits up to ~2x512 tiles of 128x128 fp32 (64 KiB each)
-        self.splitk = torch.empty(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)
-        ops.set_splitk_workspace(self.splitk)
+        if splitk:
+            self.splitk = torch.empty(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)
+            ops.set_splitk_workspace(self.splitk)
 
     @classmethod
     def get(cls, device) -> "Workspace":
@@ -85,6 +86,38 @@ class Workspace:
 
     def need_sums(self, floats):
         self._grow("sums", floats)
+
+
+class SideStream:
+    """Second HIP stream (with its own scratch) for work that does not feed the critical path of a training step: the
+    weight-gradient GEMMs with their reductions and bias-gradient sums run beside the backward-data GEMMs of the layers
+    below, and weight re-packing after an optimizer step runs beside the next sub-step.  ``fork()``: the side stream
+    waits for everything enqueued on the current stream so far; ``join()``: the current stream waits for the side
+    stream.  Both are event record/wait pairs, capturable into the step's hipGraph.  The side stream never launches NT
+    convolutions (the split-K scratch belongs to the main stream)."""
+
+    def __init__(self, device, like: "Workspace"):
+        self.stream = torch.cuda.Stream(device)
+        self.ws = Workspace(device, splitk=False)
+        for name in ("slab", "gtmp", "small", "sums", "partials"):
+            setattr(self.ws, name, torch.empty_like(getattr(like, name)))
+
+    def fork(self):
+        ev = torch.cuda.Event()
+        ev.record()
+        self.stream.wait_event(ev)
+
+    def join(self):
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        torch.cuda.current_stream().wait_event(ev)
+
+    def __enter__(self):
+        self._ctx = torch.cuda.stream(self.stream)
+        return self._ctx.__enter__()
+
+    def __exit__(self, *a):
+        return self._ctx.__exit__(*a)
 
 
 class ConvRec:

@@ -276,3 +276,27 @@ def test_graph_replay_equals_eager():
         torch.cuda.synchronize()
         losses.append(torch.stack(out).cpu())
     assert torch.equal(losses[0], losses[1]), (losses[0], losses[1])
+
+
+def test_side_stream_overlap_is_bit_identical():
+    """Weight-gradient chains and re-packing on the second stream (eager and captured) vs everything on one stream: the same
+    kernels on the same operands in the same per-chain order -> identical losses and identical parameters after 3 steps."""
+    B = 8
+    res = []
+    for overlap, capture in ((False, False), (True, False), (True, True)):
+        orc, G, D = build_pair(11, "bf16")
+        tr = eg.celeba.CelebATrainer(G, D, B, dtype="bf16", overlap=overlap)
+        rng = np.random.RandomState(2)
+        real = co.synthetic_real(B, seed=6).to(DEV)
+        out = []
+        for i in range(3):
+            z, code, labels = co.draw_step_inputs(rng, B)
+            tr.load_inputs(real, z.to(DEV), code.to(DEV), labels.to(DEV))
+            if capture and i == 1:
+                tr.capture()
+            out.append(tr.step_resident().clone())
+        torch.cuda.synchronize()
+        res.append((torch.stack(out).cpu(), G.arena.flat.clone().cpu(), D.arena.flat.clone().cpu()))
+    for r in res[1:]:
+        assert torch.equal(r[0], res[0][0]), (r[0], res[0][0])
+        assert torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
