@@ -352,44 +352,60 @@ extern "C" int eg_cast_pad(int dtype, const float* src, void* dst, int rows, int
 // ------------------------------------------------------------------------------------------------
 // small-N dense head:  y[b][n] = sum_k x[b][k] * Wp[n][k] (+ bias[n]);  x dtype T [B][K], Wp dtype T [N][Kpad]
 // ------------------------------------------------------------------------------------------------
+#define EG_DS_ROWS 4   // batch rows per workgroup: the weight panel (N x K, e.g. 19 x 16384) is streamed once per 4 rows
 template <typename T>
 __global__ __launch_bounds__(256) void dense_small_fwd_kernel(const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ bias,
-                                                              float* __restrict__ y, int K, int Kpad, int N, const float* __restrict__ sigma,
+                                                              float* __restrict__ y, int B, int K, int Kpad, int N, const float* __restrict__ sigma,
                                                               int sigma_rows) {
     constexpr int VEC = Elt<T>::VEC;
-    __shared__ float part[4][64];
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const T* xr = x + (size_t)b * K;
-    for (int n0 = 0; n0 < N; n0 += 8) {          // 8 outputs per sweep over x: x chunks are re-read from L1/L2, W streamed once
-        float a[8];
+    constexpr int R = EG_DS_ROWS;
+    __shared__ float part[4][R][64];
+    const int b0 = blockIdx.x * R, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int n0 = 0; n0 < N; n0 += 8) {          // 8 outputs x R rows per sweep over x
+        float a[R][8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) a[q] = 0.f;
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[r][q] = 0.f;
         for (int k0 = threadIdx.x * VEC; k0 < K; k0 += 256 * VEC) {
-            const uint4 xv = *reinterpret_cast<const uint4*>(xr + k0);
-            const T* xe = reinterpret_cast<const T*>(&xv);
-            float xf[VEC];
+            float xf[R][VEC];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) xf[j] = Elt<T>::ld(xe + j);
+            for (int r = 0; r < R; ++r) {
+                const int b = min(b0 + r, B - 1);
+                const uint4 xv = *reinterpret_cast<const uint4*>(x + (size_t)b * K + k0);
+                const T* xe = reinterpret_cast<const T*>(&xv);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) xf[r][j] = Elt<T>::ld(xe + j);
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 if (n0 + q < N) {
                     const uint4 wv = *reinterpret_cast<const uint4*>(wp + (size_t)(n0 + q) * Kpad + k0);
                     const T* we = reinterpret_cast<const T*>(&wv);
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) a[q] += xf[j] * Elt<T>::ld(we + j);
+                    for (int j = 0; j < VEC; ++j) {
+                        const float wf = Elt<T>::ld(we + j);
+#pragma unroll
+                        for (int r = 0; r < R; ++r) a[r][q] += xf[r][j] * wf;
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const float w = wave_sum(a[q]);
-            if (lane == 0) part[wave][n0 + q < 64 ? n0 + q : 63] = w;
-        }
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float w = wave_sum(a[r][q]);
+                if (lane == 0) part[wave][r][n0 + q < 64 ? n0 + q : 63] = w;
+            }
     }
     __syncthreads();
-    const float inv = sigma ? 1.f / sigma[sigma_rows ? b / sigma_rows : 0] : 1.f;
-    if (threadIdx.x < N)
-        y[(size_t)b * N + threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]) * inv + (bias ? bias[threadIdx.x] : 0.f);
+    const int r = threadIdx.x >> 6, n = threadIdx.x & 63;
+    if (r < R && n < N && b0 + r < B) {
+        const int b = b0 + r;
+        const float inv = sigma ? 1.f / sigma[sigma_rows ? b / sigma_rows : 0] : 1.f;
+        y[(size_t)b * N + n] = (part[0][r][n] + part[1][r][n] + part[2][r][n] + part[3][r][n]) * inv + (bias ? bias[n] : 0.f);
+    }
 }
 
 // dx[b][k] = (sum_n dy[b][n] * Wp[n][k]) * act'(mask[b][k])
@@ -455,8 +471,8 @@ __global__ __launch_bounds__(256) void dense_small_wgrad_kernel(const float* __r
 extern "C" int eg_dense_small_fwd(int dtype, const void* x, const void* wp, const float* bias, float* y, int B, int K, int Kpad, int N,
                                   eg_stream_t s) {
     EG_REQUIRE(x && wp && y && N <= 64 && K % (dtype == EG_F32 ? 4 : 8) == 0, "eg_dense_small_fwd: bad argument (N<=64)");
-    if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_fwd_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)s, (const float*)x, (const float*)wp, bias, y, K, Kpad, N, (const float*)nullptr, 0);
-    else hipLaunchKernelGGL(dense_small_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)wp, bias, y, K, Kpad, N, (const float*)nullptr, 0);
+    if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_fwd_kernel<float>, dim3(cdiv(B, EG_DS_ROWS)), dim3(256), 0, (hipStream_t)s, (const float*)x, (const float*)wp, bias, y, B, K, Kpad, N, (const float*)nullptr, 0);
+    else hipLaunchKernelGGL(dense_small_fwd_kernel<bf16_t>, dim3(cdiv(B, EG_DS_ROWS)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)wp, bias, y, B, K, Kpad, N, (const float*)nullptr, 0);
     EG_LAUNCH_CHECK();
     return 0;
 }
@@ -464,8 +480,8 @@ extern "C" int eg_dense_small_fwd(int dtype, const void* x, const void* wp, cons
 extern "C" int eg_dense_small_fwd_sn(int dtype, const void* x, const void* wp, const float* bias, float* y, int B, int K, int Kpad, int N,
                                      const float* sigma, int sigma_rows, eg_stream_t s) {
     EG_REQUIRE(x && wp && y && sigma && N <= 64 && K % (dtype == EG_F32 ? 4 : 8) == 0, "eg_dense_small_fwd_sn: bad argument (N<=64)");
-    if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_fwd_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)s, (const float*)x, (const float*)wp, bias, y, K, Kpad, N, sigma, sigma_rows);
-    else hipLaunchKernelGGL(dense_small_fwd_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)wp, bias, y, K, Kpad, N, sigma, sigma_rows);
+    if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_fwd_kernel<float>, dim3(cdiv(B, EG_DS_ROWS)), dim3(256), 0, (hipStream_t)s, (const float*)x, (const float*)wp, bias, y, B, K, Kpad, N, sigma, sigma_rows);
+    else hipLaunchKernelGGL(dense_small_fwd_kernel<bf16_t>, dim3(cdiv(B, EG_DS_ROWS)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)wp, bias, y, B, K, Kpad, N, sigma, sigma_rows);
     EG_LAUNCH_CHECK();
     return 0;
 }
@@ -518,17 +534,26 @@ extern "C" int eg_dense_small_bwd(int dtype, const float* dy, const void* wp, co
 }
 
 /* gw (master [N][Cin][taps], accumulate) and gb[n] += sum_b dy[b][n] */
-__global__ void dense_small_bgrad_kernel(const float* dy, float* gb, int B, int N) {
-    const int n = threadIdx.x;
-    if (n >= N) return;
+__global__ __launch_bounds__(512) void dense_small_bgrad_kernel(const float* dy, float* gb, int B, int N) {
+    // 8 row groups x 64 columns: independent loads in flight instead of one dependent chain per column; fixed-order combine
+    __shared__ float part[8][64];
+    const int n = threadIdx.x & 63, g = threadIdx.x >> 6;
     float a = 0.f;
-    for (int b = 0; b < B; ++b) a += dy[(size_t)b * N + n];
-    gb[n] += a;
+    if (n < N)
+        for (int b = g; b < B; b += 8) a += dy[(size_t)b * N + n];
+    part[g][n] = a;
+    __syncthreads();
+    if (g == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += part[q][n];
+        gb[n] += t;
+    }
 }
 
 extern "C" int eg_dense_small_bgrad(const float* dy, float* gb, int B, int N, eg_stream_t s) {
     EG_REQUIRE(dy && gb && N <= 64, "eg_dense_small_bgrad: bad argument");
-    hipLaunchKernelGGL(dense_small_bgrad_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, dy, gb, B, N);
+    hipLaunchKernelGGL(dense_small_bgrad_kernel, dim3(1), dim3(512), 0, (hipStream_t)s, dy, gb, B, N);
     EG_LAUNCH_CHECK();
     return 0;
 }
@@ -539,7 +564,7 @@ extern "C" int eg_dense_small_wgrad(int dtype, const float* dy, const void* x, f
     const size_t lds = (size_t)B * N * sizeof(float);
     if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_wgrad_kernel<float>, dim3(cdiv(K, 256)), dim3(256), lds, (hipStream_t)s, dy, (const float*)x, gw, B, K, N, Cin, taps);
     else hipLaunchKernelGGL(dense_small_wgrad_kernel<bf16_t>, dim3(cdiv(K, 256)), dim3(256), lds, (hipStream_t)s, dy, (const bf16_t*)x, gw, B, K, N, Cin, taps);
-    if (gb) hipLaunchKernelGGL(dense_small_bgrad_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, dy, gb, B, N);
+    if (gb) hipLaunchKernelGGL(dense_small_bgrad_kernel, dim3(1), dim3(512), 0, (hipStream_t)s, dy, gb, B, N);
     EG_LAUNCH_CHECK();
     return 0;
 }

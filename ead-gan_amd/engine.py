@@ -141,7 +141,5 @@ class ConvRec:
             ws.need_small(ops.bias_grad_ws_floats(B * max(self.OH * self.OW, (H << up) * (W << up)), max(Cin, Cout)))
 
     def pack(self, w_master):
-        if self.wp_fwd is not None:
-            ops.pack_fwd(self.c, self.dtype, w_master, self.wp_fwd)
-        if self.wp_bwd is not None:
-            ops.pack_bwd(self.c, self.dtype, w_master, self.wp_bwd)
+        if self.wp_fwd is not None or self.wp_bwd is not None:
+            ops.pack_conv(self.c, self.dtype, w_master, self.wp_fwd, self.wp_bwd)

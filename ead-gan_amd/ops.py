@@ -80,6 +80,10 @@ def pack_bwd(c, dtype, w_master, wp):
     lib().call("eg_pack_bwd", ctypes.byref(c), dtype, _p(w_master), _p(wp), _stream())
 
 
+def pack_conv(c, dtype, w_master, wp_fwd, wp_bwd):
+    lib().call("eg_pack_conv", ctypes.byref(c), dtype, _p(w_master), _p(wp_fwd), _p(wp_bwd), _stream())
+
+
 def pack_strided(dtype, w, wp, N, K, Kpad, n_div, s_hi, s_lo, s_k):
     lib().call("eg_pack_strided", dtype, _p(w), _p(wp), N, K, Kpad, n_div, s_hi, s_lo, s_k, _stream())
 

@@ -69,6 +69,8 @@ size_t eg_pack_fwd_elems(const eg_conv* c, int dtype);                 /* elemen
 size_t eg_pack_bwd_elems(const eg_conv* c, int dtype);                 /* elements of Wp_bwd */
 int eg_pack_fwd(const eg_conv* c, int dtype, const float* w_master, void* wp, eg_stream_t s);
 int eg_pack_bwd(const eg_conv* c, int dtype, const float* w_master, void* wp, eg_stream_t s);
+/* both panels in one pass over the master (either destination may be NULL); same bytes as eg_pack_fwd + eg_pack_bwd */
+int eg_pack_conv(const eg_conv* c, int dtype, const float* w_master, void* wp_fwd, void* wp_bwd, eg_stream_t s);
 /* Y = conv(X, W) */
 int eg_conv_fwd(const eg_conv* c, int dtype, const void* X, const void* wp_fwd, void* Y,
                 const eg_epilogue* ep, eg_stream_t s);

@@ -621,3 +621,26 @@ def test_igemm_shallow_single_tap_runs_on_persistent_pipeline(dtype):
     assert torch.equal(outs[0], outs[1])
     rt, at = tol(dtype, Cin)
     torch.testing.assert_close(nchw(outs[0][:16]), F.leaky_relu(F.conv2d(x[:16], rq(w, dtype) / 0.9, b), 0.1), rtol=rt, atol=at)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("k,stride,pad,Cin,Cout", [(4, 2, 1, 32, 64), (4, 2, 1, 128, 48), (3, 1, 1, 64, 32), (4, 1, 0, 64, 16), (3, 1, 1, 32, 16)])
+def test_pack_conv_tiled_equals_per_element_pack(dtype, k, stride, pad, Cin, Cout):
+    """eg_pack_conv (LDS-tiled, both panels in one pass; falls back where K needs padding) writes exactly the bytes of
+    eg_pack_fwd + eg_pack_bwd."""
+    g = torch.Generator().manual_seed(31)
+    w = torch.randn(Cout, Cin, k, k, generator=g).to(DEV)
+    c = ops.make_conv(2, 16, 16, Cin, Cout, k, stride, pad)
+    tdt = ops.torch_dtype(dtype)
+    f0 = torch.full((ops.pack_fwd_elems(c, dtype),), 7.0, device=DEV, dtype=tdt)
+    b0 = torch.full((ops.pack_bwd_elems(c, dtype),), 7.0, device=DEV, dtype=tdt)
+    f1, b1 = f0.clone(), b0.clone()
+    ops.pack_fwd(c, dtype, w, f0)
+    ops.pack_bwd(c, dtype, w, b0)
+    ops.pack_conv(c, dtype, w, f1, b1)
+    torch.cuda.synchronize()
+    assert torch.equal(f0, f1) and torch.equal(b0, b1)
+    f2 = torch.full_like(f0, 7.0)
+    ops.pack_conv(c, dtype, w, f2, None)
+    torch.cuda.synchronize()
+    assert torch.equal(f0, f2)
