@@ -365,7 +365,7 @@ class _DiscEngine:
             ops.conv_fwd(g["mid"][i], dt, sl(self.a[i], i), self.mid[i].wp_fwd, sl(self.a[i + 1], i + 1), ep(i + 1))
         K = 16 * W[3]
         out = self.out[t0 * B:(t0 + T) * B]
-        ops.dense_small_fwd(dt, sl(self.a[3], 3), self.head.wp_fwd, self._m(4).bias, out, T * B, K, self.head.Kpad_fwd, self.nout)
+        ops.dense_small_fwd(dt, sl(self.a[3], 3), self.head.wp_fwd, self._m(4).bias, out, T * B, K, self.head.Kpad_fwd, self.nout, ws.small)
         return out
 
     def backward(self, t0, T, dout, grad, need_wgrad=True, need_dimg=False, side=None):

@@ -2075,6 +2075,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (MODE == 2)
         for (int q = 0; q < ntapes; ++q) un[q] = coef[q] * u[(size_t)q * N + n];
     const int crow = c_row ? c_row : C;                 // row length of the destination (<= C when the slab is column padded)
+    if (cw == EG_RC && c0 + EG_RC <= crow && (C & 3) == 0) {
+        // full 64-channel block: 16-byte loads along the channels (one float4 per thread and slab for k = 4), same summation order
+        for (int e4 = threadIdx.x; e4 < T * (EG_RC / 4); e4 += 256) {
+            const int t = e4 / (EG_RC / 4), c = (e4 % (EG_RC / 4)) * 4;
+            const size_t si = ((size_t)n * T + t) * C + c0 + c;
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int z = 0; z < nsplit; ++z) {
+                const float4 x = *reinterpret_cast<const float4*>(slab + z * split_stride + si);
+                a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+            }
+            if (MODE == 2)
+                for (int q = 0; q < ntapes; ++q) {
+                    const float* vq = v + (size_t)q * crow * T + (size_t)(c0 + c) * T + t;
+                    a.x -= un[q] * vq[0]; a.y -= un[q] * vq[T]; a.z -= un[q] * vq[2 * T]; a.w -= un[q] * vq[3 * T];
+                }
+            tile[c * (T + 1) + t] = a.x; tile[(c + 1) * (T + 1) + t] = a.y; tile[(c + 2) * (T + 1) + t] = a.z; tile[(c + 3) * (T + 1) + t] = a.w;
+        }
+    } else
     for (int e = threadIdx.x; e < T * EG_RC; e += 256) {
         const int t = e / EG_RC, c = e % EG_RC;
         if (c < cw && c0 + c < crow) {
@@ -2172,11 +2190,21 @@ extern "C" int eg_wgrad_reduce_sn(const eg_conv* c, const float* slab, int nspli
 // ------------------------------------------------------------------------------------------------
 // bias gradient: column sums of a [rows][N] tensor (two deterministic stages)
 // ------------------------------------------------------------------------------------------------
-#define EG_BG_RPB 256   // rows per block
+// rows per workgroup: 256, halved (down to 16) until the launch has >= 512 workgroups -- the head layers have few rows (B*16) of
+// 1024 columns, where 256-row blocks left 8-24 workgroups walking a dependent-load chain
+static int bg_rpb(int rows_per_group, int ngroups, int gx) {
+    int rpb = 256;
+    while (rpb > 16 && (long long)gx * ngroups * cdiv(rows_per_group, rpb) < 512) rpb >>= 1;
+    return rpb;
+}
+static int bg_gx(int N, int dtype) {
+    const int cpr = N / (dtype == EG_F32 ? 4 : 8);
+    return cdiv(cpr, cpr < 256 ? cpr : 256);
+}
 
 // block = 256 threads = (N/VEC chunk columns) x (row lanes); 16-byte loads; LDS combine of the row lanes
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int rows, int N, float* __restrict__ partials) {
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int rows, int N, int rpb, float* __restrict__ partials) {
     constexpr int VEC = Elt<T>::VEC;
     __shared__ float sm[256 * VEC];
     const int cpr = N / VEC;                       // chunks per row (host guarantees cpr <= 256 and 256 % cpr == 0 via tiling in x)
@@ -2184,7 +2212,7 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     const int lanes = 256 / ccols;
     const int cj = threadIdx.x % ccols, rl = threadIdx.x / ccols;
     const int chunk = blockIdx.x * ccols + cj;
-    const int r0 = blockIdx.y * EG_BG_RPB, r1 = min(rows, r0 + EG_BG_RPB);
+    const int r0 = blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
     float a[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) a[j] = 0.f;
@@ -2220,7 +2248,10 @@ __global__ void colsum_final_kernel(const float* __restrict__ partials, int nrb,
     if (lane == 0) gb[j] += a * (scale ? scale[0] : 1.f);
 }
 
-extern "C" size_t eg_bias_grad_ws_floats(int rows, int N) { return (size_t)cdiv(rows, EG_BG_RPB) * N; }
+extern "C" size_t eg_bias_grad_ws_floats(int rows, int N) {
+    // dtype-independent upper bound: the bf16 launch has the fewer column blocks, hence the smaller rows-per-block
+    return (size_t)cdiv(rows, bg_rpb(rows, 1, bg_gx(N, EG_BF16))) * N;
+}
 
 extern "C" int eg_bias_grad(int dtype, const void* dY, int rows, int N, int bias_mod, float* partials, float* gb, eg_stream_t s) {
     EG_REQUIRE(dY && partials && gb && rows > 0 && N > 0, "eg_bias_grad: bad argument");
@@ -2229,10 +2260,11 @@ extern "C" int eg_bias_grad(int dtype, const void* dY, int rows, int N, int bias
     const int cpr = N / vecw;
     const int ccols = cpr < 256 ? cpr : 256;
     EG_REQUIRE(256 % ccols == 0, "eg_bias_grad: N/vec must divide 256 or be a multiple of it");
-    const int nrb = cdiv(rows, EG_BG_RPB);
+    const int rpb = bg_rpb(rows, 1, cdiv(cpr, ccols));
+    const int nrb = cdiv(rows, rpb);
     dim3 grid(cdiv(cpr, ccols), nrb);
-    if (dtype == EG_F32) hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)dY, rows, N, partials);
-    else hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)dY, rows, N, partials);
+    if (dtype == EG_F32) hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)dY, rows, N, rpb, partials);
+    else hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)dY, rows, N, rpb, partials);
     const int nb = bias_mod > 0 ? bias_mod : N;
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(nb, 4)), dim3(256), 0, (hipStream_t)s, partials, nrb, N, nb, (const float*)nullptr, gb);
     EG_LAUNCH_CHECK();
@@ -2242,7 +2274,7 @@ extern "C" int eg_bias_grad(int dtype, const void* dY, int rows, int N, int bias
 // ---- tape-segmented bias gradient + <G,W>/sigma^2 coefficient from activations (spectrally normalised layers) --------
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_sn_partial_kernel(const T* __restrict__ x, const T* __restrict__ act, const float* __restrict__ bias,
-                                                                int N, int rows_per_tape, int blocks_per_tape, float inv_slope,
+                                                                int N, int rows_per_tape, int blocks_per_tape, int rpb, float inv_slope,
                                                                 float* __restrict__ partials, float* __restrict__ dots) {
     constexpr int VEC = Elt<T>::VEC;
     __shared__ float sm[256 * VEC];
@@ -2253,8 +2285,8 @@ __global__ __launch_bounds__(256) void colsum_sn_partial_kernel(const T* __restr
     const int cj = threadIdx.x % ccols, rl = threadIdx.x / ccols;
     const int chunk = blockIdx.x * ccols + cj;
     const int tape = blockIdx.y / blocks_per_tape, blk = blockIdx.y % blocks_per_tape;
-    const int r0 = tape * rows_per_tape + blk * EG_BG_RPB;
-    const int r1 = min(tape * rows_per_tape + rows_per_tape, r0 + EG_BG_RPB);
+    const int r0 = tape * rows_per_tape + blk * rpb;
+    const int r1 = min(tape * rows_per_tape + rows_per_tape, r0 + rpb);
     float a[VEC], bv[VEC];
     float dot = 0.f;
 #pragma unroll
@@ -2311,7 +2343,7 @@ __global__ void colsum_sn_final_kernel(const float* __restrict__ partials, const
 
 extern "C" size_t eg_bias_grad_sn_ws_floats(int rows, int N, int rows_per_tape) {
     const int ntapes = rows / rows_per_tape;
-    const int bpt = cdiv(rows_per_tape, EG_BG_RPB);
+    const int bpt = cdiv(rows_per_tape, bg_rpb(rows_per_tape, 1, bg_gx(N, EG_BF16)));    // upper bound over tape counts and dtypes
     return (size_t)ntapes * bpt * (N + 64);
 }
 
@@ -2325,14 +2357,15 @@ extern "C" int eg_bias_grad_sn(int dtype, const void* dzs, const void* a, const 
     EG_REQUIRE(256 % ccols == 0, "eg_bias_grad_sn: N/vec must divide 256 or be a multiple of it");
     const int ntapes = rows / rows_per_tape;
     EG_REQUIRE(ntapes <= 4, "eg_bias_grad_sn: at most 4 tapes");
-    const int bpt = cdiv(rows_per_tape, EG_BG_RPB);
-    const int nrb = ntapes * bpt;
     const int gx = cdiv(cpr, ccols);
+    const int rpb = bg_rpb(rows_per_tape, ntapes, gx);
+    const int bpt = cdiv(rows_per_tape, rpb);
+    const int nrb = ntapes * bpt;
     float* partials = ws;
     float* dots = ws + (size_t)nrb * N;
     dim3 grid(gx, nrb);
-    if (dtype == EG_F32) hipLaunchKernelGGL(colsum_sn_partial_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)dzs, (const float*)a, bias, N, rows_per_tape, bpt, 1.f / slope, partials, dots);
-    else hipLaunchKernelGGL(colsum_sn_partial_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)dzs, (const bf16_t*)a, bias, N, rows_per_tape, bpt, 1.f / slope, partials, dots);
+    if (dtype == EG_F32) hipLaunchKernelGGL(colsum_sn_partial_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)dzs, (const float*)a, bias, N, rows_per_tape, bpt, rpb, 1.f / slope, partials, dots);
+    else hipLaunchKernelGGL(colsum_sn_partial_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)dzs, (const bf16_t*)a, bias, N, rows_per_tape, bpt, rpb, 1.f / slope, partials, dots);
     hipLaunchKernelGGL(colsum_sn_final_kernel, dim3(cdiv(N + ntapes, 4)), dim3(256), 0, (hipStream_t)s, partials, dots, nrb, N, bpt, gx, ntapes, sigma, gb, coef);
     EG_LAUNCH_CHECK();
     return 0;

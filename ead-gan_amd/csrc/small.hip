@@ -356,18 +356,21 @@ extern "C" int eg_cast_pad(int dtype, const float* src, void* dst, int rows, int
 template <typename T>
 __global__ __launch_bounds__(256) void dense_small_fwd_kernel(const T* __restrict__ x, const T* __restrict__ wp, const float* __restrict__ bias,
                                                               float* __restrict__ y, int B, int K, int Kpad, int N, const float* __restrict__ sigma,
-                                                              int sigma_rows) {
+                                                              int sigma_rows, float* __restrict__ partials, int kper) {
     constexpr int VEC = Elt<T>::VEC;
     constexpr int R = EG_DS_ROWS;
     __shared__ float part[4][R][64];
     const int b0 = blockIdx.x * R, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // blockIdx.y = K slice (kper elements): with `partials` the slices' sums go to partials[slice][b][n] and dense_small_combine_kernel
+    // adds them in slice order -- a head over B*16384 inputs has only B/4 row groups, far too few workgroups without the K split
+    const int kbeg = blockIdx.y * kper, kend = min(K, kbeg + kper);
     for (int n0 = 0; n0 < N; n0 += 8) {          // 8 outputs x R rows per sweep over x
         float a[R][8];
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int q = 0; q < 8; ++q) a[r][q] = 0.f;
-        for (int k0 = threadIdx.x * VEC; k0 < K; k0 += 256 * VEC) {
+        for (int k0 = kbeg + threadIdx.x * VEC; k0 < kend; k0 += 256 * VEC) {
             float xf[R][VEC];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -403,9 +406,44 @@ __global__ __launch_bounds__(256) void dense_small_fwd_kernel(const T* __restric
     const int r = threadIdx.x >> 6, n = threadIdx.x & 63;
     if (r < R && n < N && b0 + r < B) {
         const int b = b0 + r;
-        const float inv = sigma ? 1.f / sigma[sigma_rows ? b / sigma_rows : 0] : 1.f;
-        y[(size_t)b * N + n] = (part[0][r][n] + part[1][r][n] + part[2][r][n] + part[3][r][n]) * inv + (bias ? bias[n] : 0.f);
+        const float tot = part[0][r][n] + part[1][r][n] + part[2][r][n] + part[3][r][n];
+        if (partials) {
+            partials[((size_t)blockIdx.y * B + b) * N + n] = tot;
+        } else {
+            const float inv = sigma ? 1.f / sigma[sigma_rows ? b / sigma_rows : 0] : 1.f;
+            y[(size_t)b * N + n] = tot * inv + (bias ? bias[n] : 0.f);
+        }
     }
+}
+
+__global__ void dense_small_combine_kernel(const float* __restrict__ partials, int nslice, const float* __restrict__ bias, float* __restrict__ y, int B,
+                                           int N, const float* __restrict__ sigma, int sigma_rows) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * N) return;
+    const int b = i / N, n = i - b * N;
+    float tot = 0.f;
+    for (int z = 0; z < nslice; ++z) tot += partials[(size_t)z * B * N + i];
+    const float inv = sigma ? 1.f / sigma[sigma_rows ? b / sigma_rows : 0] : 1.f;
+    y[i] = tot * inv + (bias ? bias[n] : 0.f);
+}
+
+template <typename T>
+static void launch_dense_small_fwd(const T* x, const T* wp, const float* bias, float* y, int B, int K, int Kpad, int N, const float* sigma, int sigma_rows,
+                                   float* ws, size_t ws_floats, hipStream_t st) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int groups = cdiv(B, EG_DS_ROWS);
+    int ns = 1;
+    if (ws) {
+        while (ns < 16 && groups * ns < 256 && K / (ns * 2) >= 256 * VEC) ns *= 2;
+        while (ns > 1 && (size_t)ns * B * N > ws_floats) ns /= 2;
+    }
+    if (ns == 1) {
+        hipLaunchKernelGGL(dense_small_fwd_kernel<T>, dim3(groups), dim3(256), 0, st, x, wp, bias, y, B, K, Kpad, N, sigma, sigma_rows, (float*)nullptr, K);
+        return;
+    }
+    const int kper = cdiv(cdiv(K, VEC), ns) * VEC;
+    hipLaunchKernelGGL(dense_small_fwd_kernel<T>, dim3(groups, ns), dim3(256), 0, st, x, wp, bias, y, B, K, Kpad, N, sigma, sigma_rows, ws, kper);
+    hipLaunchKernelGGL(dense_small_combine_kernel, dim3(cdiv(B * N, 256)), dim3(256), 0, st, ws, ns, bias, y, B, N, sigma, sigma_rows);
 }
 
 // dx[b][k] = (sum_n dy[b][n] * Wp[n][k]) * act'(mask[b][k])
@@ -469,19 +507,19 @@ __global__ __launch_bounds__(256) void dense_small_wgrad_kernel(const float* __r
 }
 
 extern "C" int eg_dense_small_fwd(int dtype, const void* x, const void* wp, const float* bias, float* y, int B, int K, int Kpad, int N,
-                                  eg_stream_t s) {
+                                  float* ws, size_t ws_floats, eg_stream_t s) {
     EG_REQUIRE(x && wp && y && N <= 64 && K % (dtype == EG_F32 ? 4 : 8) == 0, "eg_dense_small_fwd: bad argument (N<=64)");
-    if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_fwd_kernel<float>, dim3(cdiv(B, EG_DS_ROWS)), dim3(256), 0, (hipStream_t)s, (const float*)x, (const float*)wp, bias, y, B, K, Kpad, N, (const float*)nullptr, 0);
-    else hipLaunchKernelGGL(dense_small_fwd_kernel<bf16_t>, dim3(cdiv(B, EG_DS_ROWS)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)wp, bias, y, B, K, Kpad, N, (const float*)nullptr, 0);
+    if (dtype == EG_F32) launch_dense_small_fwd<float>((const float*)x, (const float*)wp, bias, y, B, K, Kpad, N, nullptr, 0, ws, ws_floats, (hipStream_t)s);
+    else launch_dense_small_fwd<bf16_t>((const bf16_t*)x, (const bf16_t*)wp, bias, y, B, K, Kpad, N, nullptr, 0, ws, ws_floats, (hipStream_t)s);
     EG_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int eg_dense_small_fwd_sn(int dtype, const void* x, const void* wp, const float* bias, float* y, int B, int K, int Kpad, int N,
-                                     const float* sigma, int sigma_rows, eg_stream_t s) {
+                                     const float* sigma, int sigma_rows, float* ws, size_t ws_floats, eg_stream_t s) {
     EG_REQUIRE(x && wp && y && sigma && N <= 64 && K % (dtype == EG_F32 ? 4 : 8) == 0, "eg_dense_small_fwd_sn: bad argument (N<=64)");
-    if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_fwd_kernel<float>, dim3(cdiv(B, EG_DS_ROWS)), dim3(256), 0, (hipStream_t)s, (const float*)x, (const float*)wp, bias, y, B, K, Kpad, N, sigma, sigma_rows);
-    else hipLaunchKernelGGL(dense_small_fwd_kernel<bf16_t>, dim3(cdiv(B, EG_DS_ROWS)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (const bf16_t*)wp, bias, y, B, K, Kpad, N, sigma, sigma_rows);
+    if (dtype == EG_F32) launch_dense_small_fwd<float>((const float*)x, (const float*)wp, bias, y, B, K, Kpad, N, sigma, sigma_rows, ws, ws_floats, (hipStream_t)s);
+    else launch_dense_small_fwd<bf16_t>((const bf16_t*)x, (const bf16_t*)wp, bias, y, B, K, Kpad, N, sigma, sigma_rows, ws, ws_floats, (hipStream_t)s);
     EG_LAUNCH_CHECK();
     return 0;
 }

@@ -70,7 +70,7 @@ class _PxyEngine:
         ops.conv_fwd(self.l0.c, dt, self.patches, self.l0.wp_fwd, self.a[0], ops.epilogue(bias=cb[0].bias, act=ACT_LRELU, slope=0.1))
         for i in range(3):
             ops.conv_fwd(self.mid[i].c, dt, self.a[i], self.mid[i].wp_fwd, self.a[i + 1], ops.epilogue(bias=cb[2 * (i + 1)].bias, act=ACT_LRELU, slope=0.1))
-        ops.dense_small_fwd(dt, self.a[3], self.head.wp_fwd, self.mod.fc1.bias, self.out, B, 16 * TRUNK[3], self.head.Kpad_fwd, self.nout)
+        ops.dense_small_fwd(dt, self.a[3], self.head.wp_fwd, self.mod.fc1.bias, self.out, B, 16 * TRUNK[3], self.head.Kpad_fwd, self.nout, self.ws.small)
         return self.out
 
 

@@ -242,12 +242,13 @@ def bias_grad_nchw(x, B, C, HW, gb):
     lib().call("eg_bias_grad_nchw", _p(x), B, C, HW, _p(gb), _stream())
 
 
-def dense_small_fwd(dtype, x, wp, bias, y, B, K, Kpad, N):
-    lib().call("eg_dense_small_fwd", dtype, _p(x), _p(wp), _p(bias), _p(y), B, K, Kpad, N, _stream())
+def dense_small_fwd(dtype, x, wp, bias, y, B, K, Kpad, N, ws=None):
+    lib().call("eg_dense_small_fwd", dtype, _p(x), _p(wp), _p(bias), _p(y), B, K, Kpad, N, _p(ws), ws.numel() if ws is not None else 0, _stream())
 
 
-def dense_small_fwd_sn(dtype, x, wp, bias, y, B, K, Kpad, N, sigma, sigma_rows):
-    lib().call("eg_dense_small_fwd_sn", dtype, _p(x), _p(wp), _p(bias), _p(y), B, K, Kpad, N, _p(sigma), sigma_rows, _stream())
+def dense_small_fwd_sn(dtype, x, wp, bias, y, B, K, Kpad, N, sigma, sigma_rows, ws=None):
+    lib().call("eg_dense_small_fwd_sn", dtype, _p(x), _p(wp), _p(bias), _p(y), B, K, Kpad, N, _p(sigma), sigma_rows,
+               _p(ws), ws.numel() if ws is not None else 0, _stream())
 
 
 def head_prep_sn(dtype, dy, ldy, y, ldyy, bias, rows, N, sigma, rows_per_tape, dys, npad, col0, gb, coef, dys32=None, ld32=0):

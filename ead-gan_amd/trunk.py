@@ -189,9 +189,9 @@ class TrunkEngine:
             out = self.outs[h.name][t0 * B:(t0 + T) * B]
             wp = self.head_rec.wp_fwd[h.off * kpad:]
             if h.sn:
-                ops.dense_small_fwd_sn(dt, x, wp, h.module.bias, out, T * B, self.K, kpad, h.N, self.hsigma[h.name][t0:], B)
+                ops.dense_small_fwd_sn(dt, x, wp, h.module.bias, out, T * B, self.K, kpad, h.N, self.hsigma[h.name][t0:], B, self.ws.small)
             else:
-                ops.dense_small_fwd(dt, x, wp, h.module.bias, out, T * B, self.K, kpad, h.N)
+                ops.dense_small_fwd(dt, x, wp, h.module.bias, out, T * B, self.K, kpad, h.N, self.ws.small)
 
     def forward(self, imgs, t0=0, training=True):
         """len(imgs) forwards as tapes t0.. (power iterations in list order).  Returns {head name: [len(imgs)*B, N]} views."""

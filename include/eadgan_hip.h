@@ -164,12 +164,14 @@ int eg_flat_reduce_sn(const float* slab, int nslab, int rows, int Kdim, const fl
 int eg_bias_grad_nchw(const float* x, int B, int C, int HW, float* gb, eg_stream_t s);
 
 /* --- small-N dense heads (celebA/EAD-GAN_celebA.py:122; MNIST/EAD-GAN_rpqmnxy.py:124,161-163; dSprites/rp.py:109-110,180-183)
- * y[b][n] = sum_k x[b][k] Wp[n][k] + bias[n];  x dtype T [B][K]; Wp dtype T [N][Kpad] (eg_pack_fwd order);  y fp32 */
+ * y[b][n] = sum_k x[b][k] Wp[n][k] + bias[n];  x dtype T [B][K]; Wp dtype T [N][Kpad] (eg_pack_fwd order);  y fp32
+ * ws (optional, ws_floats >= 16*B*N lets the planner go as far as it wants): scratch for splitting K over workgroups when B/4 row groups
+ * do not fill the GPU; the slices are added in a fixed order by a second launch. */
 int eg_dense_small_fwd(int dtype, const void* x, const void* wp, const float* bias, float* y, int B, int K,
-                       int Kpad, int N, eg_stream_t s);
+                       int Kpad, int N, float* ws, size_t ws_floats, eg_stream_t s);
 /* spectrally normalised variant: y = (x Wp^T) / sigma[b / sigma_rows] + bias */
 int eg_dense_small_fwd_sn(int dtype, const void* x, const void* wp, const float* bias, float* y, int B, int K,
-                          int Kpad, int N, const float* sigma, int sigma_rows, eg_stream_t s);
+                          int Kpad, int N, const float* sigma, int sigma_rows, float* ws, size_t ws_floats, eg_stream_t s);
 /* gradient prep of a dense head: dys = dy / sigma[tape] (sigma == NULL: plain head) written as dtype T at column col0 of a
  * [rows][npad] buffer and, if dys32 != NULL, as fp32 at column col0 of a [rows][ld32] buffer; gb[n] += sum_rows dy;
  * coef[tape] = sum dys * (y - bias)  (== <G_t,W>/sigma_t^2, the spectral-norm rank-1 coefficient) */
