@@ -123,25 +123,23 @@ class _GenEngine:
         dt, B, W, ws, gen = self.dtype, self.B, G_WIDTHS, self.ws, self.gen
         gof = lambda name: gen.arena.grad_of(name, grad)
         C, S = gen.channels, self.img.shape[-1]
-        wsw = side.ws if side is not None else ws
-
-        def wgrad_side(fn):
+        def wgrad_side(fn, lane):
             if side is None:
-                fn()
+                fn(ws)
             else:
-                side.fork()
-                with side:
-                    fn()
+                ln = side.fork(lane)
+                with ln:
+                    fn(ln.ws)
 
         # tanh backward fused with the bias gradient of the last ConvTranspose2d
         ops.act_grad_mul_bias_nchw(dimg, self.img, self.dimg_z, B, C, S * S, ACT_TANH, 0.0, ws.small, gof("conv_blocks.10.bias"))
         # L4 = ConvTranspose2d(128 -> C): weight / input gradients as 1x1-conv GEMMs over im2col patches of d(img)
         ops.im2col_img(dt, self.dimg_z, self.patches, B, C, S, S, 4, 2, 1, self.kp)
 
-        def l4_wgrad():
+        def l4_wgrad(wsw):
             ns = ops.conv_wgrad(self.l4p.c, dt, self.patches, self.a[2], wsw.slab)
             ops.wgrad_reduce(wsw.slab, ns, W[3], W[3], self.kp, 1, gof("conv_blocks.10.weight"))
-        wgrad_side(l4_wgrad)
+        wgrad_side(l4_wgrad, 0)
         ops.conv_fwd(self.l4p.c, dt, self.patches, self.l4p.wp_fwd, self.da[2], None)
         # L3..L1
         for i, idx in ((2, 7), (1, 4), (0, 1)):
@@ -152,19 +150,19 @@ class _GenEngine:
                        gof(f"conv_blocks.{idx + 1}.weight"), gof(f"conv_blocks.{idx + 1}.bias"), ws.sums, ws.small)
             x_in = self.a[i - 1] if i > 0 else self.h0
 
-            def mid_wgrad(i=i, idx=idx, r=r, M=M, x_in=x_in):
+            def mid_wgrad(wsw, i=i, idx=idx, r=r, M=M, x_in=x_in):
                 ns = ops.conv_wgrad(r.c, dt, self.dz[i], x_in, wsw.slab)
                 ops.wgrad_reduce(wsw.slab, ns, r.Cout, r.Cout, r.Cin, 16, gof(f"conv_blocks.{idx}.weight"))
                 ops.bias_grad(dt, self.dz[i], M, W[i + 1], wsw.small, gof(f"conv_blocks.{idx}.bias"))
-            wgrad_side(mid_wgrad)
+            wgrad_side(mid_wgrad, i + 1)
             ops.conv_fwd(r.c, dt, self.dz[i], r.wp_fwd, self.da[i - 1] if i > 0 else self.dh0, None)
 
         # L0
-        def l0_wgrad():
+        def l0_wgrad(wsw):
             ns = ops.conv_wgrad(self.l0w.c, dt, self.dh0, self.inp, wsw.slab)
             ops.wgrad_reduce(wsw.slab, ns, self.cpad, self.cin, W[0], 16, gof("conv_blocks.0.weight"))
             ops.bias_grad(dt, self.dh0, B * 16, W[0], wsw.small, gof("conv_blocks.0.bias"))
-        wgrad_side(l0_wgrad)
+        wgrad_side(l0_wgrad, 0)
 
 
 class _HipModule(nn.Module):
@@ -323,7 +321,8 @@ class _DiscEngine:
                 ent = [(self._m(i).weight_orig, self._m(i).weight_u, self._m(i).weight_v, self.sigma[i][tt:tt + 1], self.u[i][tt], self.v[i][tt])
                        for i in range(4)]
                 self._sn_arrays.append(ops.sn_layers(ent))
-            self.ws.need_small(ops.sn_multi_ws_floats(self._sn_arrays[0]))
+            # own scratch: the power iterations may run on a side stream while the main stream uses the shared workspace
+            self.sn_scratch = torch.empty(ops.sn_multi_ws_floats(self._sn_arrays[0]), device=self.ws.device, dtype=torch.float32)
         return self._sn_arrays[t]
 
     def _m(self, i):
@@ -340,23 +339,40 @@ class _DiscEngine:
         """lattice rows of one tape at the output of layer i"""
         return self.B * self.hw[i] ** 2
 
-    def forward(self, imgs, t0=0, training=True):
+    def _sn_tape(self, t, training=True):
+        ops.sn_power_iter_multi(self._sn(t), self.sn_scratch, training, SN_EPS)
+        if not training:
+            for i in range(4):
+                self.u[i][t].copy_(self._m(i).weight_u)
+                self.v[i][t].copy_(self._m(i).weight_v)
+
+    def _im2col_tape(self, t, img):
+        npix = self.B * (self.S // 2) ** 2
+        ops.im2col_img(self.dtype, img, self.patches[t * npix:(t + 1) * npix], self.B, self.C, self.S, self.S, 4, 2, 1, self.kp)
+
+    def prepare(self, t0, imgs, training=True):
+        """Image-independent head start of ``forward(imgs, t0, prepared=...)``: the tapes' power iterations (in list order, like
+        consecutive D(...) calls) and the patch rows of the images that already exist (``None`` entries are left to forward).
+        The trainer runs this on a side stream while the previous sub-step is still busy."""
+        for k, img in enumerate(imgs):
+            self._sn_tape(t0 + k, training)
+            if img is not None:
+                self._im2col_tape(t0 + k, img)
+
+    def forward(self, imgs, t0=0, training=True, prepared=None):
         """Runs len(imgs) forwards as tapes t0.. (power iterations in list order, like consecutive D(...) calls).
-        Returns the head outputs [len(imgs)*B, 19] (a view of the tape buffer)."""
+        ``prepared``: per-tape flags of a preceding ``prepare`` call (power iterations done for all tapes, patch rows done where
+        the flag is set).  Returns the head outputs [len(imgs)*B, 19] (a view of the tape buffer)."""
         dt, B, W, ws = self.dtype, self.B, D_WIDTHS, self.ws
         T = len(imgs)
         assert 1 <= T and t0 + T <= self.NT
         for k, img in enumerate(imgs):
             t = t0 + k
             self.imgs[t] = img
-            arr = self._sn(t)
-            ops.sn_power_iter_multi(arr, self.ws.small, training, SN_EPS)
-            if not training:
-                for i in range(4):
-                    self.u[i][t].copy_(self._m(i).weight_u)
-                    self.v[i][t].copy_(self._m(i).weight_v)
-            npix = B * (self.S // 2) ** 2
-            ops.im2col_img(dt, img, self.patches[t * npix:(t + 1) * npix], B, self.C, self.S, self.S, 4, 2, 1, self.kp)
+            if prepared is None:
+                self._sn_tape(t, training)
+            if prepared is None or not prepared[k]:
+                self._im2col_tape(t, img)
         g = self.geo[T]
         sl = lambda buf, i: buf[t0 * (buf.shape[0] // self.NT):]
         ep = lambda i: ops.epilogue(bias=self._m(i).bias, sigma=self.sigma[i][t0:], sigma_rows=self.rows(i), act=ACT_LRELU, slope=LRELU_SLOPE)
@@ -377,23 +393,21 @@ class _DiscEngine:
         g = self.geo[T]
         sl = lambda buf: buf[t0 * (buf.shape[0] // self.NT):]
         K = 16 * W[3]
-        wsw = side.ws if side is not None else ws
-
-        def wgrad_side(fn):
+        def wgrad_side(fn, lane):
             if side is None:
-                fn()
+                fn(ws)
             else:
-                side.fork()
-                with side:
-                    fn()
+                ln = side.fork(lane)
+                with ln:
+                    fn(ln.ws)
 
         if need_wgrad:
-            def head_wgrad():
+            def head_wgrad(wsw):
                 ops.cast_pad(dt, dout, self.dout_t, T * B, self.nout, 32)
                 ns = ops.conv_wgrad(g["headw"], dt, sl(self.a[3]), self.dout_t, wsw.slab)
                 ops.wgrad_reduce(wsw.slab, ns, 32, self.nout, W[3], 16, gof("main.8.weight"))
                 ops.dense_small_bgrad(dout, gof("main.8.bias"), T * B, self.nout)
-            wgrad_side(head_wgrad)
+            wgrad_side(head_wgrad, 0)
         # dzs_3 = (W5^T dout) * lrelu'(a3) / sigma_3[tape]
         ops.dense_small_bwd(dt, dout, self.head.wp_fwd, sl(self.a[3]), sl(self.dz[3]), T * B, K, self.head.Kpad_fwd, self.nout, ACT_LRELU, LRELU_SLOPE,
                             self.sigma[3][t0:], B)
@@ -402,14 +416,14 @@ class _DiscEngine:
             geo = g["mid"][i - 1] if i > 0 else g["l1p"]
             x_in = sl(self.a[i - 1]) if i > 0 else sl(self.patches)
             if need_wgrad:
-                def layer_wgrad(i=i, m=m, geo=geo, x_in=x_in):
+                def layer_wgrad(wsw, i=i, m=m, geo=geo, x_in=x_in):
                     ops.bias_grad_sn(dt, sl(self.dz[i]), sl(self.a[i]), m.bias, T * self.rows(i), W[i], self.rows(i), self.sigma[i][t0:], LRELU_SLOPE,
                                      wsw.small, gof(f"main.{2 * i}.bias"), self.coef[i])
                     ns = ops.conv_wgrad(geo, dt, x_in, sl(self.dz[i]), wsw.slab)
                     taps = 16 if i > 0 else 1
                     ops.wgrad_reduce_rank1(wsw.slab, ns, W[i], W[i], self.cin[i], taps, gof(f"main.{2 * i}.weight_orig"), T, self.coef[i],
                                            self.u[i][t0:], self.v[i][t0:])
-                wgrad_side(layer_wgrad)
+                wgrad_side(layer_wgrad, i + 1)
             if i > 0:
                 # dzs_{i-1} = conv^T(dzs_i, W_i) * lrelu'(a_{i-1}) / sigma_{i-1}[tape]
                 ops.conv_bwd_data(geo, dt, sl(self.dz[i]), self.mid[i - 1].wp_bwd, sl(self.dz[i - 1]),
@@ -608,31 +622,34 @@ class CelebATrainer:
         ops.theta_rpqxy(self.code, cd, B, self.theta)
         ops.warp_affine(self.real, self.theta, self.scaled, B, G.channels, G.img_size, G.img_size)
         side = self.side
+        prep = side is not None
 
-        def on_side(fn):                                # fn's launches go to the side stream, behind everything enqueued so far
+        def on_side(fn, lane=0):                        # fn's launches go to a side lane, behind everything enqueued so far
             if side is None:
                 fn()
             else:
-                side.fork()
-                with side:
+                with side.fork(lane):
                     fn()
 
         join = side.join if side is not None else (lambda: None)
-        # ---- 1) generator adversarial step (:334-345) ----
+        # ---- 1) generator adversarial step (:334-345); D(gen) lives in tape slot 2 so that step 2's tapes can be prepared meanwhile ----
         ops.fill_f32(ga.grad)
         gen = ge.forward(self.z, self.onehot, self.code)
-        out = de.forward([gen])
-        ops.loss_bce_sigmoid(out, 19, 0, B, 1.0, 1.0, self.losses[0:1], self.dout[:B])
-        dimg = de.backward(0, 1, self.dout[:B], da.grad, need_wgrad=False, need_dimg=True)
+        out = de.forward([gen], 2)
+        # step 2's power iterations (they follow step 1's in the u/v chain) and patch rows, beside the rest of step 1
+        if prep:
+            on_side(lambda: de.prepare(0, [self.scaled, gen]), 1)
+        ops.loss_bce_sigmoid(out, 19, 0, B, 1.0, 1.0, self.losses[0:1], self.dout[2 * B:])
+        dimg = de.backward(2, 1, self.dout[2 * B:], da.grad, need_wgrad=False, need_dimg=True)
         ge.backward(dimg, ga.grad, side)
         join()
         if self.allreduce is not None:
             self.allreduce(ga.grad)
         self._adam(ga, self.mG, self.vG, self.lr[0], 0, True)
-        on_side(ge.repack)                              # G's panels are next read in step 3
+        on_side(ge.repack, 0)                           # G's panels are next read in step 3
         # ---- 2) discriminator step (:353-366); gen is the (detached) output of step 1; D(scaled) then D(gen), batched ----
         ops.fill_f32(da.grad)
-        out = de.forward([self.scaled, gen])
+        out = de.forward([self.scaled, gen], 0, prepared=(True, True) if prep else None)
         ops.loss_bce_sigmoid(out[:B], 19, 0, B, 1.0, 0.5, self.losses[1:2], self.dout[:B])
         ops.loss_bce_sigmoid(out[B:], 19, 0, B, 0.0, 0.5, self.losses[1:2], self.dout[B:2 * B])
         de.backward(0, 2, self.dout[:2 * B], da.grad, side=side)
@@ -640,13 +657,16 @@ class CelebATrainer:
         if self.allreduce is not None:
             self.allreduce(da.grad)
         self._adam(da, self.mD, self.vD, self.lr[1], 1, True)
-        on_side(de.repack)                              # beside the generator forward below
+        # beside the generator forward below: D's panels, step 3's three power iterations, the patch rows of scaled / real
+        on_side(de.repack, 0)
+        if prep:
+            on_side(lambda: de.prepare(0, [None, self.scaled, self.real]), 1)
         # ---- 3) info + affine step (:375-401): D(gen), D(scaled), D(real) batched as tapes 0,1,2 ----
         ops.fill_f32(ga.grad)
         ops.fill_f32(da.grad)
         gen = ge.forward(self.z, self.onehot, self.code)
         join()
-        out = de.forward([gen, self.scaled, self.real])
+        out = de.forward([gen, self.scaled, self.real], 0, prepared=(False, True, True) if prep else None)
         o_gen, o_trans, o_real = out[:B], out[B:2 * B], out[2 * B:]
         ops.loss_mse(o_gen, 19, 1, cd, B, self.code, cd, 0.0, lcon, self.losses[2:3], self.dout[:B])
         ops.loss_ce_softmaxed(o_gen, 19, cd + 1, nc, B, self.labels, lcat, self.losses[2:3], self.dout[:B])
@@ -656,7 +676,7 @@ class CelebATrainer:
         if self.allreduce is not None and hasattr(self.allreduce, "start"):
             join()                                      # D's weight gradients are complete
             pending = self.allreduce.start(da.grad)
-        ge.backward(dimg, ga.grad, side)                # beside D's weight-gradient chain / the D-gradient all-reduce
+        ge.backward(dimg, ga.grad, side)                # beside D's weight-gradient chains / the D-gradient all-reduce
         join()
         if self.allreduce is not None:
             self.allreduce(ga.grad)
@@ -666,7 +686,7 @@ class CelebATrainer:
                 self.allreduce(da.grad)
         self._adam(ga, self.miG, self.viG, self.lr[2], 2, True)
         self._adam(da, self.miD, self.viD, self.lr[2], 2, False)
-        on_side(de.repack)
+        on_side(de.repack, 0)
         ge.repack()
         join()
 

@@ -2249,8 +2249,9 @@ __global__ void colsum_final_kernel(const float* __restrict__ partials, int nrb,
 }
 
 extern "C" size_t eg_bias_grad_ws_floats(int rows, int N) {
-    // dtype-independent upper bound: the bf16 launch has the fewer column blocks, hence the smaller rows-per-block
-    return (size_t)cdiv(rows, bg_rpb(rows, 1, bg_gx(N, EG_BF16))) * N;
+    // bound for every launch with <= rows rows and <= N columns, either dtype: bg_rpb stops halving once there are 512 workgroups, so
+    // a launch has at most max(rows / 256, 1024) row blocks
+    return (size_t)std::max(cdiv(rows, 256), 1024) * N;
 }
 
 extern "C" int eg_bias_grad(int dtype, const void* dY, int rows, int N, int bias_mod, float* partials, float* gb, eg_stream_t s) {
@@ -2342,9 +2343,9 @@ __global__ void colsum_sn_final_kernel(const float* __restrict__ partials, const
 }
 
 extern "C" size_t eg_bias_grad_sn_ws_floats(int rows, int N, int rows_per_tape) {
+    // same bound as eg_bias_grad_ws_floats (row blocks over all tapes), plus the per-block dot partials
     const int ntapes = rows / rows_per_tape;
-    const int bpt = cdiv(rows_per_tape, bg_rpb(rows_per_tape, 1, bg_gx(N, EG_BF16)));    // upper bound over tape counts and dtypes
-    return (size_t)ntapes * bpt * (N + 64);
+    return (size_t)std::max(ntapes * cdiv(rows_per_tape, 256), 1024 + ntapes) * (N + 64);
 }
 
 extern "C" int eg_bias_grad_sn(int dtype, const void* dzs, const void* a, const float* bias, int rows, int N, int rows_per_tape,

@@ -88,29 +88,12 @@ class Workspace:
         self._grow("sums", floats)
 
 
-class SideStream:
-    """Second HIP stream (with its own scratch) for work that does not feed the critical path of a training step: the
-    weight-gradient GEMMs with their reductions and bias-gradient sums run beside the backward-data GEMMs of the layers
-    below, and weight re-packing after an optimizer step runs beside the next sub-step.  ``fork()``: the side stream
-    waits for everything enqueued on the current stream so far; ``join()``: the current stream waits for the side
-    stream.  Both are event record/wait pairs, capturable into the step's hipGraph.  The side stream never launches NT
-    convolutions (the split-K scratch belongs to the main stream)."""
-
+class _Lane:
     def __init__(self, device, like: "Workspace"):
         self.stream = torch.cuda.Stream(device)
         self.ws = Workspace(device, splitk=False)
         for name in ("slab", "gtmp", "small", "sums", "partials"):
             setattr(self.ws, name, torch.empty_like(getattr(like, name)))
-
-    def fork(self):
-        ev = torch.cuda.Event()
-        ev.record()
-        self.stream.wait_event(ev)
-
-    def join(self):
-        ev = torch.cuda.Event()
-        ev.record(self.stream)
-        torch.cuda.current_stream().wait_event(ev)
 
     def __enter__(self):
         self._ctx = torch.cuda.stream(self.stream)
@@ -118,6 +101,36 @@ class SideStream:
 
     def __exit__(self, *a):
         return self._ctx.__exit__(*a)
+
+
+class SideStream:
+    """Extra HIP streams ("lanes", each with its own scratch) for work that does not feed the critical path of a training
+    step: the weight-gradient GEMMs with their reductions and bias-gradient sums run beside the backward-data GEMMs of
+    the layers below (consecutive layers on alternating lanes, so one layer's HBM-bound reductions overlap the next
+    layer's GEMM), weight re-packing after an optimizer step and the spectral-norm power iterations of the next sub-step
+    run beside the current one.  ``fork(i)``: lane i waits for everything enqueued on the current stream so far;
+    ``join()``: the current stream waits for every lane.  Both are event record/wait pairs, capturable into the step's
+    hipGraph.  Lanes never launch NT convolutions (the split-K scratch belongs to the main stream)."""
+
+    def __init__(self, device, like: "Workspace", lanes: int = 2):
+        self.lanes = [_Lane(device, like) for _ in range(lanes)]
+
+    def lane(self, i: int) -> _Lane:
+        return self.lanes[i % len(self.lanes)]
+
+    def fork(self, i: int = 0) -> _Lane:
+        ln = self.lane(i)
+        ev = torch.cuda.Event()
+        ev.record()
+        ln.stream.wait_event(ev)
+        return ln
+
+    def join(self):
+        cur = torch.cuda.current_stream()
+        for ln in self.lanes:
+            ev = torch.cuda.Event()
+            ev.record(ln.stream)
+            cur.wait_event(ev)
 
 
 class ConvRec:
