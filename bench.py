@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--force-dist", action="store_true", help="initialise a process group and run the all-reduce hooks even with one rank "
                                                               "(rehearses the N>1 code path, incl. RCCL capture into the hipGraph, on one GPU)")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no side lanes for weight-gradient chains / re-packing")
-    ap.add_argument("--igemm-tuning", default="", help="buf_min_tiles,splitk_target,big_min_tiles,persistent for eg_set_igemm_tuning (experiments)")
+    ap.add_argument("--igemm-tuning", default="", help="buf_min_tiles,splitk_target,big_min_tiles,persistent,wide_min_tiles for eg_set_igemm_tuning (experiments)")
     ap.add_argument("--igemm-dma", type=int, default=4, help="LDS-DMA staged NT kernel variant for large launches (0 off, 1 = 256x128x3, 2 = 128x128x2, 3 = 128x128x3, 4 = buffer-descriptor 128x128x2 [default])")
     ap.add_argument("--workload", default="celeba", choices=["celeba", "mnist", "dsprites", "colored"],
                     help="celeba = the headline metric (default); mnist = BASELINE config[1] (use --batch 256 --dtype f32); "

@@ -868,6 +868,163 @@ __global__ __launch_bounds__(256) void igemm_nt_buf_kernel(const NtParams p, uns
 }
 
 // ------------------------------------------------------------------------------------------------
+// igemm_nt_w: 256 x 128 tile, 4 waves x (128 x 64), K steps of 64 BYTES per row (32 bf16 / 16 fp32), 3-stage LDS-DMA ring of 24 KiB
+// stages (72 KiB -> still two workgroups per CU).  The K loop of igemm_nt_buf is bound by the LDS-DMA issue path, not by MFMA: this
+// shape needs 6 pieces and 12 ds_read_b128 per 32 MFMAs and wave where 128x128 needs 8 and 16 (87 vs 64 FLOP per staged byte), and the
+// third stage keeps two K steps in flight.  LDS image: 64-byte rows, 16-byte chunk c of row r at chunk c ^ g((r >> 2) & 3),
+// g = {0,3,2,1}: every 16-lane group of a fragment ds_read_b128 covers 16 different rows and lands on 16 different bank quads.
+// DMA piece = 16 rows x 64 B; slot j of wave w covers tile rows (j*4+w)*16 .. +15 (A: j < 4, B: j < 2).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int eg_g4(int h) { return (4 - h) & 3; }
+__device__ __forceinline__ int lds_off64(int row, int chunk) { return row * 64 + ((chunk ^ eg_g4((row >> 2) & 3)) << 4); }
+
+__device__ __forceinline__ void eg_bufdma2(const u32x4_t srd, unsigned v0, unsigned v1, unsigned soff, unsigned lds) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
+        "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(v0), "v"(v1), "s"(srd), "s"(soff), "s"(lds)
+        : "memory", "scc");
+}
+
+template <typename T, bool SPLITK = false>
+__global__ __launch_bounds__(256, 2) void igemm_nt_w_kernel(const NtParams p) {
+    constexpr int VEC = Elt<T>::VEC;
+    constexpr int BK = 4 * VEC;                    // 64 bytes of K per row and step
+    constexpr int BM = 256, BN = 128;
+    constexpr int STAGE = (BM + BN) * 64;          // 24 KiB
+    constexpr int NST = 3;
+    constexpr int TM = 8, TN = 4;                  // waves 2 x 2, wave tile 128 x 64
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int nsplit = SPLITK && p.nsplit > 1 ? p.nsplit : 1;
+    const int phase = blockIdx.z / nsplit, split = blockIdx.z - phase * nsplit;
+    const NtPhase ph = p.ph[phase];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
+    const int HU = p.H << p.up, WU = p.W << p.up;
+    const int rsub = lane >> 2, pos = lane & 3;                  // row inside the 16-row piece, 16-byte slot inside the row
+    const int srcchunk = pos ^ eg_g4((lane >> 4) & 3);           // piece bases are multiples of 16 rows: (row >> 2) & 3 == lane >> 4
+
+    int a_pix0[4], a_y[4], a_x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + (j * 4 + wave) * 16 + rsub;
+        const int b = m >> (p.lOW + p.lOH);
+        a_pix0[j] = (m < p.M) ? b * p.H * p.W : -1;
+        a_y[j] = ((m >> p.lOW) & OHm) * p.sy + ph.dy0;
+        a_x[j] = (m & OWm) * p.sx + ph.dx0;
+    }
+    const unsigned row_bytes = (unsigned)p.C * sizeof(T);
+    unsigned va[4], vb[2];
+    auto tap_offsets = [&](int ty, int tx) {
+        const int oy = ty * ph.dys, ox = tx * ph.dxs;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int iy = a_y[j] + oy, ix = a_x[j] + ox;
+            const bool ok = a_pix0[j] >= 0 && iy >= 0 && iy < HU && ix >= 0 && ix < WU;
+            const unsigned pix = (unsigned)(a_pix0[j] + (iy >> p.up) * p.W + (ix >> p.up));
+            va[j] = ok ? pix * row_bytes + (unsigned)srcchunk * 16u : EG_OOB;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + (j * 4 + wave) * 16 + rsub;
+        vb[j] = n < p.N ? (unsigned)n * (unsigned)ph.Kpad * (unsigned)sizeof(T) + (unsigned)srcchunk * 16u : EG_OOB;
+    }
+    const u32x4_t srdA = eg_make_srd(p.src, (unsigned)((size_t)p.B * p.H * p.W * p.C * sizeof(T)));
+    const u32x4_t srdB = eg_make_srd(reinterpret_cast<const T*>(p.wp) + ph.w_off, (unsigned)((size_t)p.N * ph.Kpad * sizeof(T)));
+    const int nk_all = ph.Kpad / BK;
+    const int per = (nk_all + nsplit - 1) / nsplit;
+    const int kt0 = split * per;
+    const int nk = min(per, nk_all - kt0);
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)wave * 1024u;
+    const int steps_per_tap = p.C / BK;
+    const int tap0 = kt0 / steps_per_tap;
+    int ty = tap0 / ph.TW, tx = tap0 - ty * ph.TW;
+    unsigned kc_bytes = (unsigned)(kt0 - tap0 * steps_per_tap) * 64u;
+    if (ty < ph.TH) tap_offsets(ty, tx);
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) va[j] = EG_OOB;
+    }
+    auto issue = [&](int kt, int stage) {
+        const unsigned sa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)stage * STAGE);
+        eg_bufdma4(srdA, va[0], va[1], va[2], va[3], kc_bytes, sa);
+        eg_bufdma2(srdB, vb[0], vb[1], (unsigned)(kt0 + kt) * 64u, sa + BM * 64);
+        kc_bytes += 64u;
+        if (kc_bytes >= row_bytes) {               // next tap (uniform branch)
+            kc_bytes = 0;
+            if (++tx == ph.TW) { tx = 0; ++ty; }
+            if (ty < ph.TH) tap_offsets(ty, tx);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) va[j] = EG_OOB;
+            }
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    if (nk > 0) issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int st_use = 0, st_fill = 2;
+    for (int kt = 0; kt < nk; ++kt) {
+        // stage kt has landed once at most the 6 pieces of stage kt+1 are outstanding
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // everyone's stage kt landed; everyone finished reading stage kt-1
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) issue(kt + 2, st_fill);
+        const char* sa = smem + st_use * STAGE;
+        const char* sb = sa + BM * 64;
+        uint4 bfr[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(sb + lds_off64((wn * TN + j) * 16 + frow, fq));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const uint4 af = *reinterpret_cast<const uint4*>(sa + lds_off64((wm * TM + i) * 16 + frow, fq));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) mfma_step<T>(af, bfr[j], acc[i][j]);
+        }
+        st_use = st_use == NST - 1 ? 0 : st_use + 1;
+        st_fill = st_fill == NST - 1 ? 0 : st_fill + 1;
+    }
+    if (nsplit > 1) {
+        const int nphase = gridDim.z / nsplit;
+        float* part = p.part + ((size_t)(split * nphase + phase) * (gridDim.x * BM) + m0) * p.N + n0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = (wm * TM + i) * 16 + frow;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                *reinterpret_cast<f32x4*>(part + (size_t)row * p.N + (wn * TN + j) * 16 + fq * 4) = acc[i][j];
+        }
+        return;
+    }
+    // the 256 x 128 fp32 tile does not fit the 72 KiB: two windows of 128 rows (= the two wave rows)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+        nt_epilogue_lds<T, 128, 128, TM, TN, 256>(p, ph, acc, smem, m0 + h * 128, n0, 0, wm == h ? wn * TN * 16 : -1, tid, frow, fq);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // igemm_nt_pers: the 128x128 buffer-descriptor kernel as a persistent pipeline.  A workgroup walks tiles t = blockIdx.x, +gridDim.x, ...
 // with ONE continuous 2-stage LDS-DMA ring: the first K step of the next tile is in flight while the last step of the current tile is
 // computed, the epilogue operands (1/sigma, bias, activation-gradient mask in accumulator layout) are fetched during that last step,
@@ -1325,8 +1482,9 @@ extern "C" int eg_set_igemm_dma(int on) { const int old = g_use_dma; g_use_dma =
 // tuning knobs of the buffer-descriptor kernels (units: workgroups per launch).  128x128 kernel: launches with fewer tiles than
 // g_buf_min_tiles go to the register-staged kernels; launches below g_splitk_target tiles are split along K (when the caller lent a
 // workspace) to reach that many workgroups.  256-row kernel: taken when the launch has at least g_big_min_tiles of its tiles (0 = never).
-static int g_buf_min_tiles = 512, g_splitk_target = 512, g_big_min_tiles = 0, g_persistent = 0;
-extern "C" int eg_set_igemm_tuning(int buf_min_tiles, int splitk_target, int big_min_tiles, int persistent) {
+static int g_buf_min_tiles = 512, g_splitk_target = 512, g_big_min_tiles = 0, g_persistent = 0, g_wide_min_tiles = 0;
+extern "C" int eg_set_igemm_tuning(int buf_min_tiles, int splitk_target, int big_min_tiles, int persistent, int wide_min_tiles) {
+    if (wide_min_tiles >= 0) g_wide_min_tiles = wide_min_tiles;
     if (buf_min_tiles > 0) g_buf_min_tiles = buf_min_tiles;
     if (splitk_target >= 0) g_splitk_target = splitk_target;
     if (big_min_tiles >= 0) g_big_min_tiles = big_min_tiles;
@@ -1334,7 +1492,7 @@ extern "C" int eg_set_igemm_tuning(int buf_min_tiles, int splitk_target, int big
     return 0;
 }
 
-enum { NT_PLAN_NONE = 0, NT_PLAN_BUF128 = 1, NT_PLAN_BIG128 = 2, NT_PLAN_BIG256 = 3, NT_PLAN_PERS = 4 };
+enum { NT_PLAN_NONE = 0, NT_PLAN_BUF128 = 1, NT_PLAN_BIG128 = 2, NT_PLAN_BIG256 = 3, NT_PLAN_PERS = 4, NT_PLAN_WIDE = 5 };
 struct NtPlan { int kind, ns; };
 
 static NtPlan nt_plan(const NtParams& p, int nphase, int vec, size_t esize, size_t ws_bytes) {
@@ -1355,6 +1513,7 @@ static NtPlan nt_plan(const NtParams& p, int nphase, int vec, size_t esize, size
     // shallow launches (1-2 K steps: the image-side layers as 1x1 convolutions over patches) are all prologue and epilogue for a
     // workgroup-per-tile kernel: only the persistent pipeline overlaps them
     if (nk_max < 3 || !c_tiles) return tiles >= 128 ? NtPlan{NT_PLAN_PERS, 1} : none;
+    if (g_wide_min_tiles > 0 && (long long)cdiv(p.M, 256) * (p.N / 128) * nphase >= g_wide_min_tiles) return {NT_PLAN_WIDE, 1};
     if (g_big_min_tiles > 0) {
         const int bn = (p.N % 256) == 0 ? 256 : 128;
         if ((long long)cdiv(p.M, 256) * (p.N / bn) * nphase >= g_big_min_tiles) return {bn == 256 ? NT_PLAN_BIG256 : NT_PLAN_BIG128, 1};
@@ -1421,6 +1580,18 @@ static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
         const dim3 grid(cdiv(p.M, 256), p.N / (wide ? 256 : 128), nphase);
         if (wide) hipLaunchKernelGGL((igemm_nt_big_kernel<T, 256, 128, 2>), grid, dim3(512), lds, st, q);
         else hipLaunchKernelGGL((igemm_nt_big_kernel<T, 128, 64, 3>), grid, dim3(512), lds, st, q);
+        return;
+    }
+    if (plan.kind == NT_PLAN_WIDE) {
+        static bool attr_set = false;
+        const size_t lds = 3 * (256 + 128) * 64;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_nt_w_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        NtParams q = p;
+        q.nsplit = 1;
+        hipLaunchKernelGGL((igemm_nt_w_kernel<T>), dim3(cdiv(p.M, 256), p.N / 128, nphase), dim3(256), lds, st, q);
         return;
     }
     if (plan.kind == NT_PLAN_PERS) {
@@ -1505,6 +1676,7 @@ extern "C" int eg_igemm_nt_tile(int dtype, int M, int N, int C, int K, int nphas
     const NtPlan plan = nt_plan(p, nphase, vec, dtype == EG_F32 ? 4 : 2, (size_t)1 << 40);
     if (plan.kind == NT_PLAN_BIG128) return 256 * 1000 + 133;
     if (plan.kind == NT_PLAN_BIG256) return 256 * 1000 + 134;
+    if (plan.kind == NT_PLAN_WIDE) return 256 * 1000 + 136;
     if (plan.kind == NT_PLAN_PERS) return 128 * 1000 + 135;
     if (plan.kind == NT_PLAN_BUF128) return 128 * 1000 + (plan.ns > 1 ? 132 : 131);
     if (dma_eligible(p, nphase, vec)) return g_use_dma == 1 ? 256 * 1000 + 128 : (g_use_dma == 3 ? 128 * 1000 + 130 : 128 * 1000 + 129);

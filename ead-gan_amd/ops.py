@@ -116,7 +116,7 @@ def _timed(kind, c, dtype, args):
         bm, bn = tile // 1000, tile % 1000
         label = {129: f"igemm_nt_dma_kernel<{tname},{bm},2>", 130: f"igemm_nt_dma_kernel<{tname},{bm},3>",
                  131: f"igemm_nt_buf_kernel<{tname}>", 132: f"igemm_nt_buf_kernel<{tname}>+splitk",
-                 135: f"igemm_nt_pers_kernel<{tname}>", 133: f"igemm_nt_big_kernel<{tname},128,64,3>", 134: f"igemm_nt_big_kernel<{tname},256,128,2>"}.get(bn, f"igemm_nt_dma_kernel<{tname},256,3>" if bm == 256 else f"igemm_nt_kernel<{tname},{bm},{bn}>")
+                 135: f"igemm_nt_pers_kernel<{tname}>", 136: f"igemm_nt_w_kernel<{tname}>", 133: f"igemm_nt_big_kernel<{tname},128,64,3>", 134: f"igemm_nt_big_kernel<{tname},256,128,2>"}.get(bn, f"igemm_nt_dma_kernel<{tname},256,3>" if bm == 256 else f"igemm_nt_kernel<{tname},{bm},{bn}>")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     lib().call(*args, _stream())

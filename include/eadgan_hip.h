@@ -79,18 +79,19 @@ int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, const void* wp
                      const eg_epilogue* ep, eg_stream_t s);
 /* tile (BM*1000+BN) of the igemm_nt instantiation a problem (M rows, N columns, C gathered channels per tap, K per phase) is
  * dispatched to; BN = 129 / 130 / 131 / 132 name the 128-wide LDS-DMA variants (2-stage, 3-stage, buffer-descriptor, the latter with
- * split-K), 133 / 134 the 256-row buffer-descriptor kernel with 128 / 256 columns, 135 the persistent 128x128 pipeline.  Profiling labels only. */
+ * split-K), 133 / 134 the 256-row buffer-descriptor kernel with 128 / 256 columns, 135 the persistent 128x128 pipeline, 136 igemm_nt_w.  Profiling labels only. */
 int eg_igemm_nt_tile(int dtype, int M, int N, int C, int K, int nphase);
 /* LDS-DMA (global_load_lds) staged variants of the NT kernel for large launches: 0 = off (register staging only),
  * 1 = 256x128 tile / 3-stage ring, 2 = 128x128 tile / 2 stages, 3 = 128x128 / 3 stages, 4 (default) = 128x128 / 2 stages gathered
  * through buffer descriptors (`buffer_load ... lds`, scalar tap bookkeeping) where C is a multiple of the K tile, else as 2.  Returns the previous
  * setting.  All variants are bit-identical to the register-staged kernel; measurements in DESIGN.md section 4. */
 int eg_set_igemm_dma(int on);
-/* dispatch policy of the buffer-descriptor kernels, thresholds in workgroups per launch: launches with at least big_min_tiles tiles of
- * 256 rows run the 256x256 / 256x128 kernel (0 = never, the default: slower than 128x128 so far); otherwise the 128x128 kernel runs when
- * there are at least buf_min_tiles tiles -- as one persistent pipeline over all tiles (persistent = 1, default) or one workgroup per
- * tile -- and is split along K (eg_epilogue.splitk_ws lent) below splitk_target tiles.  Arguments <= 0 / < 0 / < 0 / < 0 keep. */
-int eg_set_igemm_tuning(int buf_min_tiles, int splitk_target, int big_min_tiles, int persistent);
+/* dispatch policy of the buffer-descriptor kernels, thresholds in workgroups per launch.  In this order: launches with at least
+ * wide_min_tiles tiles of 256 rows run igemm_nt_w (256x128 tile, 64-byte K steps, 3-stage ring; 0 = never); with at least big_min_tiles
+ * the 8-wave 256x256 / 256x128 kernels (0 = never, the default: slower); otherwise the 128x128 kernel runs when there are at least
+ * buf_min_tiles tiles -- one workgroup per tile, or one persistent pipeline over all tiles (persistent = 1) -- and is split along K
+ * (eg_epilogue.splitk_ws lent) below splitk_target tiles.  Arguments <= 0 / < 0 / < 0 / < 0 / < 0 keep the current value. */
+int eg_set_igemm_tuning(int buf_min_tiles, int splitk_target, int big_min_tiles, int persistent, int wide_min_tiles);
 /* bytes of eg_epilogue.splitk_ws that let eg_conv_fwd (bwd = 0) / eg_conv_bwd_data (bwd = 1) split as far as the policy wants */
 size_t eg_conv_splitk_ws_bytes(const eg_conv* c, int dtype, int bwd);
 /* dW partial slabs: slab[split][Cout][k*k][Cin] fp32.  Returns the split count through *nsplit. */

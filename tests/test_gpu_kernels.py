@@ -413,13 +413,15 @@ def test_spectral_norm_multi_layer_launch_matches_single():
 
 
 # (eg_set_igemm_dma mode, big_min_tiles) -> label of the kernel the forward case below must be dispatched to
-NT_VARIANTS = [((1, 0), 256128), ((2, 0), 128129), ((3, 0), 128130), ((4, 0), 128131), ((4, -1), 128135), ((4, 224), 256133), ((0, 0), 128128)]
+NT_VARIANTS = [((1, 0), 256128), ((2, 0), 128129), ((3, 0), 128130), ((4, 0), 128131), ((4, -1), 128135), ((4, -2), 256136), ((4, 224), 256133),
+               ((0, 0), 128128)]
 
 
 def _set_variant(lib, mode, big):
-    """big < 0: the persistent 128x128 pipeline; otherwise one workgroup per tile (library default) and big_min_tiles = big"""
+    """big == -1: the persistent 128x128 pipeline; big == -2: igemm_nt_w (256x128, 64-byte K steps) from 64 tiles on; otherwise one
+    workgroup per 128x128 tile and big_min_tiles = big"""
     lib.query("eg_set_igemm_dma", mode)
-    lib.query("eg_set_igemm_tuning", 512, 512, max(big, 0), 1 if big < 0 else 0)
+    lib.query("eg_set_igemm_tuning", 512, 512, max(big, 0), 1 if big == -1 else 0, 64 if big == -2 else 0)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -484,7 +486,7 @@ def test_igemm_dma_variant_matches_register_staged_kernel(dtype):
     wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
     ops.pack_fwd(c, dtype, w.to(DEV), wp)
     outs = []
-    for (mode, big), label in (((4, 32), 256134), ((0, 0), 128128)):
+    for (mode, big), label in (((4, 32), 256134), ((4, -2), 256136), ((0, 0), 128128)):
         _set_variant(lib, mode, big)
         assert lib.query("eg_igemm_nt_tile", dtype, B * 16 * 16, Cout, Cin, 16 * Cin, 1) == (label if mode else 128064)
         y = torch.zeros(B, 16, 16, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
@@ -492,12 +494,12 @@ def test_igemm_dma_variant_matches_register_staged_kernel(dtype):
         torch.cuda.synchronize()
         outs.append(y)
     _set_variant(lib, 4, 0)
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
     rt, at = tol(dtype, Cin * 16)
     torch.testing.assert_close(nchw(outs[0]), F.relu(F.conv2d(x, rq(w, dtype), b, 2, 1)), rtol=rt, atol=at)
 
 
-@pytest.mark.parametrize("big,Cout", [(0, 128), (-1, 128), (-1, 256), (224, 128), (224, 256)])
+@pytest.mark.parametrize("big,Cout", [(0, 128), (-1, 128), (-1, 256), (-2, 128), (-2, 256), (224, 128), (224, 256)])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_igemm_buf_variant_ragged_rows_and_k_padding(dtype, big, Cout):
     """Buffer-descriptor LDS-DMA NT kernels (128x128, 256x128, 256x256) on a launch whose last row tile is almost empty
@@ -515,7 +517,7 @@ def test_igemm_buf_variant_ragged_rows_and_k_padding(dtype, big, Cout):
     for mode in (4, 0):
         _set_variant(lib, mode, big)
         if mode:
-            assert lib.query("eg_igemm_nt_tile", dtype, B * 64, Cout, Cin, 9 * Cin, 1) == {(0, 128): 128131, (-1, 128): 128135, (-1, 256): 128135, (224, 128): 256133, (224, 256): 256134}[(big, Cout)]
+            assert lib.query("eg_igemm_nt_tile", dtype, B * 64, Cout, Cin, 9 * Cin, 1) == {(0, 128): 128131, (-1, 128): 128135, (-1, 256): 128135, (-2, 128): 256136, (-2, 256): 256136, (224, 128): 256133, (224, 256): 256134}[(big, Cout)]
         y = torch.zeros(B, H, H, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
         ops.conv_fwd(c, dtype, xd, wp, y, ops.epilogue())
         torch.cuda.synchronize()
