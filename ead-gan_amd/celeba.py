@@ -632,6 +632,24 @@ class CelebATrainer:
                     fn()
 
         join = side.join if side is not None else (lambda: None)
+        # Data parallel: every gradient all-reduce is started asynchronously (RCCL's own stream) and finished as late as the data
+        # flow allows: G's of step 1 runs beside the whole of step 2 (which neither reads nor writes G), D's of step 2 beside the
+        # generator forward of step 3, D's of step 3 beside the generator backward.  Only the last one (G, step 3) is exposed.
+        ar = self.allreduce
+        ar_async = ar is not None and hasattr(ar, "start")
+
+        def ar_start(flat):
+            if ar is None:
+                return None
+            if ar_async:
+                return ar.start(flat)
+            ar(flat)
+            return None
+
+        def ar_finish(h):
+            if h is not None:
+                ar.finish(h)
+
         # ---- 1) generator adversarial step (:334-345); D(gen) lives in tape slot 2 so that step 2's tapes can be prepared meanwhile ----
         ops.fill_f32(ga.grad)
         gen = ge.forward(self.z, self.onehot, self.code)
@@ -643,10 +661,14 @@ class CelebATrainer:
         dimg = de.backward(2, 1, self.dout[2 * B:], da.grad, need_wgrad=False, need_dimg=True)
         ge.backward(dimg, ga.grad, side)
         join()
-        if self.allreduce is not None:
-            self.allreduce(ga.grad)
-        self._adam(ga, self.mG, self.vG, self.lr[0], 0, True)
-        on_side(ge.repack, 0)                           # G's panels are next read in step 3
+        pend_g = ar_start(ga.grad)
+
+        def update_g():
+            ar_finish(pend_g)
+            self._adam(ga, self.mG, self.vG, self.lr[0], 0, True)
+            on_side(ge.repack, 0)                       # G's panels are next read in step 3
+        if not ar_async:
+            update_g()
         # ---- 2) discriminator step (:353-366); gen is the (detached) output of step 1; D(scaled) then D(gen), batched ----
         ops.fill_f32(da.grad)
         out = de.forward([self.scaled, gen], 0, prepared=(True, True) if prep else None)
@@ -654,17 +676,27 @@ class CelebATrainer:
         ops.loss_bce_sigmoid(out[B:], 19, 0, B, 0.0, 0.5, self.losses[1:2], self.dout[B:2 * B])
         de.backward(0, 2, self.dout[:2 * B], da.grad, side=side)
         join()
-        if self.allreduce is not None:
-            self.allreduce(da.grad)
-        self._adam(da, self.mD, self.vD, self.lr[1], 1, True)
-        # beside the generator forward below: D's panels, step 3's three power iterations, the patch rows of scaled / real
-        on_side(de.repack, 0)
-        if prep:
-            on_side(lambda: de.prepare(0, [None, self.scaled, self.real]), 1)
+        if ar_async:
+            update_g()
+        pend_d = ar_start(da.grad)
+
+        def update_d():
+            ar_finish(pend_d)
+            self._adam(da, self.mD, self.vD, self.lr[1], 1, True)
+            # beside what follows on the main stream: D's panels, step 3's three power iterations, the patch rows of scaled / real
+            on_side(de.repack, 0)
+            if prep:
+                on_side(lambda: de.prepare(0, [None, self.scaled, self.real]), 1)
+            ops.fill_f32(da.grad)
+        if not ar_async:
+            update_d()
         # ---- 3) info + affine step (:375-401): D(gen), D(scaled), D(real) batched as tapes 0,1,2 ----
         ops.fill_f32(ga.grad)
-        ops.fill_f32(da.grad)
+        if ar_async:
+            join()                                      # G's panels were re-packed a moment ago (update_g)
         gen = ge.forward(self.z, self.onehot, self.code)
+        if ar_async:
+            update_d()
         join()
         out = de.forward([gen, self.scaled, self.real], 0, prepared=(False, True, True) if prep else None)
         o_gen, o_trans, o_real = out[:B], out[B:2 * B], out[2 * B:]
@@ -672,18 +704,18 @@ class CelebATrainer:
         ops.loss_ce_softmaxed(o_gen, 19, cd + 1, nc, B, self.labels, lcat, self.losses[2:3], self.dout[:B])
         ops.loss_affine_rpqxy(o_real, o_trans, 19, 1, B, self.code, cd, laff, self.losses[2:3], self.dout[2 * B:], self.dout[B:2 * B])
         dimg = de.backward(0, 3, self.dout, da.grad, need_dimg=True, side=side)
-        pending = None
-        if self.allreduce is not None and hasattr(self.allreduce, "start"):
+        pend = None
+        if ar_async:
             join()                                      # D's weight gradients are complete
-            pending = self.allreduce.start(da.grad)
+            pend = ar_start(da.grad)
         ge.backward(dimg, ga.grad, side)                # beside D's weight-gradient chains / the D-gradient all-reduce
         join()
-        if self.allreduce is not None:
-            self.allreduce(ga.grad)
-            if pending is not None:
-                self.allreduce.finish(pending)
-            elif not hasattr(self.allreduce, "start"):
-                self.allreduce(da.grad)
+        if ar is not None:
+            ar(ga.grad)
+            if ar_async:
+                ar_finish(pend)
+            else:
+                ar(da.grad)
         self._adam(ga, self.miG, self.viG, self.lr[2], 2, True)
         self._adam(da, self.miD, self.viD, self.lr[2], 2, False)
         on_side(de.repack, 0)
