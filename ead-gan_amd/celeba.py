@@ -99,7 +99,8 @@ class _GenEngine:
         self.l4.pack(self._p(10, "weight"))
         ops.pack_strided(dt, self._p(10, "weight"), self.l4p.wp_fwd, G_WIDTHS[3], self.kp, self.l4p.Kpad_fwd, 1, self.kp, 0, 1)
 
-    def forward(self, noise, labels, code):
+    def forward(self, noise, labels, code, training=True):
+        """``training=False``: BatchNorm with the running statistics, nothing updated (module.eval())."""
         dt, B, W = self.dtype, self.B, G_WIDTHS
         ops.concat_cast(dt, noise, labels, code, self.inp, B, self.cpad)
         ops.conv_fwd(self.l0.c, dt, self.inp, self.l0.wp_fwd, self.h0, ops.epilogue(bias=self._p(0, "bias"), bias_mod=W[0]))
@@ -109,8 +110,11 @@ class _GenEngine:
             ops.conv_bwd_data(r.c, dt, x, r.wp_bwd, self.z[i], ops.epilogue(bias=self._p(idx, "bias")))
             bn = self.gen.conv_blocks[idx + 1]
             M = self.z[i].numel() // W[i + 1]
-            ops.bn_fwd_train(dt, self.z[i], self.a[i], M, W[i + 1], bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean,
-                             bn.running_var, bn.num_batches_tracked, self.mean[i], self.invstd[i], self.ws.small, ACT_RELU)
+            if training:
+                ops.bn_fwd_train(dt, self.z[i], self.a[i], M, W[i + 1], bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean,
+                                 bn.running_var, bn.num_batches_tracked, self.mean[i], self.invstd[i], self.ws.small, ACT_RELU)
+            else:
+                ops.bn_fwd_eval(dt, self.z[i], self.a[i], M, W[i + 1], bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, self.ws.small, ACT_RELU)
             x = self.a[i]
         ops.conv_bwd_data(self.l4.c, dt, x, self.l4.wp_bwd, self.img,
                           ops.epilogue(bias=self._p(10, "bias"), act=ACT_TANH, out_mode=OUT_NCHW_F32))
@@ -233,9 +237,11 @@ class Generator(_HipModule):
 
     def forward(self, noise, labels, code):
         _require_cuda(noise)
-        if not self.training:
-            raise NotImplementedError("eval-mode generator (running-stat BN) is outside the training hot path of this round")
         eng = self.engine(noise.shape[0])
+        if not self.training:
+            # inference (generate_image.py:146-154, gen_imgs.py:106-120): running-stat BatchNorm, no autograd graph
+            with torch.no_grad():
+                return eng.forward(noise.float().contiguous(), labels.float().contiguous(), code.float().contiguous(), training=False).clone()
         params = [p for p in self.parameters()]
         return _GenFn.apply(eng, noise.float().contiguous(), labels.float().contiguous(), code.float().contiguous(), *params)
 

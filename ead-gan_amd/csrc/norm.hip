@@ -134,6 +134,30 @@ extern "C" int eg_bn_fwd_train(int dtype, const void* x, void* y, int M, int C, 
     return 0;
 }
 
+// ---- eval-mode forward (running statistics; generate_image.py / gen_imgs.py of the reference put the generator in .eval()) ------
+__global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+                                    const float* __restrict__ rv, float eps, int C, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float a = gamma[c] / sqrtf(rv[c] + eps);       // torch: (x - mean) / sqrt(var + eps) * weight + bias
+    coef[c] = a;
+    coef[C + c] = beta[c] - rm[c] * a;
+}
+
+extern "C" int eg_bn_fwd_eval(int dtype, const void* x, void* y, int M, int C, const float* gamma, const float* beta, float eps,
+                              const float* running_mean, const float* running_var, float* ws, int act, float slope, eg_stream_t s) {
+    EG_REQUIRE(x && y && gamma && beta && running_mean && running_var && ws && M > 0 && C > 0, "eg_bn_fwd_eval: bad argument");
+    EG_REQUIRE(C % (dtype == EG_F32 ? 4 : 8) == 0, "eg_bn_fwd_eval: C must be a multiple of the 16-byte vector width");
+    hipStream_t st = (hipStream_t)s;
+    hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, gamma, beta, running_mean, running_var, eps, C, ws);
+    const int cpr = C / (dtype == EG_F32 ? 4 : 8);
+    const int blocks = bn_apply_blocks((size_t)M, cpr);
+    if (dtype == EG_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, (size_t)M, C, ws, act, slope);
+    else hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (size_t)M, C, ws, act, slope);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- backward -----------------------------------------------------------------------------------
 __device__ __forceinline__ float pre_act_grad(float y, int act, float slope) {
     switch (act) {

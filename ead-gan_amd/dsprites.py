@@ -241,8 +241,8 @@ class _GenEngine:
         self.l4.pack(cb[9].weight)
         ops.pack_strided(dt, cb[9].weight, self.l4p.wp_fwd, 64, self.k0, self.l4p.Kpad_fwd, 1, self.k0, 0, 1)
 
-    def forward(self, labels, code):
-        """z_c = cat(one-hot labels, code)  (rp.py:404-405)"""
+    def forward(self, labels, code, training=True):
+        """z_c = cat(one-hot labels, code)  (rp.py:404-405).  ``training=False``: running-stat BatchNorm (module.eval())."""
         dt, B, g, ws = self.dtype, self.B, self.gen, self.ws
         cb = g.conv_block
         ops.concat_cast(dt, labels, code, None, self.inp, B, self.cpad)
@@ -253,8 +253,11 @@ class _GenEngine:
             r = self.mid[i]
             ops.conv_bwd_data(r.c, dt, x, r.wp_bwd, self.z[i], ops.epilogue(bias=cb[idx].bias))
             bn = cb[idx + 1]
-            ops.bn_fwd_train(dt, self.z[i], self.a[i], B * (8 << i) ** 2, 64, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
-                             bn.num_batches_tracked, self.mean[i], self.invstd[i], ws.small, ACT_RELU)
+            if training:
+                ops.bn_fwd_train(dt, self.z[i], self.a[i], B * (8 << i) ** 2, 64, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                                 bn.num_batches_tracked, self.mean[i], self.invstd[i], ws.small, ACT_RELU)
+            else:
+                ops.bn_fwd_eval(dt, self.z[i], self.a[i], B * (8 << i) ** 2, 64, bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, ws.small, ACT_RELU)
             x = self.a[i]
         ops.conv_bwd_data(self.l4.c, dt, x, self.l4.wp_bwd, self.img, ops.epilogue(bias=cb[9].bias, act=ACT_SIGMOID, out_mode=OUT_NCHW_F32))
         return self.img
@@ -319,10 +322,11 @@ class Generator(_HipModule):
 
     def forward(self, z_c):
         _require_cuda(z_c)
-        if not self.training:
-            raise NotImplementedError("eval-mode generator (running-stat BN) is outside the training hot path")
         z_c = z_c.float().contiguous()
         eng = self.engine(z_c.shape[0])
+        if not self.training:       # inference (dSprites/gen_imgs.py): running-stat BatchNorm, no autograd graph
+            with torch.no_grad():
+                return eng.forward(z_c[:, :self.n_classes].contiguous(), z_c[:, self.n_classes:].contiguous(), training=False).clone()
         return _GenFn.apply(eng, z_c[:, :self.n_classes].contiguous(), z_c[:, self.n_classes:].contiguous(), *list(self.parameters()))
 
 

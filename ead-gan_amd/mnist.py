@@ -105,13 +105,17 @@ class _GenEngine:
         ops.pack_strided(EG_F32, g.conv_blocks[9].weight, self.w3pad, self.CH, 576, 576, 1, 576, 0, 1)
         self.c3.pack(self.w3pad)
 
-    def forward(self, noise, labels, code):
+    def forward(self, noise, labels, code, training=True):
+        """``training=False``: BatchNorm with the running statistics, nothing updated (module.eval())."""
         dt, B, g, ws = self.dtype, self.B, self.gen, self.ws
         cb = g.conv_blocks
         ops.concat_cast(dt, noise, labels, code, self.inp, B, self.cpad)
         ops.conv_fwd(self.l1.c, dt, self.inp, self.l1.wp_fwd, self.h, ops.epilogue(bias=self.bias_perm))
 
         def bn(x, y, mod, i, M, C, act, slope=0.0):
+            if not training:
+                ops.bn_fwd_eval(dt, x, y, M, C, mod.weight, mod.bias, mod.eps, mod.running_mean, mod.running_var, ws.small, act, slope)
+                return
             ops.bn_fwd_train(dt, x, y, M, C, mod.weight, mod.bias, mod.eps, mod.momentum, mod.running_mean, mod.running_var, mod.num_batches_tracked,
                              self.mean[i], self.invstd[i], ws.small, act, slope)
         s = g.init_size
@@ -190,9 +194,10 @@ class Generator(_HipModule):
 
     def forward(self, noise, labels, code):
         _require_cuda(noise)
-        if not self.training:
-            raise NotImplementedError("eval-mode generator (running-stat BN) is outside the training hot path")
         eng = self.engine(noise.shape[0])
+        if not self.training:       # inference (MNIST/generate_image.py): running-stat BatchNorm, no autograd graph
+            with torch.no_grad():
+                return eng.forward(noise.float().contiguous(), labels.float().contiguous(), code.float().contiguous(), training=False).clone()
         return _GenFn.apply(eng, noise.float().contiguous(), labels.float().contiguous(), code.float().contiguous(), *list(self.parameters()))
 
 

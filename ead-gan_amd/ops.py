@@ -269,6 +269,11 @@ def bn_ws_floats(M, C):
     return lib().query("eg_bn_ws_floats", M, C)
 
 
+def bn_fwd_eval(dtype, x, y, M, C, gamma, beta, eps, running_mean, running_var, ws, act=ACT_NONE, slope=0.0):
+    lib().call("eg_bn_fwd_eval", dtype, _p(x), _p(y), M, C, _p(gamma), _p(beta), float(eps), _p(running_mean), _p(running_var), _p(ws),
+               act, float(slope), _stream())
+
+
 def bn_fwd_train(dtype, x, y, M, C, gamma, beta, eps, momentum, rmean, rvar, nbt, save_mean, save_invstd, ws, act=ACT_NONE, slope=0.0):
     lib().call("eg_bn_fwd_train", dtype, _p(x), _p(y), M, C, _p(gamma), _p(beta), eps, momentum, _p(rmean), _p(rvar), _p(nbt),
                _p(save_mean), _p(save_invstd), _p(ws), act, slope, _stream())

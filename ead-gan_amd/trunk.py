@@ -164,7 +164,7 @@ class TrunkEngine:
             return self._sl(self.patches, t0)
         return self._sl(self.y[i - 1] if self.bns[i - 1] is not None else self.a[i - 1], t0)
 
-    def _fwd_pass(self, t0, T):
+    def _fwd_pass(self, t0, T, training=True):
         dt, B = self.dtype, self.B
         g = self.geo[T]
         for i in range(self.L):
@@ -175,8 +175,12 @@ class TrunkEngine:
             bn = self.bns[i]
             if bn is not None:
                 assert T == 1
-                ops.bn_fwd_train(dt, self._sl(self.a[i], t0), self._sl(self.y[i], t0), self.rows(i), self.W[i], bn.weight, bn.bias, bn.eps, bn.momentum,
-                                 bn.running_mean, bn.running_var, bn.num_batches_tracked, self.mean[i][t0], self.invstd[i][t0], self.ws.small, ACT_NONE)
+                if training:
+                    ops.bn_fwd_train(dt, self._sl(self.a[i], t0), self._sl(self.y[i], t0), self.rows(i), self.W[i], bn.weight, bn.bias, bn.eps, bn.momentum,
+                                     bn.running_mean, bn.running_var, bn.num_batches_tracked, self.mean[i][t0], self.invstd[i][t0], self.ws.small, ACT_NONE)
+                else:       # module.eval() (score/*.load_encoder of the reference): running statistics, nothing updated
+                    ops.bn_fwd_eval(dt, self._sl(self.a[i], t0), self._sl(self.y[i], t0), self.rows(i), self.W[i], bn.weight, bn.bias, bn.eps,
+                                    bn.running_mean, bn.running_var, self.ws.small, ACT_NONE)
         x = self._inp(self.L, t0)
         for i, f in enumerate(self.fcs):
             ops.conv_fwd(g["fc"][i], dt, x, self.frec[i].wp_fwd, self.fa[i][t0 * B:],
@@ -217,9 +221,9 @@ class TrunkEngine:
             ops.im2col_img(dt, img, self.patches[t * npix:(t + 1) * npix], B, self.in_ch, self.S, self.S, self.k, 2, 1, self.kp)
         if self.has_bn:
             for kk in range(T):
-                self._fwd_pass(t0 + kk, 1)
+                self._fwd_pass(t0 + kk, 1, training)
         else:
-            self._fwd_pass(t0, T)
+            self._fwd_pass(t0, T, training)
         return {h.name: self.outs[h.name][t0 * B:(t0 + T) * B] for h in self.heads if h.compute}
 
     # ------------------------------------------------------------------------------------------------------------------

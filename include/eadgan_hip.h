@@ -193,6 +193,10 @@ size_t eg_bn_ws_floats(int M, int C);
 int eg_bn_fwd_train(int dtype, const void* x, void* y, int M, int C, const float* gamma, const float* beta, float eps,
                     float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
                     float* save_mean, float* save_invstd, float* ws, int act, float slope, eg_stream_t s);
+/* eval mode (module.eval(): generate_image.py:146-154, gen_imgs.py:106-120 of the reference): y = act((x - running_mean) /
+ * sqrt(running_var + eps) * gamma + beta); nothing is updated; ws: 2*C floats */
+int eg_bn_fwd_eval(int dtype, const void* x, void* y, int M, int C, const float* gamma, const float* beta, float eps,
+                   const float* running_mean, const float* running_var, float* ws, int act, float slope, eg_stream_t s);
 /* dz from da (gradient w.r.t. the activation output); dgamma/dbeta accumulate; sums: 2*C floats scratch */
 int eg_bn_bwd(int dtype, const void* z, const void* da, void* dz, int M, int C, const float* gamma, const float* beta,
               const float* save_mean, const float* save_invstd, int act, float slope, float* dgamma, float* dbeta,

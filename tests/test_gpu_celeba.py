@@ -300,3 +300,32 @@ def test_side_stream_overlap_is_bit_identical():
     for r in res[1:]:
         assert torch.equal(r[0], res[0][0]), (r[0], res[0][0])
         assert torch.equal(r[1], res[0][1]) and torch.equal(r[2], res[0][2])
+
+
+def test_generator_eval_mode_uses_running_statistics():
+    """generate_image.py / gen_imgs.py of the reference sample from G.eval(): BatchNorm with the running statistics, nothing
+    updated.  Two training forwards move the running statistics, then eval forwards (fp32, bf16) are compared with torch."""
+    B = 8
+    orc, G, D = build_pair(5, "f32")
+    rng = np.random.RandomState(4)
+    for _ in range(2):
+        z, code, labels = co.draw_step_inputs(rng, B)
+        G(z.to(DEV), F.one_hot(labels, 10).float().to(DEV), code.to(DEV))
+    z, code, labels = co.draw_step_inputs(rng, B)
+    onehot = F.one_hot(labels, 10).float()
+    sd = {k: v.detach().cpu().clone() for k, v in G.state_dict().items()}
+    x = torch.cat((z, onehot, code), -1).view(B, -1, 1, 1)
+    x = F.conv_transpose2d(x, sd["conv_blocks.0.weight"], sd["conv_blocks.0.bias"], 1, 0)
+    for idx in (1, 4, 7):
+        x = F.conv_transpose2d(x, sd[f"conv_blocks.{idx}.weight"], sd[f"conv_blocks.{idx}.bias"], 2, 1)
+        x = F.relu(F.batch_norm(x, sd[f"conv_blocks.{idx + 1}.running_mean"], sd[f"conv_blocks.{idx + 1}.running_var"],
+                                sd[f"conv_blocks.{idx + 1}.weight"], sd[f"conv_blocks.{idx + 1}.bias"], False, 0.1, 1e-5))
+    want = torch.tanh(F.conv_transpose2d(x, sd["conv_blocks.10.weight"], sd["conv_blocks.10.bias"], 2, 1))
+    G.eval()
+    got = G(z.to(DEV), onehot.to(DEV), code.to(DEV))
+    assert not got.requires_grad
+    assert rel_err(got, want) < 2e-5
+    for k, v in G.state_dict().items():           # eval touched neither running statistics nor num_batches_tracked
+        assert torch.equal(v.cpu(), sd[k]), k
+    G.set_compute_dtype("bf16")
+    assert rel_err(G(z.to(DEV), onehot.to(DEV), code.to(DEV)), want) < 3e-2
