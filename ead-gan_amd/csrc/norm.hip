@@ -6,33 +6,62 @@
 
 #define BN_RPB 256   // rows per block in the partial kernels
 
+// rows per workgroup of the partial kernels: 256, halved (down to 16) until the launch has >= 512 workgroups
+static int bn_rpb(int M, int gx) {
+    int rpb = BN_RPB;
+    while (rpb > 16 && (long long)gx * cdiv(M, rpb) < 512) rpb >>= 1;
+    return rpb;
+}
+static int bn_gx(int C, int dtype) {
+    const int cpr = C / (dtype == EG_F32 ? 4 : 8);
+    return cdiv(cpr, cpr < 256 ? cpr : 256);
+}
+
+// block = 256 threads = (C/VEC chunk columns) x (row lanes); 16-byte loads; ONE pass: sums of (x - pivot) and (x - pivot)^2 with the
+// block's first row as pivot (no cancellation for row blocks of <= 256 rows), LDS combine of the row lanes in a fixed order
 template <typename T>
-__global__ void bn_stats_partial_kernel(const T* __restrict__ x, int M, int C, float* __restrict__ partial) {
-    __shared__ float sm[4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + cl;
-    const int r0 = blockIdx.y * BN_RPB, r1 = min(M, r0 + BN_RPB);
-    const int cnt = r1 - r0;
-    float s = 0.f;
-    if (col < C)
-        for (int r = r0 + rl; r < r1; r += 4) s += Elt<T>::ld(x + (size_t)r * C + col);
-    sm[rl][cl] = s;
-    __syncthreads();
-    const float mean = (sm[0][cl] + sm[1][cl] + sm[2][cl] + sm[3][cl]) / (float)cnt;
-    __syncthreads();
-    float q = 0.f;
-    if (col < C)
-        for (int r = r0 + rl; r < r1; r += 4) {
-            const float d = Elt<T>::ld(x + (size_t)r * C + col) - mean;
-            q += d * d;
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const T* __restrict__ x, int M, int C, int rpb, float* __restrict__ partial) {
+    constexpr int VEC = Elt<T>::VEC;
+    __shared__ float sm[2][256 * VEC];
+    const int cpr = C / VEC;
+    const int ccols = cpr < 256 ? cpr : 256;
+    const int lanes = 256 / ccols;
+    const int cj = threadIdx.x % ccols, rl = threadIdx.x / ccols;
+    const int chunk = blockIdx.x * ccols + cj;
+    const int r0 = blockIdx.y * rpb, r1 = min(M, r0 + rpb);
+    float s[VEC], q[VEC], pv[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { s[j] = 0.f; q[j] = 0.f; pv[j] = 0.f; }
+    if (chunk < cpr && rl < lanes) {        // (256 % ccols threads idle when ccols does not divide 256)
+        const uint4 p0 = *reinterpret_cast<const uint4*>(x + (size_t)r0 * C + (size_t)chunk * VEC);
+        const T* pe = reinterpret_cast<const T*>(&p0);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) pv[j] = Elt<T>::ld(pe + j);
+        for (int r = r0 + rl; r < r1; r += lanes) {
+            const uint4 v = *reinterpret_cast<const uint4*>(x + (size_t)r * C + (size_t)chunk * VEC);
+            const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float d = Elt<T>::ld(e + j) - pv[j];
+                s[j] += d;
+                q[j] += d * d;
+            }
         }
-    sm[rl][cl] = q;
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { sm[0][threadIdx.x * VEC + j] = s[j]; sm[1][threadIdx.x * VEC + j] = q[j]; }
     __syncthreads();
-    if (rl == 0 && col < C) {
-        float* o = partial + (size_t)blockIdx.y * 3 * C;
-        o[col] = (float)cnt;
-        o[C + col] = mean;
-        o[2 * C + col] = sm[0][cl] + sm[1][cl] + sm[2][cl] + sm[3][cl];
+    if (rl == 0 && chunk < cpr) {
+        const float cnt = (float)(r1 - r0);
+        float* o = partial + (size_t)blockIdx.y * 3 * C + (size_t)chunk * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float ts = 0.f, tq = 0.f;
+            for (int l = 0; l < lanes; ++l) { ts += sm[0][(l * ccols + cj) * VEC + j]; tq += sm[1][(l * ccols + cj) * VEC + j]; }
+            o[j] = cnt;
+            o[C + j] = pv[j] + ts / cnt;
+            o[2 * C + j] = fmaxf(tq - ts * ts / cnt, 0.f);
+        }
     }
 }
 
@@ -111,18 +140,20 @@ static inline int bn_apply_blocks(size_t nrows, int cpr) {
     return (int)want;
 }
 
-extern "C" size_t eg_bn_ws_floats(int M, int C) { return (size_t)cdiv(M, BN_RPB) * 3 * C + 5 * (size_t)C; }
+// bound for every dtype: bn_rpb stops halving once there are 512 workgroups -> at most max(M / 256, 1024) row blocks
+extern "C" size_t eg_bn_ws_floats(int M, int C) { return (size_t)(cdiv(M, BN_RPB) > 1024 ? cdiv(M, BN_RPB) : 1024) * 3 * C + 5 * (size_t)C; }
 
 extern "C" int eg_bn_fwd_train(int dtype, const void* x, void* y, int M, int C, const float* gamma, const float* beta, float eps,
                                float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
                                float* save_mean, float* save_invstd, float* ws, int act, float slope, eg_stream_t s) {
     EG_REQUIRE(x && y && gamma && beta && save_mean && save_invstd && ws && M > 0 && C > 0, "eg_bn_fwd_train: bad argument");
     EG_REQUIRE(C % (dtype == EG_F32 ? 4 : 8) == 0, "eg_bn_fwd_train: C must be a multiple of the 16-byte vector width");
-    const int nrb = cdiv(M, BN_RPB);
-    dim3 g1(cdiv(C, 64), nrb);
+    const int gx = bn_gx(C, dtype), rpb = bn_rpb(M, gx);
+    const int nrb = cdiv(M, rpb);
+    dim3 g1(gx, nrb);
     hipStream_t st = (hipStream_t)s;
-    if (dtype == EG_F32) hipLaunchKernelGGL(bn_stats_partial_kernel<float>, g1, dim3(256), 0, st, (const float*)x, M, C, ws);
-    else hipLaunchKernelGGL(bn_stats_partial_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)x, M, C, ws);
+    if (dtype == EG_F32) hipLaunchKernelGGL(bn_stats_partial_kernel<float>, g1, dim3(256), 0, st, (const float*)x, M, C, rpb, ws);
+    else hipLaunchKernelGGL(bn_stats_partial_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)x, M, C, rpb, ws);
     const int cpr = C / (dtype == EG_F32 ? 4 : 8);
     float* coef = ws + (size_t)nrb * 3 * C;           // 2*C floats behind the partials
     hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, ws, nrb, C, M, eps, momentum, running_mean, running_var,
@@ -168,31 +199,55 @@ __device__ __forceinline__ float pre_act_grad(float y, int act, float slope) {
 }
 
 template <typename T>
-__global__ void bn_bwd_partial_kernel(const T* __restrict__ z, const T* __restrict__ da, int M, int C, const float* __restrict__ gamma,
-                                      const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                      int act, float slope, float* __restrict__ partial) {
-    __shared__ float sm[2][4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + cl;
-    const int r0 = blockIdx.y * BN_RPB, r1 = min(M, r0 + BN_RPB);
-    float s1 = 0.f, s2 = 0.f;
-    if (col < C) {
-        const float mu = mean[col], is = invstd[col], g = gamma[col], b = beta[col];
-        for (int r = r0 + rl; r < r1; r += 4) {
-            const size_t o = (size_t)r * C + col;
-            const float xh = (Elt<T>::ld(z + o) - mu) * is;
-            const float dy = Elt<T>::ld(da + o) * pre_act_grad(xh * g + b, act, slope);
-            s1 += dy;
-            s2 += dy * xh;
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const T* __restrict__ z, const T* __restrict__ da, int M, int C, int rpb,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ mean, const float* __restrict__ invstd, int act, float slope,
+                                                             float* __restrict__ partial) {
+    constexpr int VEC = Elt<T>::VEC;
+    __shared__ float sm[2][256 * VEC];
+    const int cpr = C / VEC;
+    const int ccols = cpr < 256 ? cpr : 256;
+    const int lanes = 256 / ccols;
+    const int cj = threadIdx.x % ccols, rl = threadIdx.x / ccols;
+    const int chunk = blockIdx.x * ccols + cj;
+    const int r0 = blockIdx.y * rpb, r1 = min(M, r0 + rpb);
+    float s1[VEC], s2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    if (chunk < cpr && rl < lanes) {
+        float mu[VEC], is[VEC], g[VEC], bb[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = chunk * VEC + j;
+            mu[j] = mean[c]; is[j] = invstd[c]; g[j] = gamma[c]; bb[j] = beta[c];
+        }
+        for (int r = r0 + rl; r < r1; r += lanes) {
+            const size_t o = (size_t)r * C + (size_t)chunk * VEC;
+            const uint4 vz = *reinterpret_cast<const uint4*>(z + o);
+            const uint4 vd = *reinterpret_cast<const uint4*>(da + o);
+            const T* ez = reinterpret_cast<const T*>(&vz);
+            const T* ed = reinterpret_cast<const T*>(&vd);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float xh = (Elt<T>::ld(ez + j) - mu[j]) * is[j];
+                const float dy = Elt<T>::ld(ed + j) * pre_act_grad(xh * g[j] + bb[j], act, slope);
+                s1[j] += dy;
+                s2[j] += dy * xh;
+            }
         }
     }
-    sm[0][rl][cl] = s1;
-    sm[1][rl][cl] = s2;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { sm[0][threadIdx.x * VEC + j] = s1[j]; sm[1][threadIdx.x * VEC + j] = s2[j]; }
     __syncthreads();
-    if (rl == 0 && col < C) {
-        float* o = partial + (size_t)blockIdx.y * 2 * C;
-        o[col] = sm[0][0][cl] + sm[0][1][cl] + sm[0][2][cl] + sm[0][3][cl];
-        o[C + col] = sm[1][0][cl] + sm[1][1][cl] + sm[1][2][cl] + sm[1][3][cl];
+    if (rl == 0 && chunk < cpr) {
+        float* o = partial + (size_t)blockIdx.y * 2 * C + (size_t)chunk * VEC;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int l = 0; l < lanes; ++l) { t1 += sm[0][(l * ccols + cj) * VEC + j]; t2 += sm[1][(l * ccols + cj) * VEC + j]; }
+            o[j] = t1;
+            o[C + j] = t2;
+        }
     }
 }
 
@@ -259,10 +314,11 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ z, const T* __restrict
 static int bn_bwd_impl(int dtype, const void* z, const void* da, void* dz, int M, int C, const float* gamma, const float* beta,
                        const float* save_mean, const float* save_invstd, int act, float slope, float* dgamma, float* dbeta, float* sums, float* ws,
                        int post_act, float post_slope, const float* post_sigma, hipStream_t st) {
-    const int nrb = cdiv(M, BN_RPB);
-    dim3 g1(cdiv(C, 64), nrb);
-    if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_partial_kernel<float>, g1, dim3(256), 0, st, (const float*)z, (const float*)da, M, C, gamma, beta, save_mean, save_invstd, act, slope, ws);
-    else hipLaunchKernelGGL(bn_bwd_partial_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)da, M, C, gamma, beta, save_mean, save_invstd, act, slope, ws);
+    const int gx = bn_gx(C, dtype), rpb = bn_rpb(M, gx);
+    const int nrb = cdiv(M, rpb);
+    dim3 g1(gx, nrb);
+    if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_partial_kernel<float>, g1, dim3(256), 0, st, (const float*)z, (const float*)da, M, C, rpb, gamma, beta, save_mean, save_invstd, act, slope, ws);
+    else hipLaunchKernelGGL(bn_bwd_partial_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)da, M, C, rpb, gamma, beta, save_mean, save_invstd, act, slope, ws);
     const int cpr = C / (dtype == EG_F32 ? 4 : 8);
     float* coef = ws + (size_t)nrb * 3 * C;
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, ws, nrb, C, sums, dgamma, dbeta, gamma, beta, save_mean, save_invstd, M, coef);

@@ -77,7 +77,8 @@ def test_generator_forward_backward(dtype, tol):
     rng = np.random.RandomState(5)
     z, code, labels = mo.draw_step_inputs(rng, B)
     onehot = F.one_hot(labels, 10).float()
-    want = mo.generator_forward(orc.G, z, onehot, code)
+    taps = []
+    want = mo.generator_forward(orc.G, z, onehot, code, taps)
     dimg = torch.randn(want.shape, generator=torch.Generator().manual_seed(3)) * 1e-2
     want.backward(dimg)
     ge = G.engine(B)
@@ -86,11 +87,15 @@ def test_generator_forward_backward(dtype, tol):
     assert rel_err(got, want) < tol
     grad = torch.zeros_like(G.arena.grad)
     ge.backward(dimg.to(DEV), grad)
+    # a BatchNorm output within rounding of 0 can take the other LeakyReLU branch than in torch (summation order); one such unit
+    # moves the upstream gradients by ~1e-3 in fp32 -> the tight bound holds when the masks agree, an allowance per flip otherwise
+    flips = sum(int(((a.permute(0, 3, 1, 2).float().cpu() > 0) != (t > 0)).sum()) for a, t in zip((ge.a1, ge.a2), taps)) if dtype == "f32" else 0
+    assert flips <= 3, flips
     for k in dict(G.named_parameters()):
         if k in PRE_BN_BIAS:
             continue
         off, n = G.arena.slices[k]
-        assert rel_err(grad[off:off + n], orc.G[k].grad) < tol * 20, k
+        assert rel_err(grad[off:off + n], orc.G[k].grad) < tol * 20 + 4e-3 * flips, (k, flips)
     for k in ("conv_blocks.0.running_mean", "conv_blocks.3.running_var", "conv_blocks.7.running_mean"):
         assert rel_err(G.state_dict()[k], orc.G[k]) < max(tol, 1e-4), k
 
