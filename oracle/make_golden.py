@@ -194,7 +194,25 @@ def make_colored(B=8, steps=3, seed=0, pxy_seed=654):
     print("colored golden:", {k: out[k] for k in names})
 
 
-MAKERS = {"colored": make_colored, "dsprites": make_dsprites, "celeba": make_celeba, "celeba_affine": make_celeba_affine, "mnist": make_mnist, "mnist_affine": make_mnist_affine}
+def make_celeba_curve(B=4, steps=120, seed=0):
+    """Loss curves of a longer reference run (celebA/EAD-GAN_celebA.py:297-401, B=4, 120 iterations on seeded synthetic batches).
+    Free-running trajectories of two fp32 implementations separate step by step (Adam's +-lr first updates amplify rounding
+    noise), so these are compared as windowed means, not per step: the fixture pins the training DYNAMICS (optimizer
+    schedules, BatchNorm / spectral-norm state evolution) that single-step vectors cannot."""
+    torch.set_num_threads(8)
+    real = co.synthetic_real(B * steps, seed=4242).view(steps, B, 3, 64, 64)
+    names = ("d_loss", "g_loss", "info_loss")
+    batches = [(real[i].clone(), torch.zeros(B, dtype=torch.int64)) for i in range(steps)]
+    g, recs = rh.run_script_loop("celebA/EAD-GAN_celebA.py", rh.celeba_opt(B), batches, names, seed)
+    out = {"B": np.array(B), "steps": np.array(steps), "seed": np.array(seed), "real_seed": np.array(4242)}
+    for k in names:
+        out[k] = np.array([r[k] for r in recs], dtype=np.float32)
+    np.savez_compressed(os.path.join(GOLD, f"celeba_curve_b{B}_s{steps}.npz"), **out)
+    print("celeba curve golden: first/last", {k: (float(out[k][0]), float(out[k][-1])) for k in names})
+
+
+MAKERS = {"colored": make_colored, "dsprites": make_dsprites, "celeba": make_celeba, "celeba_affine": make_celeba_affine, "mnist": make_mnist, "mnist_affine": make_mnist_affine,
+          "celeba_curve": make_celeba_curve}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
