@@ -63,12 +63,14 @@ def roofline_pass(eg, trainer, dtype, iters=3):
     # stream here (same kernels, same arguments, same order inside every chain).  `--no-overlap` runs the whole bench that way:
     # profiles/ holds the rocprofv3 summaries of both commands; the per-kernel averages of the --no-overlap one agree with this table.
     side, trainer.side = getattr(trainer, "side", None), None
+    # rank 0 runs this pass alone: no collectives inside it (the other ranks are not calling them)
+    allreduce, trainer.allreduce = getattr(trainer, "allreduce", None), None
     ops.RECORDER = []
     for _ in range(iters):
         trainer._step_body()
     torch.cuda.synchronize()
     rec, ops.RECORDER = ops.RECORDER, None
-    trainer.side = side
+    trainer.side, trainer.allreduce = side, allreduce
     table, detail = {}, {}
     for label, flops, e0, e1, shape in rec:
         ms = e0.elapsed_time(e1)

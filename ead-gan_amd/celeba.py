@@ -17,7 +17,7 @@ import torch.nn as nn
 from torch.nn.utils import spectral_norm
 
 from . import ops
-from .engine import Arena, ConvRec, SideStream, Workspace, parse_dtype
+from .engine import Arena, ConvRec, SideStream, Workspace, capture_step, parse_dtype
 from .ops import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, EG_BF16, EG_F32, OUT_NCHW_F32)
 
 # module-level hyper-parameters, mirroring the reference's global ``opt`` (argparse defaults, :39-51)
@@ -767,11 +767,7 @@ class CelebATrainer:
         ``warmup=True`` runs that iteration here -- note that it IS a real training step on the current inputs."""
         if warmup:
             self._step_body()
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._step_body()
-        return self
+        return capture_step(self, self._step_body)
 
     def step_resident(self):
         """Run one iteration on whatever is in the static input slots; returns the device loss tensor [g,d,info,_]."""

@@ -13,6 +13,14 @@ void eg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* eg_last_error(void) { return g_err; }
+
+/* drains HIP's sticky last-error slot (e.g. hipErrorStreamCaptureInvalidated after a hipGraph capture that a collective refused);
+ * returns how many errors were pending.  Callers that fall back from graph replay to eager launches call this once. */
+extern "C" int eg_clear_errors(void) {
+    int n = 0;
+    while (hipGetLastError() != hipSuccess && n < 16) ++n;
+    return n;
+}
 extern "C" int eg_version(void) { return 100; }
 
 // out[b][0:wa|wa:wa+wb|..] = cast(a|b|c), zero padded to Cpad  (generator input, celebA/EAD-GAN_celebA.py:97)

@@ -15,6 +15,11 @@ def init_from_env(backend: str | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box: EG_DIST_BACKEND=gloo EG_SHARE_GPU=1 runs N ranks on device 0 over gloo (RCCL refuses
+    # two ranks on one device); the driver's N-GPU runs never set these
+    backend = backend or os.environ.get("EG_DIST_BACKEND") or None
+    if os.environ.get("EG_SHARE_GPU"):
+        local = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")

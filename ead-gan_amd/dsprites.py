@@ -14,7 +14,7 @@ from torch.nn.utils import spectral_norm
 
 from . import ops
 from .celeba import _HipModule, _require_cuda, transformation_2D      # noqa: F401
-from .engine import ConvRec, Workspace, parse_dtype
+from .engine import ConvRec, Workspace, capture_step, parse_dtype
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, EG_F32, OUT_NCHW_F32
 from .trunk import Head, TrunkEngine
 
@@ -528,11 +528,7 @@ class DspritesTrainer:
     def capture(self, warmup=False):
         if warmup:
             self._step_body()
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._step_body()
-        return self
+        return capture_step(self, self._step_body)
 
     def step_resident(self):
         if self.graph is not None:

@@ -133,6 +133,32 @@ class SideStream:
             cur.wait_event(ev)
 
 
+def capture_step(trainer, body):
+    """Capture ``body()`` (one whole training iteration) into a hipGraph and store it as ``trainer.graph``.  If the capture fails
+    (e.g. a collective that cannot be captured) the trainer stays usable for eager launches: torch.cuda.graph's exit raises
+    inside capture_end, i.e. before it restores the stream, so that is done here, HIP's sticky error is drained, and side lanes
+    that were forked into the invalidated capture are replaced; the exception is re-raised for the caller to report."""
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    before = torch.cuda.current_stream()
+    try:
+        with torch.cuda.graph(graph):
+            body()
+    except Exception:
+        trainer.graph = None
+        torch.cuda.set_stream(before)
+        try:
+            torch.cuda.synchronize()
+        except Exception:
+            pass
+        ops.clear_errors()
+        if getattr(trainer, "side", None) is not None:
+            trainer.side = SideStream(trainer.dev, Workspace.get(trainer.dev))
+        raise
+    trainer.graph = graph
+    return trainer
+
+
 class ConvRec:
     """One conv-view layer at a fixed batch size: geometry, packed panels, workspace reservations."""
 

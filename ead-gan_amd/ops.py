@@ -317,6 +317,10 @@ def adam_step(p, g, m, v, n, lr, b1, b2, eps, step, tick=True):
     lib().call("eg_adam_step", _p(p), _p(g), _p(m), _p(v), n, lr, b1, b2, eps, _p(step), int(tick), _stream())
 
 
+def clear_errors():
+    return lib().query("eg_clear_errors")
+
+
 def fill_f32(t, val=0.0):
     lib().call("eg_fill_f32", _p(t), t.numel(), val, _stream())
 

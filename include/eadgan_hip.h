@@ -33,6 +33,8 @@ enum { EG_OUT_NHWC = 0, EG_OUT_NCHW_F32 = 1 };
 
 int eg_version(void);
 const char* eg_last_error(void);
+/* drain HIP's sticky last-error slot after a failed hipGraph capture (returns the number of pending errors) */
+int eg_clear_errors(void);
 
 /* One square 2-D convolution in conv view.  X is [B,H,W,Cin] (NHWC); if up==1 the conv reads the
  * nearest-2x-upsampled X (nn.Upsample fused, MNIST/EAD-GAN_rpqmnxy.py:81,85).  Y is [B,OH,OW,Cout],
