@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step (BASELINE config: 128)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -92,7 +92,7 @@ def roofline_pass(eg, trainer, dtype, iters=3):
         return None, table
     dom = max(table, key=lambda k: table[k]["ms"])
     d = table[dom]
-    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+    peak = PEAK_F32_TFLOPS if dtype == "f32" else PEAK_BF16_TFLOPS        # f16 and bf16 MFMA run at the same rate
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
     traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json), if this kernel is in them
     try:
@@ -152,7 +152,7 @@ def main_mnist(a, eg, rank, world, local, dev):
     dt = eg.dp.max_over_ranks(time.perf_counter() - t0, dev)
     if rank == 0:
         ips = B * world * a.steps / dt
-        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_F32_TFLOPS if a.dtype == "f32" else PEAK_BF16_TFLOPS
         print(json.dumps({"metric": "imgs/sec per G+D+E train step, MNIST 32x32", "value": round(ips, 1), "unit": "imgs/s", "n_gpus": world,
                           "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
@@ -198,7 +198,7 @@ def main_sprites(a, eg, rank, world, local, dev):
     dt = eg.dp.max_over_ranks(time.perf_counter() - t0, dev)
     if rank == 0:
         ips = B * world * a.steps / dt
-        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_F32_TFLOPS if a.dtype == "f32" else PEAK_BF16_TFLOPS
         gf = 0.533 if color else 0.485
         print(json.dumps({"metric": f"imgs/sec per train step, {'colored ' if color else ''}dSprites 64x64", "value": round(ips, 1), "unit": "imgs/s",
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
@@ -277,7 +277,7 @@ def main():
 
     if rank == 0:
         ips = B * world * a.steps / dt
-        peak = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_F32_TFLOPS if a.dtype == "f32" else PEAK_BF16_TFLOPS
         out = {
             "metric": "imgs/sec per G+D+E train step, CelebA 64x64 bs=128",
             "value": round(ips, 1), "unit": "imgs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

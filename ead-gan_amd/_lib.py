@@ -15,7 +15,7 @@ ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(ROOT, "include", "eadgan_hip.h")
 LIB_PATH = os.path.join(_HERE, "libeadgan_hip.so")
 
-EG_F32, EG_BF16 = 0, 1
+EG_F32, EG_BF16, EG_F16 = 0, 1, 2
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = range(5)
 OUT_NHWC, OUT_NCHW_F32 = 0, 1
 

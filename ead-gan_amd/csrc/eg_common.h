@@ -42,6 +42,12 @@ template <> struct Elt<float> {
     __device__ static __forceinline__ float ld(const float* p) { return *p; }
     __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
 };
+typedef _Float16 f16_t;    // IEEE binary16 (config "colored dSprites fp16"); same MFMA rate as bf16, fp32 accumulate
+template <> struct Elt<f16_t> {
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+    __device__ static __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }     // round to nearest even
+};
 template <> struct Elt<bf16_t> {
     static constexpr int VEC = 8;
     __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }

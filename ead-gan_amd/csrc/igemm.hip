@@ -19,6 +19,7 @@
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 // ------------------------------------------------------------------------------------------------
@@ -69,7 +70,7 @@ static int conv_out_dim(const eg_conv* c, int in) { return ((in << c->up) + 2 * 
 enum { NEED_CIN = 1, NEED_COUT = 2 };
 static int check_conv(const eg_conv* c, int dtype, int need) {
     EG_REQUIRE(c && c->B > 0 && c->k > 0 && c->stride > 0 && c->pad >= 0 && (c->up == 0 || c->up == 1), "eg_conv: bad field");
-    EG_REQUIRE(dtype == EG_F32 || dtype == EG_BF16, "dtype must be EG_F32 or EG_BF16");
+    EG_REQUIRE(dtype == EG_F32 || dtype == EG_BF16 || dtype == EG_F16, "dtype must be EG_F32, EG_BF16 or EG_F16");
     const int OH = conv_out_dim(c, c->H), OW = conv_out_dim(c, c->W);
     EG_REQUIRE(ilog2_exact(c->H) >= 0 && ilog2_exact(c->W) >= 0 && ilog2_exact(OH) >= 0 && ilog2_exact(OW) >= 0,
                "spatial extents must be powers of two (H=%d W=%d OH=%d OW=%d)", c->H, c->W, OH, OW);
@@ -143,6 +144,8 @@ __device__ __forceinline__ void mfma_step(const uint4& a, const uint4& b, f32x4&
         const float* bf = reinterpret_cast<const float*>(&b);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[e], af[e], acc, 0, 0, 0);
+    } else if constexpr (std::is_same<T, f16_t>::value) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, b), __builtin_bit_cast(f16x8_t, a), acc, 0, 0, 0);
     } else {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b), __builtin_bit_cast(bf16x8_t, a), acc, 0, 0, 0);
     }
@@ -1710,7 +1713,9 @@ extern "C" int eg_conv_fwd(const eg_conv* c, int dtype, const void* X, const voi
     geom_fwd(c, dtype, p);
     p.src = X; p.wp = wp_fwd; p.dst = Y;
     fill_epilogue(p, ep);
-    if (dtype == EG_F32) launch_nt<float>(p, 1, (hipStream_t)s); else launch_nt<bf16_t>(p, 1, (hipStream_t)s);
+    if (dtype == EG_F32) launch_nt<float>(p, 1, (hipStream_t)s);
+    else if (dtype == EG_F16) launch_nt<f16_t>(p, 1, (hipStream_t)s);
+    else launch_nt<bf16_t>(p, 1, (hipStream_t)s);
     EG_LAUNCH_CHECK();
     return 0;
 }
@@ -1725,7 +1730,9 @@ extern "C" int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, con
     if (int e = geom_bwd(c, dtype, p, &nphase)) return e;
     p.src = dY; p.wp = wp_bwd; p.dst = dX;
     fill_epilogue(p, ep);
-    if (dtype == EG_F32) launch_nt<float>(p, nphase, (hipStream_t)s); else launch_nt<bf16_t>(p, nphase, (hipStream_t)s);
+    if (dtype == EG_F32) launch_nt<float>(p, nphase, (hipStream_t)s);
+    else if (dtype == EG_F16) launch_nt<f16_t>(p, nphase, (hipStream_t)s);
+    else launch_nt<bf16_t>(p, nphase, (hipStream_t)s);
     EG_LAUNCH_CHECK();
     return 0;
 }
@@ -1779,6 +1786,7 @@ static void launch_pack(const PackParams& p, int dtype, hipStream_t st) {
     for (int i = 0; i < p.nphase; ++i) total = total > (long long)p.Nrows * p.ph[i].Kpad ? total : (long long)p.Nrows * p.ph[i].Kpad;
     const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
     if (dtype == EG_F32) hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks, p.nphase), dim3(256), 0, st, p);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(pack_kernel<f16_t>, dim3(blocks, p.nphase), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks, p.nphase), dim3(256), 0, st, p);
 }
 
@@ -1894,7 +1902,7 @@ __global__ __launch_bounds__(256) void pack_conv_tile_kernel(const PackTileParam
 
 extern "C" int eg_pack_conv(const eg_conv* c, int dtype, const float* w, void* wp_fwd, void* wp_bwd, eg_stream_t s) {
     EG_REQUIRE(c && w && (wp_fwd || wp_bwd), "eg_pack_conv: null pointer");
-    EG_REQUIRE(dtype == EG_F32 || dtype == EG_BF16, "dtype must be EG_F32 or EG_BF16");
+    EG_REQUIRE(dtype == EG_F32 || dtype == EG_BF16 || dtype == EG_F16, "dtype must be EG_F32, EG_BF16 or EG_F16");
     const int T = c->k * c->k, bk = bk_of(dtype);
     bool fast = (c->Cout % 16) == 0 && (c->Cin % 32) == 0 && T <= 16 && (!wp_bwd || c->stride <= 2);
     PackTileParams p;
@@ -1928,6 +1936,7 @@ extern "C" int eg_pack_conv(const eg_conv* c, int dtype, const float* w, void* w
     const dim3 grid(c->Cout / 16, c->Cin / 32);
     const size_t lds = (size_t)16 * 32 * (T + 1) * sizeof(float);
     if (dtype == EG_F32) hipLaunchKernelGGL(pack_conv_tile_kernel<float>, grid, dim3(256), lds, (hipStream_t)s, p);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(pack_conv_tile_kernel<f16_t>, grid, dim3(256), lds, (hipStream_t)s, p);
     else hipLaunchKernelGGL(pack_conv_tile_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)s, p);
     EG_LAUNCH_CHECK();
     return 0;
@@ -1964,6 +1973,7 @@ extern "C" int eg_pack_strided2(int dtype, const float* w, void* wp, int N, int 
     const long long total = (long long)N * Kpad;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     if (dtype == EG_F32) hipLaunchKernelGGL(pack_strided2_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (float*)wp, N, K, Kpad, n_div, s_hi, s_lo, k_div, s_khi, s_klo);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(pack_strided2_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (f16_t*)wp, N, K, Kpad, n_div, s_hi, s_lo, k_div, s_khi, s_klo);
     else hipLaunchKernelGGL(pack_strided2_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)wp, N, K, Kpad, n_div, s_hi, s_lo, k_div, s_khi, s_klo);
     EG_LAUNCH_CHECK();
     return 0;
@@ -1975,6 +1985,7 @@ extern "C" int eg_pack_strided(int dtype, const float* w, void* wp, int N, int K
     const long long total = (long long)N * Kpad;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     if (dtype == EG_F32) hipLaunchKernelGGL(pack_strided_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (float*)wp, N, K, Kpad, n_div, s_hi, s_lo, s_k);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(pack_strided_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (f16_t*)wp, N, K, Kpad, n_div, s_hi, s_lo, s_k);
     else hipLaunchKernelGGL(pack_strided_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)wp, N, K, Kpad, n_div, s_hi, s_lo, s_k);
     EG_LAUNCH_CHECK();
     return 0;
@@ -2146,7 +2157,10 @@ __global__ __launch_bounds__(256) void igemm_tn_kernel(const TnParams p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+                    if constexpr (std::is_same<T, f16_t>::value)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, af[i]), __builtin_bit_cast(f16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
             }
         }
         if (kt + 1 < nk) lstore((kt + 1) & 1);
@@ -2236,7 +2250,9 @@ extern "C" int eg_conv_wgrad(const eg_conv* c, int dtype, const void* X, const v
     tn_plan(c, &ns, &rps);
     tn_tiles(c, &bnt, &bct);
     p.rows_per_split = rps;
-    if (dtype == EG_F32) launch_tn<float>(p, bnt, bct, ns, (hipStream_t)s); else launch_tn<bf16_t>(p, bnt, bct, ns, (hipStream_t)s);
+    if (dtype == EG_F32) launch_tn<float>(p, bnt, bct, ns, (hipStream_t)s);
+    else if (dtype == EG_F16) launch_tn<f16_t>(p, bnt, bct, ns, (hipStream_t)s);
+    else launch_tn<bf16_t>(p, bnt, bct, ns, (hipStream_t)s);
     *nsplit_out = ns;
     EG_LAUNCH_CHECK();
     return 0;
@@ -2456,6 +2472,7 @@ extern "C" int eg_bias_grad(int dtype, const void* dY, int rows, int N, int bias
     const int nrb = cdiv(rows, rpb);
     dim3 grid(cdiv(cpr, ccols), nrb);
     if (dtype == EG_F32) hipLaunchKernelGGL(colsum_partial_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)dY, rows, N, rpb, partials);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(colsum_partial_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)s, (const f16_t*)dY, rows, N, rpb, partials);
     else hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)dY, rows, N, rpb, partials);
     const int nb = bias_mod > 0 ? bias_mod : N;
     hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(nb, 4)), dim3(256), 0, (hipStream_t)s, partials, nrb, N, nb, (const float*)nullptr, gb);
@@ -2557,6 +2574,7 @@ extern "C" int eg_bias_grad_sn(int dtype, const void* dzs, const void* a, const 
     float* dots = ws + (size_t)nrb * N;
     dim3 grid(gx, nrb);
     if (dtype == EG_F32) hipLaunchKernelGGL(colsum_sn_partial_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, (const float*)dzs, (const float*)a, bias, N, rows_per_tape, bpt, rpb, 1.f / slope, partials, dots);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(colsum_sn_partial_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)s, (const f16_t*)dzs, (const f16_t*)a, bias, N, rows_per_tape, bpt, rpb, 1.f / slope, partials, dots);
     else hipLaunchKernelGGL(colsum_sn_partial_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)dzs, (const bf16_t*)a, bias, N, rows_per_tape, bpt, rpb, 1.f / slope, partials, dots);
     hipLaunchKernelGGL(colsum_sn_final_kernel, dim3(cdiv(N + ntapes, 4)), dim3(256), 0, (hipStream_t)s, partials, dots, nrb, N, bpt, gx, ntapes, sigma, gb, coef);
     EG_LAUNCH_CHECK();

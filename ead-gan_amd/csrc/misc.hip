@@ -41,6 +41,7 @@ extern "C" int eg_concat_cast(int dtype, const float* a, int wa, const float* b,
     EG_REQUIRE(out && B > 0 && Cpad >= wa + wb + wc, "eg_concat_cast: bad argument");
     const int n = B * Cpad;
     if (dtype == EG_F32) hipLaunchKernelGGL(concat_cast_kernel<float>, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, a, wa, b, wb, c, wc, B, Cpad, (float*)out);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(concat_cast_kernel<f16_t>, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, a, wa, b, wb, c, wc, B, Cpad, (f16_t*)out);
     else hipLaunchKernelGGL(concat_cast_kernel<bf16_t>, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)s, a, wa, b, wb, c, wc, B, Cpad, (bf16_t*)out);
     EG_LAUNCH_CHECK();
     return 0;
@@ -87,6 +88,7 @@ extern "C" int eg_nchw_to_nhwc(int dtype, const float* x, void* y, int B, int C,
     const size_t n = (size_t)B * HW * Cpad;
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     if (dtype == EG_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, x, (float*)y, B, C, HW, Cpad);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, x, (f16_t*)y, B, C, HW, Cpad);
     else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, x, (bf16_t*)y, B, C, HW, Cpad);
     EG_LAUNCH_CHECK();
     return 0;
@@ -96,6 +98,7 @@ extern "C" int eg_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C,
     const size_t n = (size_t)B * C * HW;
     const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     if (dtype == EG_F32) hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)x, y, B, C, HW, Cpad);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(nhwc_to_nchw_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const f16_t*)x, y, B, C, HW, Cpad);
     else hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, y, B, C, HW, Cpad);
     EG_LAUNCH_CHECK();
     return 0;
@@ -148,6 +151,7 @@ extern "C" int eg_sumpool2x2(int dtype, const void* x, void* y, int B, int H, in
     const size_t total = (size_t)B * H * W * (C / (dtype == EG_F32 ? 4 : 8));
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     if (dtype == EG_F32) hipLaunchKernelGGL(sumpool2x2_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const float*)x, (float*)y, B, H, W, C);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(sumpool2x2_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const f16_t*)x, (f16_t*)y, B, H, W, C);
     else hipLaunchKernelGGL(sumpool2x2_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
     EG_LAUNCH_CHECK();
     return 0;

@@ -153,6 +153,7 @@ extern "C" int eg_bn_fwd_train(int dtype, const void* x, void* y, int M, int C, 
     dim3 g1(gx, nrb);
     hipStream_t st = (hipStream_t)s;
     if (dtype == EG_F32) hipLaunchKernelGGL(bn_stats_partial_kernel<float>, g1, dim3(256), 0, st, (const float*)x, M, C, rpb, ws);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(bn_stats_partial_kernel<f16_t>, g1, dim3(256), 0, st, (const f16_t*)x, M, C, rpb, ws);
     else hipLaunchKernelGGL(bn_stats_partial_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)x, M, C, rpb, ws);
     const int cpr = C / (dtype == EG_F32 ? 4 : 8);
     float* coef = ws + (size_t)nrb * 3 * C;           // 2*C floats behind the partials
@@ -160,6 +161,7 @@ extern "C" int eg_bn_fwd_train(int dtype, const void* x, void* y, int M, int C, 
                        num_batches_tracked, save_mean, save_invstd, gamma, beta, coef);
     const int blocks = bn_apply_blocks((size_t)M, cpr);
     if (dtype == EG_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, (size_t)M, C, coef, act, slope);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(bn_apply_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, (size_t)M, C, coef, act, slope);
     else hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (size_t)M, C, coef, act, slope);
     EG_LAUNCH_CHECK();
     return 0;
@@ -184,6 +186,7 @@ extern "C" int eg_bn_fwd_eval(int dtype, const void* x, void* y, int M, int C, c
     const int cpr = C / (dtype == EG_F32 ? 4 : 8);
     const int blocks = bn_apply_blocks((size_t)M, cpr);
     if (dtype == EG_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, (size_t)M, C, ws, act, slope);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(bn_apply_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, (size_t)M, C, ws, act, slope);
     else hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (size_t)M, C, ws, act, slope);
     EG_LAUNCH_CHECK();
     return 0;
@@ -318,12 +321,14 @@ static int bn_bwd_impl(int dtype, const void* z, const void* da, void* dz, int M
     const int nrb = cdiv(M, rpb);
     dim3 g1(gx, nrb);
     if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_partial_kernel<float>, g1, dim3(256), 0, st, (const float*)z, (const float*)da, M, C, rpb, gamma, beta, save_mean, save_invstd, act, slope, ws);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(bn_bwd_partial_kernel<f16_t>, g1, dim3(256), 0, st, (const f16_t*)z, (const f16_t*)da, M, C, rpb, gamma, beta, save_mean, save_invstd, act, slope, ws);
     else hipLaunchKernelGGL(bn_bwd_partial_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)da, M, C, rpb, gamma, beta, save_mean, save_invstd, act, slope, ws);
     const int cpr = C / (dtype == EG_F32 ? 4 : 8);
     float* coef = ws + (size_t)nrb * 3 * C;
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, ws, nrb, C, sums, dgamma, dbeta, gamma, beta, save_mean, save_invstd, M, coef);
     const int blocks = bn_apply_blocks((size_t)M, cpr);
     if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)z, (const float*)da, (float*)dz, (size_t)M, C, coef, act, slope, post_act, post_slope, post_sigma);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, (const f16_t*)z, (const f16_t*)da, (f16_t*)dz, (size_t)M, C, coef, act, slope, post_act, post_slope, post_sigma);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)da, (bf16_t*)dz, (size_t)M, C, coef, act, slope, post_act, post_slope, post_sigma);
     return 0;
 }

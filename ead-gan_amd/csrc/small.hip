@@ -96,7 +96,7 @@ extern "C" int eg_conv_img_fwd(int dtype, const float* img, const float* w_maste
     const size_t lds = (size_t)(CI * k * k * N + CI * k * (W + 2 * pad)) * sizeof(float);
     hipStream_t st = (hipStream_t)s;
 #define EG_CASE(T_, C_) hipLaunchKernelGGL((conv_img_fwd_kernel<T_, C_>), grid, dim3(256), lds, st, p)
-#define EG_DISPATCH(C_) do { if (dtype == EG_F32) EG_CASE(float, C_); else EG_CASE(bf16_t, C_); } while (0)
+#define EG_DISPATCH(C_) do { if (dtype == EG_F32) EG_CASE(float, C_); else if (dtype == EG_F16) EG_CASE(f16_t, C_); else EG_CASE(bf16_t, C_); } while (0)
     switch (cpt) {
         case 1: EG_DISPATCH(1); break;
         case 2: EG_DISPATCH(2); break;
@@ -172,7 +172,7 @@ extern "C" int eg_conv_img_wgrad(int dtype, const void* dz, const float* img, fl
     EG_REQUIRE(lds <= 64 * 1024, "eg_conv_img_wgrad: image does not fit LDS");
     hipStream_t st = (hipStream_t)s;
 #define EG_CASE(T_, M_) hipLaunchKernelGGL((conv_img_wgrad_kernel<T_, M_>), dim3(B), dim3(256), lds, st, (const T_*)dz, img, slab, CI, H, W, N, k, stride, pad, OH, OW)
-#define EG_DISPATCH(M_) do { if (dtype == EG_F32) EG_CASE(float, M_); else EG_CASE(bf16_t, M_); } while (0)
+#define EG_DISPATCH(M_) do { if (dtype == EG_F32) EG_CASE(float, M_); else if (dtype == EG_F16) EG_CASE(f16_t, M_); else EG_CASE(bf16_t, M_); } while (0)
     if (maxt <= 1) EG_DISPATCH(1);
     else if (maxt <= 2) EG_DISPATCH(2);
     else if (maxt <= 3) EG_DISPATCH(3);
@@ -328,6 +328,7 @@ extern "C" int eg_im2col_img(int dtype, const float* img, void* out, int B, int 
     const size_t total = (size_t)B * OH * OW * (Kp / (dtype == EG_F32 ? 4 : 8));
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
     if (dtype == EG_F32) hipLaunchKernelGGL(im2col_img_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, img, (float*)out, B, CI, H, W, k, stride, pad, OH, OW, CI * k * k, Kp);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(im2col_img_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, img, (f16_t*)out, B, CI, H, W, k, stride, pad, OH, OW, CI * k * k, Kp);
     else hipLaunchKernelGGL(im2col_img_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, img, (bf16_t*)out, B, CI, H, W, k, stride, pad, OH, OW, CI * k * k, Kp);
     EG_LAUNCH_CHECK();
     return 0;
@@ -344,6 +345,7 @@ __global__ void cast_pad_kernel(const float* __restrict__ src, T* __restrict__ d
 extern "C" int eg_cast_pad(int dtype, const float* src, void* dst, int rows, int n, int npad, eg_stream_t s) {
     EG_REQUIRE(src && dst && npad >= n, "eg_cast_pad: bad argument");
     if (dtype == EG_F32) hipLaunchKernelGGL(cast_pad_kernel<float>, dim3(cdiv(rows * npad, 256)), dim3(256), 0, (hipStream_t)s, src, (float*)dst, rows, n, npad);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(cast_pad_kernel<f16_t>, dim3(cdiv(rows * npad, 256)), dim3(256), 0, (hipStream_t)s, src, (f16_t*)dst, rows, n, npad);
     else hipLaunchKernelGGL(cast_pad_kernel<bf16_t>, dim3(cdiv(rows * npad, 256)), dim3(256), 0, (hipStream_t)s, src, (bf16_t*)dst, rows, n, npad);
     EG_LAUNCH_CHECK();
     return 0;
@@ -510,6 +512,7 @@ extern "C" int eg_dense_small_fwd(int dtype, const void* x, const void* wp, cons
                                   float* ws, size_t ws_floats, eg_stream_t s) {
     EG_REQUIRE(x && wp && y && N <= 64 && K % (dtype == EG_F32 ? 4 : 8) == 0, "eg_dense_small_fwd: bad argument (N<=64)");
     if (dtype == EG_F32) launch_dense_small_fwd<float>((const float*)x, (const float*)wp, bias, y, B, K, Kpad, N, nullptr, 0, ws, ws_floats, (hipStream_t)s);
+    else if (dtype == EG_F16) launch_dense_small_fwd<f16_t>((const f16_t*)x, (const f16_t*)wp, bias, y, B, K, Kpad, N, nullptr, 0, ws, ws_floats, (hipStream_t)s);
     else launch_dense_small_fwd<bf16_t>((const bf16_t*)x, (const bf16_t*)wp, bias, y, B, K, Kpad, N, nullptr, 0, ws, ws_floats, (hipStream_t)s);
     EG_LAUNCH_CHECK();
     return 0;
@@ -519,6 +522,7 @@ extern "C" int eg_dense_small_fwd_sn(int dtype, const void* x, const void* wp, c
                                      const float* sigma, int sigma_rows, float* ws, size_t ws_floats, eg_stream_t s) {
     EG_REQUIRE(x && wp && y && sigma && N <= 64 && K % (dtype == EG_F32 ? 4 : 8) == 0, "eg_dense_small_fwd_sn: bad argument (N<=64)");
     if (dtype == EG_F32) launch_dense_small_fwd<float>((const float*)x, (const float*)wp, bias, y, B, K, Kpad, N, sigma, sigma_rows, ws, ws_floats, (hipStream_t)s);
+    else if (dtype == EG_F16) launch_dense_small_fwd<f16_t>((const f16_t*)x, (const f16_t*)wp, bias, y, B, K, Kpad, N, sigma, sigma_rows, ws, ws_floats, (hipStream_t)s);
     else launch_dense_small_fwd<bf16_t>((const bf16_t*)x, (const bf16_t*)wp, bias, y, B, K, Kpad, N, sigma, sigma_rows, ws, ws_floats, (hipStream_t)s);
     EG_LAUNCH_CHECK();
     return 0;
@@ -557,6 +561,7 @@ extern "C" int eg_head_prep_sn(int dtype, const float* dy, int ldy, const float*
                                eg_stream_t s) {
     EG_REQUIRE(dy && y && bias && dys && rows_per_tape > 0 && rows % rows_per_tape == 0 && N <= 64 && col0 + N <= npad, "eg_head_prep_sn: bad argument");
     if (dtype == EG_F32) hipLaunchKernelGGL(head_prep_sn_kernel<float>, dim3(1), dim3(256), 0, (hipStream_t)s, dy, ldy, y, ldyy, bias, rows, N, sigma, rows_per_tape, (float*)dys, npad, col0, gb, coef, dys32, ld32);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(head_prep_sn_kernel<f16_t>, dim3(1), dim3(256), 0, (hipStream_t)s, dy, ldy, y, ldyy, bias, rows, N, sigma, rows_per_tape, (f16_t*)dys, npad, col0, gb, coef, dys32, ld32);
     else hipLaunchKernelGGL(head_prep_sn_kernel<bf16_t>, dim3(1), dim3(256), 0, (hipStream_t)s, dy, ldy, y, ldyy, bias, rows, N, sigma, rows_per_tape, (bf16_t*)dys, npad, col0, gb, coef, dys32, ld32);
     EG_LAUNCH_CHECK();
     return 0;
@@ -566,6 +571,7 @@ extern "C" int eg_dense_small_bwd(int dtype, const float* dy, const void* wp, co
                                   int mask_act, float mask_slope, const float* sigma, int sigma_rows, eg_stream_t s) {
     EG_REQUIRE(dy && wp && dx && N <= 64 && K % (dtype == EG_F32 ? 4 : 8) == 0, "eg_dense_small_bwd: bad argument");
     if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_bwd_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)s, dy, (const float*)wp, (const float*)mask, (float*)dx, K, Kpad, N, mask_act, mask_slope, sigma, sigma_rows);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(dense_small_bwd_kernel<f16_t>, dim3(B), dim3(256), 0, (hipStream_t)s, dy, (const f16_t*)wp, (const f16_t*)mask, (f16_t*)dx, K, Kpad, N, mask_act, mask_slope, sigma, sigma_rows);
     else hipLaunchKernelGGL(dense_small_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)s, dy, (const bf16_t*)wp, (const bf16_t*)mask, (bf16_t*)dx, K, Kpad, N, mask_act, mask_slope, sigma, sigma_rows);
     EG_LAUNCH_CHECK();
     return 0;
@@ -601,6 +607,7 @@ extern "C" int eg_dense_small_wgrad(int dtype, const float* dy, const void* x, f
     EG_REQUIRE(dy && x && gw && N <= 32 && (size_t)B * N * 4 <= 64 * 1024 && Cin * taps == K, "eg_dense_small_wgrad: bad argument (N<=32)");
     const size_t lds = (size_t)B * N * sizeof(float);
     if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_wgrad_kernel<float>, dim3(cdiv(K, 256)), dim3(256), lds, (hipStream_t)s, dy, (const float*)x, gw, B, K, N, Cin, taps);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(dense_small_wgrad_kernel<f16_t>, dim3(cdiv(K, 256)), dim3(256), lds, (hipStream_t)s, dy, (const f16_t*)x, gw, B, K, N, Cin, taps);
     else hipLaunchKernelGGL(dense_small_wgrad_kernel<bf16_t>, dim3(cdiv(K, 256)), dim3(256), lds, (hipStream_t)s, dy, (const bf16_t*)x, gw, B, K, N, Cin, taps);
     if (gb) hipLaunchKernelGGL(dense_small_bgrad_kernel, dim3(1), dim3(512), 0, (hipStream_t)s, dy, gb, B, N);
     EG_LAUNCH_CHECK();

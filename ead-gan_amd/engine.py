@@ -5,7 +5,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
-from .ops import EG_BF16, EG_F32
+from .ops import EG_BF16, EG_F16, EG_F32
 
 
 def parse_dtype(dtype) -> int:
@@ -13,7 +13,9 @@ def parse_dtype(dtype) -> int:
         return EG_F32
     if dtype in (EG_BF16, "bf16", "bfloat16", torch.bfloat16):
         return EG_BF16
-    raise ValueError(f"unsupported compute dtype {dtype!r} (use 'f32' or 'bf16')")
+    if dtype in (EG_F16, "f16", "fp16", "float16", "half", torch.float16):
+        return EG_F16
+    raise ValueError(f"unsupported compute dtype {dtype!r} (use 'f32', 'bf16' or 'f16')")
 
 
 class Arena:

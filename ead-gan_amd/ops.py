@@ -9,15 +9,15 @@ import ctypes
 
 import torch
 
-from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, EG_BF16, EG_F32, OUT_NCHW_F32,
+from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, EG_BF16, EG_F16, EG_F32, OUT_NCHW_F32,
                    OUT_NHWC, EgConv, EgEpilogue, EgSnLayer, lib)
 
-__all__ = ["EG_F32", "EG_BF16", "ACT_NONE", "ACT_LRELU", "ACT_RELU", "ACT_TANH", "ACT_SIGMOID", "OUT_NHWC",
+__all__ = ["EG_F32", "EG_BF16", "EG_F16", "ACT_NONE", "ACT_LRELU", "ACT_RELU", "ACT_TANH", "ACT_SIGMOID", "OUT_NHWC",
            "OUT_NCHW_F32"]
 
 
 def torch_dtype(dtype: int):
-    return torch.float32 if dtype == EG_F32 else torch.bfloat16
+    return {EG_F32: torch.float32, EG_BF16: torch.bfloat16, EG_F16: torch.float16}[dtype]
 
 
 def vec(dtype: int) -> int:
@@ -106,7 +106,7 @@ def _timed(kind, c, dtype, args):
     oh, ow = _out_hw(c)
     M = c.B * oh * ow
     flops = 2.0 * M * c.Cout * c.Cin * c.k * c.k
-    tname = "float" if dtype == EG_F32 else "bf16"
+    tname = {EG_F32: "float", EG_BF16: "bf16", EG_F16: "f16"}[dtype]
     if kind == "tn":
         label = f"igemm_tn_kernel<{tname}>"
     else:

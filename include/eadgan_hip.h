@@ -11,7 +11,7 @@
  *   - every call is an asynchronous enqueue on `stream` (hipStream_t passed as void*), no device sync,
  *     graph-capturable;
  *   - return value: 0 ok, <0 argument error, >0 hipError_t; eg_last_error() gives the text;
- *   - activations are NHWC ("pixel-major") in dtype T (EG_F32 or EG_BF16); images at the module boundary
+ *   - activations are NHWC ("pixel-major") in dtype T (EG_F32, EG_BF16 or EG_F16); images at the module boundary
  *     are NCHW fp32 like the reference's tensors; master weights / gradients / optimizer state are fp32
  *     in the reference's own layouts ([Cout][Cin][kh][kw] for Conv2d, [Cin][Cout][kh][kw] for
  *     ConvTranspose2d);
@@ -27,7 +27,7 @@ extern "C" {
 
 typedef void* eg_stream_t;
 
-enum { EG_F32 = 0, EG_BF16 = 1 };
+enum { EG_F32 = 0, EG_BF16 = 1, EG_F16 = 2 };   /* compute / activation dtype T; masters, statistics, losses and Adam are always fp32 */
 enum { EG_ACT_NONE = 0, EG_ACT_LRELU = 1, EG_ACT_RELU = 2, EG_ACT_TANH = 3, EG_ACT_SIGMOID = 4 };
 enum { EG_OUT_NHWC = 0, EG_OUT_NCHW_F32 = 1 };
 

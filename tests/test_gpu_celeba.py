@@ -362,3 +362,11 @@ def test_long_free_run_stays_on_the_reference_regime():
     for col, k in ((0, "g_loss"), (1, "d_loss")):
         m = ma(got[:, col])
         assert m.min() > 0.25 * ma(gold[k]).min() and m.max() < 4.0 * ma(gold[k]).max(), (k, m.min(), m.max())
+
+
+def test_train_step_fp16_tracks_oracle():
+    """third compute dtype (EG_F16): CelebA step in IEEE half operands, same bound as the bf16 mode"""
+    orc, G, D, tr, got, want = run_steps("f16", 8, 2)
+    for i in range(2):
+        for k in ("g_loss", "d_loss", "info_loss"):
+            assert abs(got[i][k] - want[i][k]) < 3e-2 * max(1.0, abs(want[i][k])), (i, k, got[i][k], want[i][k])

@@ -97,3 +97,13 @@ def test_train_step_bf16_tracks_oracle():
     for i in range(2):
         for k in NAMES:
             assert abs(got[i][k] - want[i][k]) < 5e-2 * max(1.0, abs(want[i][k])), (i, k, got[i][k], want[i][k])
+
+
+def test_train_step_fp16_tracks_oracle():
+    """BASELINE.json configs[4] names fp16 for this workload: IEEE half operands on the same 16-bit MFMA path (fp32 accumulate,
+    fp32 masters / statistics / losses / Adam, like the bf16 mode).  No loss scaling, as the reference has none: gradients below
+    half's 6e-5 normal range lose bits, so bf16 remains the recommended 16-bit mode; over these first steps both track the oracle."""
+    orc, G, D, E, tr, got, want = run_steps("f16", 16, 2)
+    for i in range(2):
+        for k in NAMES:
+            assert abs(got[i][k] - want[i][k]) < 5e-2 * max(1.0, abs(want[i][k])), (i, k, got[i][k], want[i][k])

@@ -22,7 +22,7 @@ def setup_module(module):
 
 
 DEV = "cuda"
-DTYPES = [0, 1]
+DTYPES = [0, 1, 2]      # EG_F32, EG_BF16, EG_F16
 
 
 def tol(dtype, K):
@@ -40,7 +40,7 @@ def nchw(y):
 
 def rq(x, dtype):
     """round a CPU fp32 tensor through the compute dtype (what the kernel sees)"""
-    return x if dtype == 0 else x.to(torch.bfloat16).float()
+    return x if dtype == 0 else x.to(torch.bfloat16 if dtype == 1 else torch.float16).float()
 
 
 CONV_CASES = [
