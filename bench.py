@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--force-dist", action="store_true", help="initialise a process group and run the all-reduce hooks even with one rank "
                                                               "(rehearses the N>1 code path, incl. RCCL capture into the hipGraph, on one GPU)")
+    ap.add_argument("--sync-bn", action="store_true", help="data parallel: BatchNorm statistics over the global batch (dp.SyncBN); default per-rank")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no side lanes for weight-gradient chains / re-packing")
     ap.add_argument("--igemm-tuning", default="", help="buf_min_tiles,splitk_target,big_min_tiles,persistent,wide_min_tiles for eg_set_igemm_tuning (experiments)")
     ap.add_argument("--igemm-dma", type=int, default=4, help="LDS-DMA staged NT kernel variant for large launches (0 off, 1 = 256x128x3, 2 = 128x128x2, 3 = 128x128x3, 4 = buffer-descriptor 128x128x2 [default])")
@@ -235,7 +236,8 @@ def main():
     G = eg.celeba.Generator(dtype=a.dtype).to(dev)
     D = eg.celeba.Discriminator(dtype=a.dtype).to(dev)
     allreduce = eg.dp.GradAllReduce(world, force=a.force_dist) if (world > 1 or a.force_dist) else None
-    tr = eg.celeba.CelebATrainer(G, D, B, dtype=a.dtype, allreduce=allreduce, overlap=not a.no_overlap)
+    sync = eg.dp.SyncBN(world, rank) if (a.sync_bn and world > 1) else None
+    tr = eg.celeba.CelebATrainer(G, D, B, dtype=a.dtype, allreduce=allreduce, overlap=not a.no_overlap, sync_bn=sync)
 
     # synthetic inputs resident in HBM before the timed region: per-rank shard of the global batch
     g = torch.Generator(device=dev).manual_seed(1000 + rank)

@@ -75,6 +75,8 @@ class _GenEngine:
         self.a = [torch.empty_like(t) for t in self.z]
         self.mean = [e(W[i + 1], dt=torch.float32) for i in range(3)]
         self.invstd = [e(W[i + 1], dt=torch.float32) for i in range(3)]
+        self.bn_stats = [e(3 * W[i + 1], dt=torch.float32) for i in range(3)]      # synchronised BatchNorm: local (n, mean, M2) / local sums
+        self.bn_sums = [e(2 * W[i + 1], dt=torch.float32) for i in range(3)]
         self.img = e(B, gen.channels, s * 16, s * 16, dt=torch.float32)
         # gradient scratch (ping-pong between layers)
         self.dimg_z = torch.empty_like(self.img)
@@ -99,8 +101,9 @@ class _GenEngine:
         self.l4.pack(self._p(10, "weight"))
         ops.pack_strided(dt, self._p(10, "weight"), self.l4p.wp_fwd, G_WIDTHS[3], self.kp, self.l4p.Kpad_fwd, 1, self.kp, 0, 1)
 
-    def forward(self, noise, labels, code, training=True):
-        """``training=False``: BatchNorm with the running statistics, nothing updated (module.eval())."""
+    def forward(self, noise, labels, code, training=True, sync=None):
+        """``training=False``: BatchNorm with the running statistics, nothing updated (module.eval()).  ``sync`` (a dp.SyncBN):
+        batch statistics over all ranks (synchronised BatchNorm)."""
         dt, B, W = self.dtype, self.B, G_WIDTHS
         ops.concat_cast(dt, noise, labels, code, self.inp, B, self.cpad)
         ops.conv_fwd(self.l0.c, dt, self.inp, self.l0.wp_fwd, self.h0, ops.epilogue(bias=self._p(0, "bias"), bias_mod=W[0]))
@@ -110,7 +113,12 @@ class _GenEngine:
             ops.conv_bwd_data(r.c, dt, x, r.wp_bwd, self.z[i], ops.epilogue(bias=self._p(idx, "bias")))
             bn = self.gen.conv_blocks[idx + 1]
             M = self.z[i].numel() // W[i + 1]
-            if training:
+            if training and sync is not None:
+                ops.bn_stats_local(dt, self.z[i], M, W[i + 1], self.ws.small, self.bn_stats[i])
+                allst = sync.gather_stats(self.bn_stats[i])
+                ops.bn_fwd_from_stats(dt, self.z[i], self.a[i], M, W[i + 1], allst, sync.world, M * sync.world, bn.weight, bn.bias, bn.eps, bn.momentum,
+                                      bn.running_mean, bn.running_var, bn.num_batches_tracked, self.mean[i], self.invstd[i], self.ws.small, ACT_RELU)
+            elif training:
                 ops.bn_fwd_train(dt, self.z[i], self.a[i], M, W[i + 1], bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean,
                                  bn.running_var, bn.num_batches_tracked, self.mean[i], self.invstd[i], self.ws.small, ACT_RELU)
             else:
@@ -120,8 +128,8 @@ class _GenEngine:
                           ops.epilogue(bias=self._p(10, "bias"), act=ACT_TANH, out_mode=OUT_NCHW_F32))
         return self.img
 
-    def backward(self, dimg, grad, side=None):
-        """Accumulates d(loss)/d(params) into the flat gradient tensor ``grad`` (arena layout).  With ``side`` (an
+    def backward(self, dimg, grad, side=None, sync=None):
+        """Accumulates d(loss)/d(params) into the flat gradient tensor ``grad`` (arena layout).  ``sync``: as in forward.  With ``side`` (an
         engine.SideStream) the weight/bias-gradient work of every layer is enqueued there, behind a fork taken right after
         the layer's output gradient exists; the caller joins before it reads ``grad``."""
         dt, B, W, ws, gen = self.dtype, self.B, G_WIDTHS, self.ws, self.gen
@@ -150,8 +158,15 @@ class _GenEngine:
             r = self.mid[i]
             bn = gen.conv_blocks[idx + 1]
             M = self.z[i].numel() // W[i + 1]
-            ops.bn_bwd(dt, self.z[i], self.da[i], self.dz[i], M, W[i + 1], bn.weight, bn.bias, self.mean[i], self.invstd[i], ACT_RELU, 0.0,
-                       gof(f"conv_blocks.{idx + 1}.weight"), gof(f"conv_blocks.{idx + 1}.bias"), ws.sums, ws.small)
+            if sync is not None:
+                ops.bn_bwd_sums_local(dt, self.z[i], self.da[i], M, W[i + 1], bn.weight, bn.bias, self.mean[i], self.invstd[i], ACT_RELU, 0.0,
+                                      gof(f"conv_blocks.{idx + 1}.weight"), gof(f"conv_blocks.{idx + 1}.bias"), self.bn_sums[i], ws.small)
+                sync.reduce_sums(self.bn_sums[i])
+                ops.bn_bwd_from_sums(dt, self.z[i], self.da[i], self.dz[i], M, W[i + 1], self.bn_sums[i], M * sync.world, bn.weight, bn.bias,
+                                     self.mean[i], self.invstd[i], ACT_RELU, 0.0, ws.small)
+            else:
+                ops.bn_bwd(dt, self.z[i], self.da[i], self.dz[i], M, W[i + 1], bn.weight, bn.bias, self.mean[i], self.invstd[i], ACT_RELU, 0.0,
+                           gof(f"conv_blocks.{idx + 1}.weight"), gof(f"conv_blocks.{idx + 1}.bias"), ws.sums, ws.small)
             x_in = self.a[i - 1] if i > 0 else self.h0
 
             def mid_wgrad(wsw, i=i, idx=idx, r=r, M=M, x_in=x_in):
@@ -579,7 +594,8 @@ class CelebATrainer:
     ``allreduce``: optional callable(flat_grad_tensor) applied after each backward pass (data parallel)."""
 
     def __init__(self, generator: Generator, discriminator: Discriminator, batch_size: int, dtype="bf16", allreduce=None,
-                 lr_g=1e-3, lr_d=2e-4, lr_info=2e-4, betas=(0.5, 0.999), lambda_cat=1.0, lambda_con=1.0, lambda_affine=1.0, overlap=True):
+                 lr_g=1e-3, lr_d=2e-4, lr_info=2e-4, betas=(0.5, 0.999), lambda_cat=1.0, lambda_con=1.0, lambda_affine=1.0, overlap=True,
+                 sync_bn=None):
         self.G, self.D, self.B = generator, discriminator, batch_size
         dt = parse_dtype(dtype)
         generator.set_compute_dtype(dt)
@@ -588,6 +604,9 @@ class CelebATrainer:
         dev = generator.arena.flat.device
         self.dev = dev
         self.allreduce = allreduce
+        # optional dp.SyncBN: the generator's BatchNorm statistics over the global batch (N ranks == 1 rank at equal global batch);
+        # default (None): per-rank statistics, like torch DistributedDataParallel without SyncBatchNorm
+        self.sync_bn = sync_bn
         self.lr = (lr_g, lr_d, lr_info)
         self.betas = betas
         self.lam = (lambda_cat, lambda_con, lambda_affine)
@@ -658,14 +677,14 @@ class CelebATrainer:
 
         # ---- 1) generator adversarial step (:334-345); D(gen) lives in tape slot 2 so that step 2's tapes can be prepared meanwhile ----
         ops.fill_f32(ga.grad)
-        gen = ge.forward(self.z, self.onehot, self.code)
+        gen = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
         out = de.forward([gen], 2)
         # step 2's power iterations (they follow step 1's in the u/v chain) and patch rows, beside the rest of step 1
         if prep:
             on_side(lambda: de.prepare(0, [self.scaled, gen]), 1)
         ops.loss_bce_sigmoid(out, 19, 0, B, 1.0, 1.0, self.losses[0:1], self.dout[2 * B:])
         dimg = de.backward(2, 1, self.dout[2 * B:], da.grad, need_wgrad=False, need_dimg=True)
-        ge.backward(dimg, ga.grad, side)
+        ge.backward(dimg, ga.grad, side, sync=self.sync_bn)
         join()
         pend_g = ar_start(ga.grad)
 
@@ -700,7 +719,7 @@ class CelebATrainer:
         ops.fill_f32(ga.grad)
         if ar_async:
             join()                                      # G's panels were re-packed a moment ago (update_g)
-        gen = ge.forward(self.z, self.onehot, self.code)
+        gen = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
         if ar_async:
             update_d()
         join()
@@ -714,7 +733,7 @@ class CelebATrainer:
         if ar_async:
             join()                                      # D's weight gradients are complete
             pend = ar_start(da.grad)
-        ge.backward(dimg, ga.grad, side)                # beside D's weight-gradient chains / the D-gradient all-reduce
+        ge.backward(dimg, ga.grad, side, sync=self.sync_bn)     # beside D's weight-gradient chains / the D-gradient all-reduce
         join()
         if ar is not None:
             ar(ga.grad)

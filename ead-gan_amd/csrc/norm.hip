@@ -167,6 +167,82 @@ extern "C" int eg_bn_fwd_train(int dtype, const void* x, void* y, int M, int C, 
     return 0;
 }
 
+// ---- synchronised BatchNorm (data parallel: statistics over the GLOBAL batch) ---------------------------------------
+// forward:  eg_bn_stats_local -> (n, mean, M2) per channel of this rank's rows; the host layer gathers the 3*C floats of every rank
+//           (slot-wise all-reduce); eg_bn_fwd_from_stats combines them with Chan's formula (same kernel as the single-rank path, the
+//           "row blocks" now being ranks) and normalises the local rows.
+// backward: eg_bn_bwd_sums_local -> local sum(dy), sum(dy*xhat) (added to dbeta / dgamma: parameter gradients stay per-rank, the
+//           gradient all-reduce averages them); the host all-reduces the 2*C sums; eg_bn_bwd_from_sums applies dz with M_global.
+__global__ void bn_stats_local_kernel(const float* __restrict__ partial, int nrb, int C, float* __restrict__ stats) {
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int r = lane; r < nrb; r += 64) {
+        const float* o = partial + (size_t)r * 3 * C;
+        const double nb = o[c], mb = o[C + c], qb = o[2 * C + c];
+        const double tot = n + nb, delta = mb - mean;
+        mean += delta * nb / tot;
+        m2 += qb + delta * delta * n * nb / tot;
+        n = tot;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double n2 = __shfl_xor(n, o, 64), mean2 = __shfl_xor(mean, o, 64), m22 = __shfl_xor(m2, o, 64);
+        const double tot = n + n2;
+        if (tot > 0.0) {
+            const double delta = mean2 - mean;
+            const double nm = mean + delta * n2 / tot;
+            m2 = m2 + m22 + delta * delta * n * n2 / tot;
+            mean = nm;
+            n = tot;
+        }
+    }
+    if (lane != 0) return;
+    stats[c] = (float)n;
+    stats[C + c] = (float)mean;
+    stats[2 * C + c] = (float)m2;
+}
+
+template <typename T>
+static void launch_bn_stats_partial(const void* x, int M, int C, int dtype, float* ws, int* nrb_out, hipStream_t st) {
+    const int gx = bn_gx(C, dtype), rpb = bn_rpb(M, gx);
+    *nrb_out = cdiv(M, rpb);
+    hipLaunchKernelGGL(bn_stats_partial_kernel<T>, dim3(gx, *nrb_out), dim3(256), 0, st, (const T*)x, M, C, rpb, ws);
+}
+
+extern "C" int eg_bn_stats_local(int dtype, const void* x, int M, int C, float* ws, float* stats, eg_stream_t s) {
+    EG_REQUIRE(x && ws && stats && M > 0 && C > 0 && C % (dtype == EG_F32 ? 4 : 8) == 0, "eg_bn_stats_local: bad argument");
+    int nrb = 0;
+    hipStream_t st = (hipStream_t)s;
+    if (dtype == EG_F32) launch_bn_stats_partial<float>(x, M, C, dtype, ws, &nrb, st);
+    else if (dtype == EG_F16) launch_bn_stats_partial<f16_t>(x, M, C, dtype, ws, &nrb, st);
+    else launch_bn_stats_partial<bf16_t>(x, M, C, dtype, ws, &nrb, st);
+    hipLaunchKernelGGL(bn_stats_local_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, ws, nrb, C, stats);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int eg_bn_fwd_from_stats(int dtype, const void* x, void* y, int M_local, int C, const float* stats_all, int nranks, int M_global,
+                                    const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                    long long* num_batches_tracked, float* save_mean, float* save_invstd, float* ws, int act, float slope,
+                                    eg_stream_t s) {
+    EG_REQUIRE(x && y && stats_all && gamma && beta && save_mean && save_invstd && ws && M_local > 0 && M_global >= M_local && nranks > 0,
+               "eg_bn_fwd_from_stats: bad argument");
+    EG_REQUIRE(C % (dtype == EG_F32 ? 4 : 8) == 0, "eg_bn_fwd_from_stats: C must be a multiple of the 16-byte vector width");
+    hipStream_t st = (hipStream_t)s;
+    float* coef = ws;                                   // 2*C floats
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, stats_all, nranks, C, M_global, eps, momentum, running_mean, running_var,
+                       num_batches_tracked, save_mean, save_invstd, gamma, beta, coef);
+    const int cpr = C / (dtype == EG_F32 ? 4 : 8);
+    const int blocks = bn_apply_blocks((size_t)M_local, cpr);
+    if (dtype == EG_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, (size_t)M_local, C, coef, act, slope);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(bn_apply_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, (size_t)M_local, C, coef, act, slope);
+    else hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (size_t)M_local, C, coef, act, slope);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- eval-mode forward (running statistics; generate_image.py / gen_imgs.py of the reference put the generator in .eval()) ------
 __global__ void bn_eval_coef_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
                                     const float* __restrict__ rv, float eps, int C, float* __restrict__ coef) {
@@ -330,6 +406,55 @@ static int bn_bwd_impl(int dtype, const void* z, const void* da, void* dz, int M
     if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)z, (const float*)da, (float*)dz, (size_t)M, C, coef, act, slope, post_act, post_slope, post_sigma);
     else if (dtype == EG_F16) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, (const f16_t*)z, (const f16_t*)da, (f16_t*)dz, (size_t)M, C, coef, act, slope, post_act, post_slope, post_sigma);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)da, (bf16_t*)dz, (size_t)M, C, coef, act, slope, post_act, post_slope, post_sigma);
+    return 0;
+}
+
+// synchronised backward, stage 1: this rank's sums (also added to dbeta / dgamma), no dz yet
+extern "C" int eg_bn_bwd_sums_local(int dtype, const void* z, const void* da, int M, int C, const float* gamma, const float* beta,
+                                    const float* save_mean, const float* save_invstd, int act, float slope, float* dgamma, float* dbeta,
+                                    float* sums, float* ws, eg_stream_t s) {
+    EG_REQUIRE(z && da && gamma && beta && save_mean && save_invstd && sums && ws && M > 0 && C > 0, "eg_bn_bwd_sums_local: bad argument");
+    hipStream_t st = (hipStream_t)s;
+    const int gx = bn_gx(C, dtype), rpb = bn_rpb(M, gx);
+    const int nrb = cdiv(M, rpb);
+    dim3 g1(gx, nrb);
+    if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_partial_kernel<float>, g1, dim3(256), 0, st, (const float*)z, (const float*)da, M, C, rpb, gamma, beta, save_mean, save_invstd, act, slope, ws);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(bn_bwd_partial_kernel<f16_t>, g1, dim3(256), 0, st, (const f16_t*)z, (const f16_t*)da, M, C, rpb, gamma, beta, save_mean, save_invstd, act, slope, ws);
+    else hipLaunchKernelGGL(bn_bwd_partial_kernel<bf16_t>, g1, dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)da, M, C, rpb, gamma, beta, save_mean, save_invstd, act, slope, ws);
+    float* coef = ws + (size_t)nrb * 3 * C;             // written but unused here (local M): stage 2 recomputes it from the global sums
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, ws, nrb, C, sums, dgamma, dbeta, gamma, beta, save_mean, save_invstd, M, coef);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void bn_bwd_coef_kernel(const float* __restrict__ sums, int C, int M, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   const float* __restrict__ mean, const float* __restrict__ invstd, float* __restrict__ coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s1 = sums[c], s2 = sums[C + c];
+    const float g = gamma[c], is = invstd[c], mu = mean[c], invM = 1.f / (float)M;
+    coef[c] = g * is;
+    coef[C + c] = g * is * is * s2 * invM;
+    coef[2 * C + c] = g * is * (s1 * invM - mu * is * s2 * invM);
+    coef[3 * C + c] = g * is;
+    coef[4 * C + c] = beta[c] - mu * g * is;
+}
+
+// stage 2: dz of the local rows from the GLOBAL sums (after the host's all-reduce) and the global row count
+extern "C" int eg_bn_bwd_from_sums(int dtype, const void* z, const void* da, void* dz, int M_local, int C, const float* sums_global, int M_global,
+                                   const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, int act, float slope,
+                                   float* ws, eg_stream_t s) {
+    EG_REQUIRE(z && da && dz && sums_global && gamma && beta && save_mean && save_invstd && ws && M_local > 0 && M_global >= M_local,
+               "eg_bn_bwd_from_sums: bad argument");
+    hipStream_t st = (hipStream_t)s;
+    float* coef = ws;                                   // 5*C floats
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, sums_global, C, M_global, gamma, beta, save_mean, save_invstd, coef);
+    const int cpr = C / (dtype == EG_F32 ? 4 : 8);
+    const int blocks = bn_apply_blocks((size_t)M_local, cpr);
+    if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)z, (const float*)da, (float*)dz, (size_t)M_local, C, coef, act, slope, EG_ACT_NONE, 0.f, (const float*)nullptr);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, (const f16_t*)z, (const f16_t*)da, (f16_t*)dz, (size_t)M_local, C, coef, act, slope, EG_ACT_NONE, 0.f, (const float*)nullptr);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)da, (bf16_t*)dz, (size_t)M_local, C, coef, act, slope, EG_ACT_NONE, 0.f, (const float*)nullptr);
+    EG_LAUNCH_CHECK();
     return 0;
 }
 

@@ -67,6 +67,35 @@ class GradAllReduce:
             flat.mul_(1.0 / self.world)
 
 
+class SyncBN:
+    """Collectives of synchronised BatchNorm (statistics over the global batch, so that N ranks x B/N images reproduce one rank
+    x B images): per BatchNorm layer one exchange of 3*C floats in the forward and 2*C floats in the backward.  The gather is a
+    slot-wise all-reduce (every rank writes its block into a zeroed [world][3*C] buffer): works on RCCL and gloo alike and is
+    capturable into the step's hipGraph."""
+
+    def __init__(self, world: int, rank: int, group=None):
+        self.world, self.rank, self.group = world, rank, group
+        self._buf = {}
+
+    def gather_stats(self, stats: torch.Tensor) -> torch.Tensor:
+        """stats: [3*C] of this rank -> [world, 3*C] of all ranks"""
+        n = stats.numel()
+        buf = self._buf.get((n, stats.device))
+        if buf is None:
+            buf = self._buf[(n, stats.device)] = torch.zeros(self.world, n, device=stats.device, dtype=torch.float32)
+        buf.zero_()
+        buf[self.rank].copy_(stats)
+        if self.world > 1:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        return buf
+
+    def reduce_sums(self, sums: torch.Tensor) -> torch.Tensor:
+        """in-place sum over ranks of the [2*C] backward sums"""
+        if self.world > 1:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+        return sums
+
+
 def barrier():
     if dist.is_initialized():
         dist.barrier()

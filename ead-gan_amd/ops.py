@@ -274,6 +274,27 @@ def bn_fwd_eval(dtype, x, y, M, C, gamma, beta, eps, running_mean, running_var, 
                act, float(slope), _stream())
 
 
+def bn_stats_local(dtype, x, M, C, ws, stats):
+    lib().call("eg_bn_stats_local", dtype, _p(x), M, C, _p(ws), _p(stats), _stream())
+
+
+def bn_fwd_from_stats(dtype, x, y, M_local, C, stats_all, nranks, M_global, gamma, beta, eps, momentum, rmean, rvar, nbt, save_mean, save_invstd, ws,
+                      act=ACT_NONE, slope=0.0):
+    lib().call("eg_bn_fwd_from_stats", dtype, _p(x), _p(y), M_local, C, _p(stats_all), nranks, M_global, _p(gamma), _p(beta), float(eps),
+               float(momentum if momentum is not None else 0.1), _p(rmean), _p(rvar), _p(nbt), _p(save_mean), _p(save_invstd), _p(ws), act, float(slope),
+               _stream())
+
+
+def bn_bwd_sums_local(dtype, z, da, M, C, gamma, beta, save_mean, save_invstd, act, slope, dgamma, dbeta, sums, ws):
+    lib().call("eg_bn_bwd_sums_local", dtype, _p(z), _p(da), M, C, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd), act, float(slope),
+               _p(dgamma), _p(dbeta), _p(sums), _p(ws), _stream())
+
+
+def bn_bwd_from_sums(dtype, z, da, dz, M_local, C, sums_global, M_global, gamma, beta, save_mean, save_invstd, act, slope, ws):
+    lib().call("eg_bn_bwd_from_sums", dtype, _p(z), _p(da), _p(dz), M_local, C, _p(sums_global), M_global, _p(gamma), _p(beta), _p(save_mean),
+               _p(save_invstd), act, float(slope), _p(ws), _stream())
+
+
 def bn_fwd_train(dtype, x, y, M, C, gamma, beta, eps, momentum, rmean, rvar, nbt, save_mean, save_invstd, ws, act=ACT_NONE, slope=0.0):
     lib().call("eg_bn_fwd_train", dtype, _p(x), _p(y), M, C, _p(gamma), _p(beta), eps, momentum, _p(rmean), _p(rvar), _p(nbt),
                _p(save_mean), _p(save_invstd), _p(ws), act, slope, _stream())

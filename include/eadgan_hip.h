@@ -195,6 +195,23 @@ size_t eg_bn_ws_floats(int M, int C);
 int eg_bn_fwd_train(int dtype, const void* x, void* y, int M, int C, const float* gamma, const float* beta, float eps,
                     float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
                     float* save_mean, float* save_invstd, float* ws, int act, float slope, eg_stream_t s);
+/* synchronised BatchNorm for data parallel runs (statistics over the global batch: N ranks x B/N images == 1 rank x B images).
+ * Forward: eg_bn_stats_local writes this rank's (count, mean, M2) per channel to stats[3*C]; the host gathers every rank's block
+ * (stats_all[nranks][3*C]); eg_bn_fwd_from_stats combines them (Chan, fp64), updates the running statistics with the GLOBAL
+ * batch (M_global rows) and normalises the local rows.  Backward: eg_bn_bwd_sums_local writes the local sum(dy), sum(dy*xhat)
+ * to sums[2*C] and adds them to dbeta / dgamma (parameter gradients stay local; the gradient all-reduce averages them); the host
+ * all-reduces sums; eg_bn_bwd_from_sums produces dz of the local rows.  ws: eg_bn_ws_floats(M, C) floats. */
+int eg_bn_stats_local(int dtype, const void* x, int M, int C, float* ws, float* stats, eg_stream_t s);
+int eg_bn_fwd_from_stats(int dtype, const void* x, void* y, int M_local, int C, const float* stats_all, int nranks, int M_global,
+                         const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                         long long* num_batches_tracked, float* save_mean, float* save_invstd, float* ws, int act, float slope,
+                         eg_stream_t s);
+int eg_bn_bwd_sums_local(int dtype, const void* z, const void* da, int M, int C, const float* gamma, const float* beta,
+                         const float* save_mean, const float* save_invstd, int act, float slope, float* dgamma, float* dbeta,
+                         float* sums, float* ws, eg_stream_t s);
+int eg_bn_bwd_from_sums(int dtype, const void* z, const void* da, void* dz, int M_local, int C, const float* sums_global, int M_global,
+                        const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, int act, float slope,
+                        float* ws, eg_stream_t s);
 /* eval mode (module.eval(): generate_image.py:146-154, gen_imgs.py:106-120 of the reference): y = act((x - running_mean) /
  * sqrt(running_var + eps) * gamma + beta); nothing is updated; ws: 2*C floats */
 int eg_bn_fwd_eval(int dtype, const void* x, void* y, int M, int C, const float* gamma, const float* beta, float eps,

@@ -26,7 +26,12 @@ def run_single_shard(_, shard, nshards, outdir, B_global):
     run_rank(shard, 1, 0, outdir, B_global, False, nshards=nshards)
 
 
-def run_rank(rank, world, port, outdir, B_global, overlap, nshards=None):
+def run_whole_batch(_, outdir, B_global):
+    """the global batch on one rank (reference for synchronised BatchNorm)"""
+    run_rank(0, 1, 0, outdir, B_global, False, nshards=1)
+
+
+def run_rank(rank, world, port, outdir, B_global, overlap, nshards=None, sync_bn=False):
     from oracle import celeba_oracle as co          # seeded initial weights + synthetic batch (test infrastructure)
     eg = importlib.import_module("ead-gan_amd")
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
@@ -41,12 +46,14 @@ def run_rank(rank, world, port, outdir, B_global, overlap, nshards=None):
     ar = eg.dp.GradAllReduce(world) if world > 1 else None
     nshards = nshards or world
     b = B_global // nshards
-    tr = eg.celeba.CelebATrainer(G, D, b, dtype="f32", allreduce=ar, lr_g=0.0, lr_d=0.0, lr_info=0.0, overlap=overlap)
+    sync = eg.dp.SyncBN(world, rank) if (sync_bn and world > 1) else None
+    tr = eg.celeba.CelebATrainer(G, D, b, dtype="f32", allreduce=ar, lr_g=0.0, lr_d=0.0, lr_info=0.0, overlap=overlap, sync_bn=sync)
     real, z, code, labels = shard_inputs(co, B_global, rank, nshards)
     losses = tr.train_step(real.cuda(), z.cuda(), code.cuda(), labels.cuda())
     torch.cuda.synchronize()
     out = {"losses": torch.tensor([losses["g_loss"], losses["d_loss"], losses["info_loss"]]),
-           "g": G.arena.grad.detach().cpu().clone(), "d": D.arena.grad.detach().cpu().clone()}
+           "g": G.arena.grad.detach().cpu().clone(), "d": D.arena.grad.detach().cpu().clone(),
+           "rm": G.state_dict()["conv_blocks.2.running_mean"].detach().cpu().clone(), "rv": G.state_dict()["conv_blocks.8.running_var"].detach().cpu().clone()}
     torch.save(out, os.path.join(outdir, f"rank{rank}_of{world}.pt"))        # plain tensors: loaded back with weights_only=True
     if world > 1:
         torch.distributed.barrier()

@@ -40,3 +40,26 @@ def test_two_ranks_average_the_shard_gradients(overlap):
         assert err < 1e-6, (key, err)
     # every rank reports the loss of ITS shard
     assert torch.allclose(r0["losses"], single[0]["losses"], atol=1e-6) and torch.allclose(r1["losses"], single[1]["losses"], atol=1e-6)
+
+
+def test_sync_batchnorm_two_ranks_equal_one_rank_at_the_same_global_batch():
+    """with synchronised BatchNorm (dp.SyncBN: 3*C floats per layer forward, 2*C backward) two ranks x 4 images
+    reproduce one rank x 8 images: the mean of the rank losses is the global loss, the all-reduced gradients are the global-batch
+    gradients, and the BatchNorm running statistics are those of the global batch.  (Gradient bound 2e-2 like the single-rank
+    full-step test: a LeakyReLU unit within rounding of 0 may flip between the two summation orders.)"""
+    B = 8
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(dp_worker.run_rank, args=(2, 29541, d, B, True, None, True), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "rank0_of2.pt"), weights_only=True)
+        r1 = torch.load(os.path.join(d, "rank1_of2.pt"), weights_only=True)
+        one = os.path.join(d, "one")
+        os.makedirs(one)
+        mp.spawn(dp_worker.run_whole_batch, args=(one, B), nprocs=1, join=True)
+        w = torch.load(os.path.join(one, "rank0_of1.pt"), weights_only=True)
+    assert torch.equal(r0["g"], r1["g"]) and torch.equal(r0["d"], r1["d"])
+    assert torch.allclose((r0["losses"] + r1["losses"]) * 0.5, w["losses"], atol=2e-5), (r0["losses"], r1["losses"], w["losses"])
+    for key in ("g", "d"):
+        err = float((r0[key] - w[key]).norm() / w[key].norm())
+        assert err < 2e-2, (key, err)
+    for key in ("rm", "rv"):
+        assert torch.allclose(r0[key], w[key], rtol=1e-4, atol=1e-6) and torch.equal(r0[key], r1[key]), key
