@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--force-dist", action="store_true", help="initialise a process group and run the all-reduce hooks even with one rank "
                                                               "(rehearses the N>1 code path, incl. RCCL capture into the hipGraph, on one GPU)")
+    ap.add_argument("--device-inputs", action="store_true", help="draw every batch on the device inside the captured step (uint8 dataset in HBM + "
+                    "counter-based z / code / labels): the timed iteration then includes the whole input pipeline")
     ap.add_argument("--sync-bn", action="store_true", help="data parallel: BatchNorm statistics over the global batch (dp.SyncBN); default per-rank")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no side lanes for weight-gradient chains / re-packing")
     ap.add_argument("--igemm-tuning", default="", help="buf_min_tiles,splitk_target,big_min_tiles,persistent,wide_min_tiles for eg_set_igemm_tuning (experiments)")
@@ -247,11 +249,15 @@ def main():
     labels = torch.randint(0, 10, (B,), device=dev, generator=g)
     tr.load_inputs(real, z, code, labels)
 
+    inputs = None
+    if a.device_inputs:                                  # synthetic uint8 "dataset" resident in HBM (16k images = 197 MB)
+        inputs = eg.celeba.DeviceInputs(torch.randint(0, 256, (16384, 3, 64, 64), device=dev, dtype=torch.uint8, generator=g), seed=1000 + rank)
+        tr.inputs = inputs
     use_graph = not a.no_graph                           # RCCL collectives are captured into the same hipGraph
     tr.step_resident()                                   # first eager iteration: loads kernels, sizes workspaces (and RCCL channels)
     if use_graph:
         try:
-            tr.capture()
+            tr.capture(inputs=inputs)
         except Exception as exc:                         # e.g. a collective that refuses capture: keep going with eager launches
             print(f"[bench] hipGraph capture failed on rank {rank} ({type(exc).__name__}: {exc}); falling back to eager launches", file=sys.stderr)
             tr.graph = None
@@ -284,7 +290,7 @@ def main():
             "metric": "imgs/sec per G+D+E train step, CelebA 64x64 bs=128",
             "value": round(ips, 1), "unit": "imgs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": a.dtype, "data": "synthetic",
+            "dtype": a.dtype, "data": "synthetic" + (" (drawn on the device inside the timed step)" if a.device_inputs else ""),
             "config": {"workload": f"EAD-GAN CelebA 64x64x3 full train iteration (G adv + D + info/affine, 3 Adams), batch {B}/GPU, "
                                    f"{'hipGraph replay' if use_graph else 'eager launches'}, data-parallel x{world}",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},

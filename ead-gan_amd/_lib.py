@@ -37,7 +37,8 @@ class EgSnLayer(ctypes.Structure):
 
 
 _SCALARS = {"int": ctypes.c_int, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
-            "long long": ctypes.c_longlong, "eg_stream_t": ctypes.c_void_p}
+            "long long": ctypes.c_longlong, "unsigned long long": ctypes.c_ulonglong, "unsigned int": ctypes.c_uint,
+            "eg_stream_t": ctypes.c_void_p}
 
 
 def _ctype_of(decl: str):

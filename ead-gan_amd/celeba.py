@@ -585,6 +585,41 @@ def affine_regularzier(real_code, trans_code):
 # ================================================================================================
 # fused train-loop entry
 # ================================================================================================
+class DeviceInputs:
+    """Device-side replacement of the loop's host input work (celebA/EAD-GAN_celebA.py:194-206 DataLoader + RandomHorizontalFlip +
+    ToTensor + Normalize(0.5, 0.5); :308-317 numpy draws of z ~ N(0,1), code ~ U(-1,1), labels ~ randint): a uint8 [N,3,64,64] dataset
+    resident in HBM (resized / cropped once on the way in) and a counter-based generator.  ``enqueue(trainer)`` fills the trainer's
+    static input slots with six launches and ticks the device step counter; inside ``trainer.capture(inputs=...)`` they become part
+    of the iteration's hipGraph, so a replay needs no host work at all.  Draws are reproducible per (seed, step) and have the
+    reference's distributions; they are NOT numpy's stream (parity tests keep using ``load_inputs`` with host draws)."""
+
+    def __init__(self, dataset_u8: torch.Tensor, seed: int = 0, flip: bool = True):
+        _require_cuda(dataset_u8)
+        if dataset_u8.dtype != torch.uint8 or dataset_u8.dim() != 4:
+            raise ValueError("dataset must be a uint8 [N, C, H, W] device tensor")
+        self.data = dataset_u8.contiguous()
+        self.seed, self.flip = int(seed), flip
+        dev = dataset_u8.device
+        self.step = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.idx = None
+        self.flips = None
+
+    def enqueue(self, tr: "CelebATrainer"):
+        B = tr.B
+        N, C, H, W = self.data.shape
+        if self.idx is None or self.idx.numel() != B:
+            self.idx = torch.empty(B, device=self.data.device, dtype=torch.int64)
+            self.flips = torch.empty(B, device=self.data.device, dtype=torch.uint8)
+        ops.rng_fill(ops.RNG_RANDINT, self.idx, 0, N, self.seed, self.step, 1)             # shuffle-with-replacement sampling
+        ops.rng_fill(ops.RNG_BERNOULLI, self.flips, 0.5, 0.0, self.seed, self.step, 2)     # RandomHorizontalFlip(p=0.5)
+        ops.gather_u8_images(self.data, self.idx, self.flips if self.flip else None, tr.real, B, C, H, W, 2.0 / 255.0, -1.0)   # ToTensor + Normalize(.5,.5)
+        ops.rng_fill(ops.RNG_NORMAL, tr.z, 0.0, 1.0, self.seed, self.step, 3)
+        ops.rng_fill(ops.RNG_UNIFORM, tr.code, -1.0, 1.0, self.seed, self.step, 4)
+        ops.rng_fill(ops.RNG_RANDINT, tr.labels, 0, tr.G.n_classes, self.seed, self.step, 5)
+        ops.onehot(tr.labels, tr.onehot, B, tr.G.n_classes)
+        ops.counter_add(self.step, 1)
+
+
 class CelebATrainer:
     """One call of :meth:`train_step` == one iteration of the reference loop body
     (celebA/EAD-GAN_celebA.py:299-401): G adversarial step, D step, info+affine step, three Adams
@@ -629,6 +664,7 @@ class CelebATrainer:
         self.onehot = torch.empty(B, generator.n_classes, device=dev, dtype=torch.float32)
         self.labels = torch.empty(B, device=dev, dtype=torch.int64)
         self.graph = None
+        self.inputs = None
         # weight-gradient chains and re-packing run on a second stream beside the backward-data chain (same arithmetic, same order
         # inside every chain -> bit-identical results with and without)
         self.side = SideStream(dev, Workspace.get(dev)) if overlap else None
@@ -779,21 +815,30 @@ class CelebATrainer:
         self.onehot.zero_()
         self.onehot.scatter_(1, self.labels.view(-1, 1), 1.0)
 
-    def capture(self, warmup: bool = False):
-        """Capture the whole iteration into one hipGraph (inputs are read from the static slots).
+    def capture(self, warmup: bool = False, inputs: "DeviceInputs | None" = None):
+        """Capture the whole iteration into one hipGraph (inputs are read from the static slots; with ``inputs`` -- a DeviceInputs --
+        the graph first draws them on the device, so a replay is a complete loop iteration without host work).
 
         At least one eager iteration must have run before (it loads every kernel and sizes the workspace);
         ``warmup=True`` runs that iteration here -- note that it IS a real training step on the current inputs."""
         if warmup:
             self._step_body()
-        return capture_step(self, self._step_body)
+        if inputs is not None:
+            self.inputs = inputs
+        return capture_step(self, self._step_with_inputs)
+
+    def _step_with_inputs(self):
+        if getattr(self, "inputs", None) is not None:
+            self.inputs.enqueue(self)
+        self._step_body()
 
     def step_resident(self):
-        """Run one iteration on whatever is in the static input slots; returns the device loss tensor [g,d,info,_]."""
+        """Run one iteration on whatever is in the static input slots (or on fresh device-side draws if the trainer was captured /
+        configured with a DeviceInputs); returns the device loss tensor [g,d,info,_]."""
         if self.graph is not None:
             self.graph.replay()
         else:
-            self._step_body()
+            self._step_with_inputs()
         return self.losses
 
     def train_step(self, real_imgs, z, code, labels):

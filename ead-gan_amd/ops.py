@@ -438,3 +438,24 @@ def loss_ce_softmaxed(o, ld, c0, n, B, labels, scale, loss, dout):
 
 def loss_affine_rpqxy(o_real, o_trans, ld, c0, B, code, ldc, scale, loss, d_real, d_trans, pred_out=None):
     lib().call("eg_loss_affine_rpqxy", _p(o_real), _p(o_trans), ld, c0, B, _p(code), ldc, scale, _p(loss), _p(d_real), _p(d_trans), _p(pred_out), _stream())
+
+
+# ---- device-side input pipeline -------------------------------------------------------------------
+RNG_UNIFORM, RNG_NORMAL, RNG_RANDINT, RNG_BERNOULLI = 0, 1, 2, 3
+
+
+def rng_fill(kind, out, a, b, seed, step, stream_id):
+    """out <- kind(a, b) from Philox4x32-10 keyed by ``seed``, counted by (element, device counter ``step``, ``stream_id``)"""
+    lib().call("eg_rng_fill", kind, _p(out), out.numel(), float(a), float(b), int(seed), _p(step), int(stream_id), _stream())
+
+
+def counter_add(counter, v=1):
+    lib().call("eg_counter_add", _p(counter), int(v), _stream())
+
+
+def gather_u8_images(data, idx, flip, out, B, C, H, W, scale, shift):
+    lib().call("eg_gather_u8_images", _p(data), _p(idx), _p(flip), _p(out), B, C, H, W, float(scale), float(shift), _stream())
+
+
+def onehot(labels, out, B, n):
+    lib().call("eg_onehot", _p(labels), _p(out), B, n, _stream())

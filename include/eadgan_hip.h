@@ -294,6 +294,19 @@ int eg_u8_to_f32(const unsigned char* x, float* y, size_t n, eg_stream_t s);    
 int eg_loss_affine_rpqxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc,
                          float scale, float* loss, float* d_real, float* d_trans, float* pred_out, eg_stream_t s);
 
+/* --- device-side input pipeline: replaces the per-iteration host work of the reference loops -- DataLoader + PIL
+ * RandomHorizontalFlip / ToTensor / Normalize (celebA/EAD-GAN_celebA.py:194-206, MNIST/EAD-GAN_rpqmnxy.py:235-246) and the numpy draws
+ * of z / code / labels (:308-317; :351-357) -- so that a captured hipGraph feeds itself.  Philox4x32-10, counter = (element, *step,
+ * stream_id), key = seed: reproducible per (seed, step), same distributions as the reference, NOT numpy's stream.
+ * kind 0: uniform [a,b) fp32; 1: normal(a, b) fp32; 2: integers in [a,b) as int64; 3: Bernoulli(a) as uint8 */
+int eg_rng_fill(int kind, void* out, size_t n, float a, float b, unsigned long long seed, const int* step, unsigned int stream_id,
+                eg_stream_t s);
+int eg_counter_add(int* counter, int v, eg_stream_t s);
+/* out[b] = data[idx[b]] (uint8 NCHW dataset in HBM), mirrored along x where flip[b], * scale + shift  -> fp32 NCHW */
+int eg_gather_u8_images(const unsigned char* data, const long long* idx, const unsigned char* flip, float* out, int B, int C, int H,
+                        int W, float scale, float shift, eg_stream_t s);
+int eg_onehot(const long long* labels, float* out, int B, int n, eg_stream_t s);          /* to_categorical (celebA.py:59-64) */
+
 #ifdef __cplusplus
 }
 #endif

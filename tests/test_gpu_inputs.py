@@ -1,0 +1,100 @@
+"""Device-side input pipeline: counter-based draws with the distributions of the reference's numpy calls
+(celebA/EAD-GAN_celebA.py:308-317) and the DataLoader transforms (:194-206) as one gather kernel over a uint8 dataset in HBM."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import celeba_oracle as co
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+eg = None
+
+
+def setup_module(module):
+    global eg
+    eg = importlib.import_module("ead-gan_amd")
+
+
+def _fill(kind, n, a, b, seed, step, stream, dtype=torch.float32):
+    ops = eg.ops
+    out = torch.empty(n, device=DEV, dtype=dtype)
+    st = torch.tensor([step], device=DEV, dtype=torch.int32)
+    ops.rng_fill(kind, out, a, b, seed, st, stream)
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def test_rng_distributions_and_reproducibility():
+    ops = eg.ops
+    n = 1 << 20
+    u = _fill(ops.RNG_UNIFORM, n, -1.0, 1.0, 7, 0, 4).double()
+    assert u.min() >= -1.0 and u.max() < 1.0
+    assert abs(u.mean()) < 3e-3 and abs(u.var() - 1.0 / 3.0) < 3e-3
+    g = _fill(ops.RNG_NORMAL, n, 0.0, 1.0, 7, 0, 3).double()
+    assert abs(g.mean()) < 4e-3 and abs(g.var() - 1.0) < 6e-3
+    assert abs(((g - g.mean()) ** 4).mean() / g.var() ** 2 - 3.0) < 0.05          # kurtosis of a normal
+    assert abs((g.abs() > 1.96).double().mean() - 0.05) < 2e-3                     # tails
+    k = _fill(ops.RNG_RANDINT, n, 0, 10, 7, 0, 5, torch.int64)
+    assert k.min() == 0 and k.max() == 9
+    assert (torch.bincount(k, minlength=10).double() / n - 0.1).abs().max() < 2e-3
+    f = _fill(ops.RNG_BERNOULLI, n, 0.5, 0.0, 7, 0, 2, torch.uint8)
+    assert abs(f.double().mean() - 0.5) < 2e-3
+    # same (seed, step, stream) -> same draws; any of the three changed -> fresh, uncorrelated draws
+    assert torch.equal(_fill(ops.RNG_NORMAL, 4099, 0.0, 1.0, 7, 5, 3), _fill(ops.RNG_NORMAL, 4099, 0.0, 1.0, 7, 5, 3))
+    base = _fill(ops.RNG_NORMAL, n, 0.0, 1.0, 7, 5, 3).double()
+    for other in (_fill(ops.RNG_NORMAL, n, 0.0, 1.0, 8, 5, 3), _fill(ops.RNG_NORMAL, n, 0.0, 1.0, 7, 6, 3), _fill(ops.RNG_NORMAL, n, 0.0, 1.0, 7, 5, 4)):
+        assert abs(float((base * other.double()).mean())) < 5e-3
+    # sequential correlation inside one stream
+    assert abs(float((base[:-1] * base[1:]).mean())) < 5e-3 and abs(float((base[:-4] * base[4:]).mean())) < 5e-3
+
+
+def test_gather_flip_normalize_and_onehot():
+    ops = eg.ops
+    g = torch.Generator().manual_seed(3)
+    data = torch.randint(0, 256, (37, 3, 64, 64), generator=g, dtype=torch.uint8)
+    idx = torch.randint(0, 37, (16,), generator=g)
+    flip = torch.randint(0, 2, (16,), generator=g, dtype=torch.uint8)
+    out = torch.empty(16, 3, 64, 64, device=DEV)
+    ops.gather_u8_images(data.to(DEV), idx.to(DEV), flip.to(DEV), out, 16, 3, 64, 64, 2.0 / 255.0, -1.0)
+    want = data[idx].float()
+    want = torch.where(flip.view(-1, 1, 1, 1).bool(), want.flip(-1), want) / 255.0       # ToTensor
+    want = (want - 0.5) / 0.5                                                             # Normalize((.5,.5,.5), (.5,.5,.5))
+    torch.testing.assert_close(out.cpu(), want, rtol=0, atol=2e-7)
+    oh = torch.empty(16, 10, device=DEV)
+    lab = torch.randint(0, 10, (16,), generator=g)
+    ops.onehot(lab.to(DEV), oh, 16, 10)
+    assert torch.equal(oh.cpu(), torch.nn.functional.one_hot(lab, 10).float())
+
+
+def test_trainer_feeds_itself_from_the_captured_graph():
+    """capture(inputs=DeviceInputs(...)): every replay draws a fresh batch (dataset sampling + flip + normalise, z, code, labels) on the
+    device and trains on it; eager and captured runs with the same seed see the same sequence of batches (identical losses)."""
+    B = 8
+    g = torch.Generator().manual_seed(11)
+    data = (co.synthetic_real(64, seed=9) * 127.5 + 127.5).clamp(0, 255).to(torch.uint8).to(DEV)
+    runs = []
+    for capture in (False, True):
+        orc = co.CelebAOracle(seed=2)
+        G = eg.celeba.Generator(dtype="bf16").to(DEV)
+        D = eg.celeba.Discriminator(dtype="bf16").to(DEV)
+        G.load_state_dict({k: v.detach() for k, v in orc.G.items()})
+        D.load_state_dict({k: v.detach() for k, v in orc.D.items()})
+        tr = eg.celeba.CelebATrainer(G, D, B, dtype="bf16")
+        inp = eg.celeba.DeviceInputs(data, seed=5)
+        tr.inputs = inp
+        out, batches = [], []
+        for i in range(4):
+            if capture and i == 1:
+                tr.capture(inputs=inp)
+            out.append(tr.step_resident().clone())
+            batches.append((tr.real.clone(), tr.z.clone(), tr.labels.clone()))
+        torch.cuda.synchronize()
+        assert int(inp.step.item()) == 4
+        assert not torch.equal(batches[0][1], batches[1][1]) and not torch.equal(batches[1][0], batches[2][0])
+        assert float(tr.real.min()) >= -1.0 and float(tr.real.max()) <= 1.0
+        runs.append((torch.stack(out).cpu(), [b[2].cpu() for b in batches]))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
