@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no side lanes for weight-gradient chains / re-packing")
     ap.add_argument("--igemm-tuning", default="", help="buf_min_tiles,splitk_target,big_min_tiles,persistent,wide_min_tiles for eg_set_igemm_tuning (experiments)")
     ap.add_argument("--igemm-dma", type=int, default=4, help="LDS-DMA staged NT kernel variant for large launches (0 off, 1 = 256x128x3, 2 = 128x128x2, 3 = 128x128x3, 4 = buffer-descriptor 128x128x2 [default])")
-    ap.add_argument("--workload", default="celeba", choices=["celeba", "mnist", "dsprites", "colored"],
+    ap.add_argument("--workload", default="celeba", choices=["celeba", "mnist", "dsprites", "colored", "pxy"],
                     help="celeba = the headline metric (default); mnist = BASELINE config[1] (use --batch 256 --dtype f32); "
                          "dsprites = config[2] (--batch 128); colored = config[4] (--batch 512)")
     return ap.parse_args()
@@ -212,6 +212,38 @@ def main_sprites(a, eg, rank, world, local, dev):
                           "final_losses": [round(x, 4) for x in tr.losses.tolist()[:5]]}), flush=True)
 
 
+def main_pxy(a, eg, rank, world, local, dev):
+    """secondary line: dSprites/pxy.py (stage-1 trainer of Encoder_pxy): 2 encoder forwards + backward per image, ~0.094 GFLOP/img."""
+    from oracle import dsprites_oracle as do        # synthetic sprites only
+    B = a.batch
+    torch.manual_seed(0)
+    P = eg.dsprites.Encoder_pxy(dtype=a.dtype).to(dev)
+    tr = eg.dsprites.PxyTrainer(P, B, dtype=a.dtype, allreduce=eg.dp.GradAllReduce(world) if world > 1 else None)
+    g = torch.Generator(device=dev).manual_seed(1000 + rank)
+    tr.load_inputs(do.synthetic_sprites(B, seed=7 + rank).to(dev), torch.rand((B, 3), device=dev, generator=g) * 2 - 1)
+    tr.step_resident()
+    use_graph = (not a.no_graph) and world == 1
+    if use_graph:
+        tr.capture()
+    for _ in range(max(a.warmup - 1, 0)):
+        tr.step_resident()
+    eg.dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        tr.step_resident()
+    torch.cuda.synchronize()
+    eg.dp.barrier()
+    dt = eg.dp.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        print(json.dumps({"metric": "imgs/sec per train step, dSprites stage-1 (Encoder_pxy)", "value": round(B * world * a.steps / dt, 1), "unit": "imgs/s",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+                          "config": {"workload": f"dSprites/pxy.py iteration (E(img), E(warp(img)), affine regulariser, Adam), batch {B}/GPU, "
+                                                 f"{'hipGraph replay' if use_graph else 'eager launches'}", "per_gpu_batch": B, "parallelism": f"dp{world}"},
+                          "roofline": None, "cpu_baseline": None, "final_losses": [round(tr.losses.tolist()[0], 4)]}), flush=True)
+
+
 def main():
     a = parse()
     eg = importlib.import_module("ead-gan_amd")
@@ -233,6 +265,8 @@ def main():
         return main_mnist(a, eg, rank, world, local, dev)
     if a.workload in ("dsprites", "colored"):
         return main_sprites(a, eg, rank, world, local, dev)
+    if a.workload == "pxy":
+        return main_pxy(a, eg, rank, world, local, dev)
 
     torch.manual_seed(0)                                 # identical replicas on every rank
     G = eg.celeba.Generator(dtype=a.dtype).to(dev)

@@ -542,3 +542,67 @@ extern "C" int eg_loss_affine_rp_color(const float* o_real, const float* o_trans
     EG_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Stage-1 trainer of Encoder_pxy (dSprites/pxy.py:156-191; dSprites/utils_pxy.py:24-66,107-126): code = (p, x, y) latent units,
+// p = 1 + .1 c0, x = .1 c1, y = .1 c2, A = diag(p,p,1) @ Trans(x,y) = [[p,0,p x],[0,p,p y],[0,0,1]].
+// relative = A_t A_r^-1 has rel00 = rel11 = p_t / p_r, rel02 = p_t (x_t - x_r), rel12 = p_t (y_t - y_r), hence
+//   rec_p = p_t / p_r,  rec_x = rel02 / rec_p = p_r (x_t - x_r),  rec_y = p_r (y_t - y_r)   (closed form, gradients by hand).
+// ------------------------------------------------------------------------------------------------------------------------
+__global__ void theta_pxy_kernel(const float* __restrict__ code, int ldc, int B, float* __restrict__ theta) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float p = code[(size_t)b * ldc] * 0.1f + 1.f, x = code[(size_t)b * ldc + 1] * 0.1f, y = code[(size_t)b * ldc + 2] * 0.1f;
+    float* t = theta + (size_t)b * 6;
+    t[0] = p; t[1] = 0.f; t[2] = p * x;
+    t[3] = 0.f; t[4] = p; t[5] = p * y;
+}
+extern "C" int eg_theta_pxy(const float* code, int ldc, int B, float* theta, eg_stream_t s) {
+    EG_REQUIRE(code && theta && ldc >= 3 && B > 0, "eg_theta_pxy: bad argument");
+    hipLaunchKernelGGL(theta_pxy_kernel, dim3(cdiv(B, 128)), dim3(128), 0, (hipStream_t)s, code, ldc, B, theta);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// loss += scale * mean((affine_regularzier_pxy(real, trans) - code)^2);  d_real / d_trans = d loss / d codes ([B][ld], zero elsewhere)
+__global__ void affine_reg_pxy_kernel(const float* __restrict__ o_real, const float* __restrict__ o_trans, int ld, int c0, int B,
+                                      const float* __restrict__ code, int ldc, float scale, float* loss, float* __restrict__ d_real,
+                                      float* __restrict__ d_trans, float* __restrict__ pred_out) {
+    __shared__ float sm[16];
+    float acc = 0.f;
+    const float gs = 2.f * scale / (float)(B * 3);
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float* r = o_real + (size_t)b * ld + c0;
+        const float* t = o_trans + (size_t)b * ld + c0;
+        const float pr = r[0] * 0.1f + 1.f, xr = r[1] * 0.1f, yr = r[2] * 0.1f;
+        const float pt = t[0] * 0.1f + 1.f, xt = t[1] * 0.1f, yt = t[2] * 0.1f;
+        const float rp = pt / pr;
+        const float out[3] = {(rp - 1.f) / 0.1f, pr * (xt - xr) / 0.1f, pr * (yt - yr) / 0.1f};
+        float d[3];
+        for (int j = 0; j < 3; ++j) {
+            d[j] = out[j] - code[(size_t)b * ldc + j];
+            acc += d[j] * d[j];
+            if (pred_out) pred_out[(size_t)b * 3 + j] = out[j];
+        }
+        if (d_real && d_trans) {
+            for (int j = 0; j < ld; ++j) { d_real[(size_t)b * ld + j] = 0.f; d_trans[(size_t)b * ld + j] = 0.f; }
+            // out0 = (pt/pr - 1)/.1 : d/dc0r = -pt/pr^2 (.1/.1), d/dc0t = 1/pr;  out1 = pr (xt - xr)/.1 : d/dc0r = .1 (xt - xr)/.1,
+            // d/dc1r = -pr, d/dc1t = pr;  out2 likewise with y
+            d_real[(size_t)b * ld + c0 + 0] = gs * (d[0] * (-pt / (pr * pr)) + d[1] * (xt - xr) + d[2] * (yt - yr));
+            d_real[(size_t)b * ld + c0 + 1] = gs * d[1] * (-pr);
+            d_real[(size_t)b * ld + c0 + 2] = gs * d[2] * (-pr);
+            d_trans[(size_t)b * ld + c0 + 0] = gs * d[0] / pr;
+            d_trans[(size_t)b * ld + c0 + 1] = gs * d[1] * pr;
+            d_trans[(size_t)b * ld + c0 + 2] = gs * d[2] * pr;
+        }
+    }
+    const float tot = block_sum(acc, sm);
+    if (threadIdx.x == 0 && loss) loss[0] += scale * tot / (float)(B * 3);
+}
+extern "C" int eg_loss_affine_pxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc, float scale,
+                                  float* loss, float* d_real, float* d_trans, float* pred_out, eg_stream_t s) {
+    EG_REQUIRE(o_real && o_trans && code && B > 0 && ld >= c0 + 3 && ldc >= 3, "eg_loss_affine_pxy: bad argument");
+    hipLaunchKernelGGL(affine_reg_pxy_kernel, dim3(1), dim3(128), 0, (hipStream_t)s, o_real, o_trans, ld, c0, B, code, ldc, scale, loss, d_real, d_trans, pred_out);
+    EG_LAUNCH_CHECK();
+    return 0;
+}

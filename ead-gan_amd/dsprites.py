@@ -14,7 +14,7 @@ from torch.nn.utils import spectral_norm
 
 from . import ops
 from .celeba import _HipModule, _require_cuda, transformation_2D      # noqa: F401
-from .engine import ConvRec, Workspace, capture_step, parse_dtype
+from .engine import Arena, ConvRec, Workspace, capture_step, parse_dtype
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, EG_F32, OUT_NCHW_F32
 from .trunk import Head, TrunkEngine
 
@@ -412,6 +412,140 @@ def mutual_info_loss(c_given_x, c):
 # ================================================================================================
 # fused train-loop entry
 # ================================================================================================
+# ================================================================================================
+# Stage-1 trainer: fits Encoder_pxy (dSprites/pxy.py), whose checkpoint the stage-2 loop loads frozen
+# ================================================================================================
+class _PxyTrainEngine:
+    """Encoder_pxy forward + backward for two batched tapes (E(img) and E(warp(img)): plain convs, no BatchNorm, so both forwards
+    share every launch).  The image and the warp matrix carry no gradient (pxy.py:166-178), so the backward ends in the first conv."""
+
+    def __init__(self, mod: "Encoder_pxy", B, dtype, arena: Arena):
+        self.mod, self.B, self.dtype, self.arena = mod, B, dtype, arena
+        dev = arena.flat.device
+        tdt = ops.torch_dtype(dtype)
+        self.ws = ws = Workspace.get(dev)
+        C, S = mod.channels, mod.img_size
+        self.C, self.S = C, S
+        NB = 2 * B
+        self.NB = NB
+        self.k0 = C * 16
+        self.kp = ops.round_up(self.k0, 8)
+        self.l0 = ConvRec(dtype, NB, S // 2, S // 2, self.kp, TRUNK[0], 1, 1, 0, device=dev, want_bwd=False, ws=ws)
+        self.mid = [ConvRec(dtype, NB, S >> (i + 1), S >> (i + 1), TRUNK[i], TRUNK[i + 1], 4, 2, 1, device=dev, ws=ws) for i in range(3)]
+        self.nout = mod.fc1.weight.shape[0]
+        self.head = ConvRec(dtype, NB, 4, 4, TRUNK[3], self.nout, 4, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
+        self.patches = torch.zeros(NB * (S // 2) ** 2, self.kp, device=dev, dtype=tdt)
+        self.a = [torch.empty(NB, S >> (i + 1), S >> (i + 1), TRUNK[i], device=dev, dtype=tdt) for i in range(4)]
+        self.dz = [torch.empty_like(t) for t in self.a]
+        self.out = torch.empty(NB, self.nout, device=dev, dtype=torch.float32)
+        self.repack()
+
+    def repack(self):
+        cb = self.mod.conv_block
+        ops.pack_strided(self.dtype, cb[0].weight, self.l0.wp_fwd, TRUNK[0], self.k0, self.l0.Kpad_fwd, 1, self.k0, 0, 1)
+        for i in range(3):
+            self.mid[i].pack(cb[2 * (i + 1)].weight)
+        self.head.pack(self.mod.fc1.weight)
+
+    def forward(self, img, trans_img):
+        """-> codes [2B, n_out] fp32: rows [:B] of ``img``, rows [B:] of ``trans_img``"""
+        dt, B, cb = self.dtype, self.B, self.mod.conv_block
+        npix = B * (self.S // 2) ** 2
+        ops.im2col_img(dt, img, self.patches[:npix], B, self.C, self.S, self.S, 4, 2, 1, self.kp)
+        ops.im2col_img(dt, trans_img, self.patches[npix:], B, self.C, self.S, self.S, 4, 2, 1, self.kp)
+        ops.conv_fwd(self.l0.c, dt, self.patches, self.l0.wp_fwd, self.a[0], ops.epilogue(bias=cb[0].bias, act=ACT_LRELU, slope=0.1))
+        for i in range(3):
+            ops.conv_fwd(self.mid[i].c, dt, self.a[i], self.mid[i].wp_fwd, self.a[i + 1], ops.epilogue(bias=cb[2 * (i + 1)].bias, act=ACT_LRELU, slope=0.1))
+        ops.dense_small_fwd(dt, self.a[3], self.head.wp_fwd, self.mod.fc1.bias, self.out, self.NB, 16 * TRUNK[3], self.head.Kpad_fwd, self.nout, self.ws.small)
+        return self.out
+
+    def backward(self, dout, grad):
+        """dout: d(loss)/d(codes) [2B, n_out] fp32; accumulates into the flat gradient ``grad`` (arena layout)."""
+        dt, NB, ws, cb = self.dtype, self.NB, self.ws, self.mod.conv_block
+        gof = lambda name: self.arena.grad_of(name, grad)
+        K = 16 * TRUNK[3]
+        ops.dense_small_wgrad(dt, dout, self.a[3], gof("fc1.weight"), gof("fc1.bias"), NB, K, self.nout, TRUNK[3], 16)
+        ops.dense_small_bwd(dt, dout, self.head.wp_fwd, self.a[3], self.dz[3], NB, K, self.head.Kpad_fwd, self.nout, ACT_LRELU, 0.1)
+        for i in (3, 2, 1, 0):
+            idx = 2 * i
+            rec = self.mid[i - 1] if i > 0 else self.l0
+            x_in = self.a[i - 1] if i > 0 else self.patches
+            rows = NB * (self.S >> (i + 1)) ** 2
+            ops.bias_grad(dt, self.dz[i], rows, TRUNK[i], ws.small, gof(f"conv_block.{idx}.bias"))
+            ns = ops.conv_wgrad(rec.c, dt, x_in, self.dz[i], ws.slab)
+            if i > 0:
+                ops.wgrad_reduce(ws.slab, ns, TRUNK[i], TRUNK[i], TRUNK[i - 1], 16, gof(f"conv_block.{idx}.weight"))
+                ops.conv_bwd_data(rec.c, dt, self.dz[i], rec.wp_bwd, self.dz[i - 1],
+                                  ops.epilogue(mask=self.a[i - 1], mask_act=ACT_LRELU, mask_slope=0.1))
+            else:
+                ops.wgrad_reduce_perm(ws.slab, ns, TRUNK[0], TRUNK[0], self.kp, 1, gof("conv_block.0.weight"), 0, 0, self.k0)
+
+
+class PxyTrainer:
+    """One call == one iteration of dSprites/pxy.py:156-191 (stage-1 trainer): real_code = E(img); trans_img = warp(img,
+    get_matrix_pxy(code)); trans_code = E(trans_img); loss = MSE(affine_regularzier_pxy(real_code, trans_code), code); Adam(lr 2e-4,
+    betas (.5, .999), :127) on Encoder_pxy.  Its ``state_dict()`` is the ``encoder_pxy_%d.pt`` the stage-2 loop loads (:205)."""
+
+    def __init__(self, encoder_pxy: "Encoder_pxy", batch_size, dtype="f32", lr=2e-4, betas=(0.5, 0.999), allreduce=None):
+        self.P, self.B = encoder_pxy, batch_size
+        dt = parse_dtype(dtype)
+        encoder_pxy.set_compute_dtype(dt)
+        _require_cuda(next(encoder_pxy.parameters()))
+        self.arena = Arena(encoder_pxy)                  # trainable here: parameters re-homed into one flat fp32 arena
+        encoder_pxy._engines = {}                        # inference engines hold panels of the old storage
+        self.eng = _PxyTrainEngine(encoder_pxy, batch_size, dt, self.arena)
+        dev = self.arena.flat.device
+        self.dev = dev
+        self.lr, self.betas, self.allreduce = lr, betas, allreduce
+        z = lambda *n: torch.zeros(*n, device=dev, dtype=torch.float32)
+        B, C = batch_size, encoder_pxy.channels
+        self.m, self.v = z(self.arena.numel), z(self.arena.numel)
+        self.steps = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.losses = z(4)
+        self.img_u8 = torch.zeros(B, 64, 64, device=dev, dtype=torch.uint8)
+        self.img, self.trans = z(B, C, 64, 64), z(B, C, 64, 64)
+        self.code = z(B, 3)
+        self.theta = z(B, 2, 3)
+        self.dout = z(2 * B, 3)
+        self.graph = None
+
+    def _step_body(self):
+        B, eng, ar = self.B, self.eng, self.arena
+        ops.fill_f32(self.losses)
+        ops.u8_to_f32(self.img_u8, self.img)                                           # pxy.py:161-162
+        ops.theta_pxy(self.code, 3, B, self.theta)                                      # :176
+        ops.warp_affine(self.img, self.theta, self.trans, B, self.P.channels, 64, 64)   # :177 (padding_mode='border')
+        codes = eng.forward(self.img, self.trans)                                       # :174,178
+        ops.loss_affine_pxy(codes[:B], codes[B:], 3, 0, B, self.code, 3, 1.0, self.losses[0:1], self.dout[:B], self.dout[B:])   # :180-182
+        ops.fill_f32(ar.grad)
+        eng.backward(self.dout, ar.grad)
+        if self.allreduce is not None:
+            self.allreduce(ar.grad)
+        ops.adam_step(ar.flat, ar.grad, self.m, self.v, ar.numel, self.lr, self.betas[0], self.betas[1], 1e-8, self.steps[0:1], True)
+        eng.repack()
+
+    def load_inputs(self, img_u8, code):
+        self.img_u8.copy_(img_u8, non_blocking=True)
+        self.code.copy_(code, non_blocking=True)
+
+    def capture(self, warmup=False):
+        if warmup:
+            self._step_body()
+        return capture_step(self, self._step_body)
+
+    def step_resident(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._step_body()
+        return self.losses
+
+    def train_step(self, img_u8, code):
+        """train-loop entry: img_u8 uint8 [B,64,64] sprites, code [B,3] ~ U(-1,1) -> {'affine_loss'}"""
+        self.load_inputs(img_u8, code)
+        return {"affine_loss": float(self.step_resident()[0])}
+
+
 class DspritesTrainer:
     """One call == one iteration of dSprites/rp.py:365-482: D step (Adam lr 2e-4), then the joint info + affine + adversarial-G +
     relative-category step over G+E (Adam lr 1e-4).  optimizer_G of the reference is never stepped and is not created.

@@ -459,3 +459,13 @@ def gather_u8_images(data, idx, flip, out, B, C, H, W, scale, shift):
 
 def onehot(labels, out, B, n):
     lib().call("eg_onehot", _p(labels), _p(out), B, n, _stream())
+
+
+# ---- stage-1 (Encoder_pxy) trainer ------------------------------------------------------------------
+def theta_pxy(code, ldc, B, theta):
+    lib().call("eg_theta_pxy", _p(code), ldc, B, _p(theta), _stream())
+
+
+def loss_affine_pxy(o_real, o_trans, ld, c0, B, code, ldc, scale, loss, d_real, d_trans, pred_out=None):
+    lib().call("eg_loss_affine_pxy", _p(o_real), _p(o_trans), ld, c0, B, _p(code), ldc, float(scale), _p(loss), _p(d_real), _p(d_trans), _p(pred_out),
+               _stream())

@@ -279,3 +279,47 @@ def draw_colored_inputs(rng: np.random.RandomState, B: int):
     """rp_color.py:372-378 draws the colour gains first, then the dSprites sequence with code_dim 7."""
     gains = torch.tensor(rng.uniform(0.5, 1, [B, 3, 1, 1]).reshape(B, 3), dtype=torch.float64)
     return (gains,) + draw_step_inputs(rng, B, code_dim=7)
+
+
+# ---- stage-1 trainer (dSprites/pxy.py): fits Encoder_pxy, whose checkpoint the stage-2 loop above loads -------------------------
+def get_matrix_pxy(code3):
+    """A = diag(p,p,1) @ Trans(x,y); p = 1 + .1 c0, x,y = .1 c1, .1 c2  (utils_pxy.py:24-34,49-66)."""
+    B = code3.shape[0]
+    p, x, y = code3[:, 0] * 0.1 + 1, code3[:, 1] * 0.1, code3[:, 2] * 0.1
+    one, zero = torch.ones(B), torch.zeros(B)
+    mk = lambda *e: torch.stack(e, 1).view(B, 3, 3)
+    return mk(p, zero, zero, zero, p, zero, zero, zero, one) @ mk(one, zero, x, zero, one, y, zero, zero, one)
+
+
+def affine_regularzier_pxy(real_code, trans_code):
+    """utils_pxy.py:107-126: relative matrix -> (p, x, y) -> latent units."""
+    rel = get_matrix_pxy(trans_code) @ torch.inverse(get_matrix_pxy(real_code))
+    p = (rel[:, 0, 0] + rel[:, 1, 1]) / 2
+    return torch.stack(((p - 1) / 0.1, rel[:, 0, 2] / p / 0.1, rel[:, 1, 2] / p / 0.1), dim=1).float()
+
+
+class PxyOracle:
+    """dSprites/pxy.py:156-191: E(img), E(warp(img, A(code))) -> affine_regularzier_pxy -> MSE vs the drawn code; Adam(lr 2e-4,
+    betas (.5,.999)) on Encoder_pxy (:127).  Neither the image nor A carries a gradient, so the backward ends in the first conv."""
+
+    def __init__(self, seed=0, lr=2e-4):
+        torch.manual_seed(seed)                        # pxy.py:123 constructs Encoder_pxy first
+        P = _containers(ch=CH, pxy_out=3)[0]
+        self.P = _to_dict(P)
+        self.opt = torch.optim.Adam(trainable(self.P), lr=lr, betas=(0.5, 0.999))
+
+    def train_step(self, img_u8, code):
+        img = img_u8.unsqueeze(1).float()
+        real_code = encoder_pxy_forward(self.P, img)
+        trans_img = warp(img, get_matrix_pxy(code)[:, 0:2])
+        trans_code = encoder_pxy_forward(self.P, trans_img)
+        loss = F.mse_loss(affine_regularzier_pxy(real_code, trans_code), code)
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        return {"affine_loss": float(loss.detach())}
+
+
+def draw_pxy_inputs(rng: np.random.RandomState, B: int):
+    """the loop's one numpy draw (pxy.py:166)"""
+    return torch.from_numpy(rng.uniform(-1, 1, (B, 3))).float()

@@ -211,8 +211,28 @@ def make_celeba_curve(B=4, steps=120, seed=0):
     print("celeba curve golden: first/last", {k: (float(out[k][0]), float(out[k][-1])) for k in names})
 
 
+def make_pxy(B=8, steps=3, seed=0):
+    """dSprites/pxy.py loop (:156-191, stage-1 trainer of Encoder_pxy) on synthetic uint8 sprites."""
+    torch.set_num_threads(8)
+    sprites = do.synthetic_sprites(B * steps, seed=98).view(steps, B, 64, 64)
+    opt = rh.dsprites_opt(B)
+    opt.lr, opt.code_dim = 0.0002, 3                 # argparse defaults pxy.py:37,42
+    out = {"B": np.array(B), "steps": np.array(steps), "seed": np.array(seed), "sprite_seed": np.array(98)}
+    names = ("affine_loss",)
+    for n in (1, steps):
+        batches = [sprites[i].clone() for i in range(n)]
+        g, recs = rh.run_script_loop("dSprites/pxy.py", opt, batches, names, seed)
+        if n == 1:
+            probe_state("P1", g["encoder_pxy"].state_dict(), out)
+            probe_grads("gP1", g["encoder_pxy"], out)
+    for k in names:
+        out[k] = np.array([r[k] for r in recs], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, f"pxy_b{B}_s{steps}.npz"), **out)
+    print("pxy golden:", {k: out[k] for k in names})
+
+
 MAKERS = {"colored": make_colored, "dsprites": make_dsprites, "celeba": make_celeba, "celeba_affine": make_celeba_affine, "mnist": make_mnist, "mnist_affine": make_mnist_affine,
-          "celeba_curve": make_celeba_curve}
+          "celeba_curve": make_celeba_curve, "pxy": make_pxy}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
