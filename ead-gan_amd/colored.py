@@ -110,3 +110,33 @@ class ColoredTrainer(ds.DspritesTrainer):
         self.load_inputs(sprites_u8, gains, code1, labels1, code2, labels2)
         l = self.step_resident().tolist()
         return dict(d_loss=l[0], g_loss=l[1], info_loss=l[2], affine_loss=l[3], relative_cat_loss=l[4])
+
+
+# ---- stage-1 trainer of the colored Encoder_pxy (colored_dSprites/pxy_color.py:160-216) ----------------------------------------
+class PxyColorTrainer(ds.PxyTrainer):
+    """pxy_color.py loop: sprites repeated to 3 channels and multiplied by U(.5,1) gains (:166-177); 6-d code (p, x, y, r, g, b);
+    trans = warp(img, get_matrix_pxy(code)) with ZERO padding (:90) times the colour gains 1 + .1 c[3:] (:196-201);
+    affine_regularzier_pxy with the colour ratio (utils_pxy.py:150-176); Adam lr 2e-4 on Encoder_pxy(channels=3, n_out=6)."""
+
+    def __init__(self, encoder_pxy, batch_size, dtype="f32", lr=2e-4, betas=(0.5, 0.999), allreduce=None):
+        super().__init__(encoder_pxy, batch_size, dtype=dtype, lr=lr, betas=betas, allreduce=allreduce)
+        dev = self.dev
+        self.gains = torch.ones(batch_size, 3, device=dev, dtype=torch.float32)
+        self.warped = torch.zeros(batch_size, 3, 64, 64, device=dev, dtype=torch.float32)
+
+    def _make_image(self):
+        ops.u8_colorize(self.img_u8, self.gains, self.img, self.B, 3, 64 * 64)
+
+    def _transform(self):
+        ops.warp_affine_zeros(self.img, self.theta, self.warped, self.B, 3, 64, 64)
+        ops.color_scale(self.warped, self.code, self.nd, 3, 0.1, False, self.trans, self.B, 3, 64 * 64)
+
+    def load_inputs(self, img_u8, gains, code):
+        self.img_u8.copy_(img_u8, non_blocking=True)
+        self.gains.copy_(gains.view(-1, 3), non_blocking=True)
+        self.code.copy_(code, non_blocking=True)
+
+    def train_step(self, img_u8, gains, code):
+        """img_u8 uint8 [B,64,64]; gains [B,3] ~ U(.5,1); code [B,6] ~ U(-1,1) -> {'affine_loss'}"""
+        self.load_inputs(img_u8, gains, code)
+        return {"affine_loss": float(self.step_resident()[0])}

@@ -22,6 +22,7 @@ extern "C" int eg_theta_rpqxy(const float* code, int ldc, int B, float* theta, e
 }
 
 // out[b,c,y,x] = bilinear sample of img[b,c] at theta[b] * (xn, yn, 1), align_corners=False, border padding
+template <bool ZEROS>      // ZEROS: grid_sample(padding_mode='zeros') (colored_dSprites/pxy_color.py:90), else 'border'
 __global__ void warp_affine_kernel(const float* __restrict__ img, const float* __restrict__ theta, float* __restrict__ out, int B, int C,
                                    int H, int W) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -33,17 +34,23 @@ __global__ void warp_affine_kernel(const float* __restrict__ img, const float* _
     const float gx = t[0] * xn + t[1] * yn + t[2];
     const float gy = t[3] * xn + t[4] * yn + t[5];
     float ix = ((gx + 1.f) * W - 1.f) * 0.5f, iy = ((gy + 1.f) * H - 1.f) * 0.5f;
-    ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
-    iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+    if (!ZEROS) {
+        ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
+        iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+    } else {                                        // keep the index arithmetic finite for far-away samples (all four taps are outside anyway)
+        ix = fminf(fmaxf(ix, -2.f), (float)(W + 1));
+        iy = fminf(fmaxf(iy, -2.f), (float)(H + 1));
+    }
     const float fx = floorf(ix), fy = floorf(iy);
     const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
     const float wx1 = ix - fx, wx0 = 1.f - wx1, wy1 = iy - fy, wy0 = 1.f - wy1;
-    const bool vx1 = x1 < W, vy1 = y1 < H;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
     for (int c = 0; c < C; ++c) {
         const float* p = img + ((size_t)b * C + c) * H * W;
-        float v = p[y0 * W + x0] * (wx0 * wy0);
-        if (vx1) v += p[y0 * W + x1] * (wx1 * wy0);
-        if (vy1) v += p[y1 * W + x0] * (wx0 * wy1);
+        float v = 0.f;
+        if (vx0 && vy0) v += p[y0 * W + x0] * (wx0 * wy0);
+        if (vx1 && vy0) v += p[y0 * W + x1] * (wx1 * wy0);
+        if (vx0 && vy1) v += p[y1 * W + x0] * (wx0 * wy1);
         if (vx1 && vy1) v += p[y1 * W + x1] * (wx1 * wy1);
         out[((size_t)b * C + c) * H * W + (size_t)y * W + x] = v;
     }
@@ -52,7 +59,15 @@ __global__ void warp_affine_kernel(const float* __restrict__ img, const float* _
 extern "C" int eg_warp_affine(const float* img, const float* theta, float* out, int B, int C, int H, int W, eg_stream_t s) {
     EG_REQUIRE(img && theta && out, "eg_warp_affine: null pointer");
     const size_t total = (size_t)B * H * W;
-    hipLaunchKernelGGL(warp_affine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, img, theta, out, B, C, H, W);
+    hipLaunchKernelGGL(warp_affine_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, img, theta, out, B, C, H, W);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int eg_warp_affine_zeros(const float* img, const float* theta, float* out, int B, int C, int H, int W, eg_stream_t s) {
+    EG_REQUIRE(img && theta && out, "eg_warp_affine_zeros: null pointer");
+    const size_t total = (size_t)B * H * W;
+    hipLaunchKernelGGL(warp_affine_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, img, theta, out, B, C, H, W);
     EG_LAUNCH_CHECK();
     return 0;
 }
@@ -565,12 +580,14 @@ extern "C" int eg_theta_pxy(const float* code, int ldc, int B, float* theta, eg_
 }
 
 // loss += scale * mean((affine_regularzier_pxy(real, trans) - code)^2);  d_real / d_trans = d loss / d codes ([B][ld], zero elsewhere)
+// ncol (0 or 3) further code entries are colour gains g = 1 + .1 c (colored_dSprites/utils_pxy.py:150-176): rec_j = (g_t / g_r - 1) / .1
 __global__ void affine_reg_pxy_kernel(const float* __restrict__ o_real, const float* __restrict__ o_trans, int ld, int c0, int B,
                                       const float* __restrict__ code, int ldc, float scale, float* loss, float* __restrict__ d_real,
-                                      float* __restrict__ d_trans, float* __restrict__ pred_out) {
+                                      float* __restrict__ d_trans, float* __restrict__ pred_out, int ncol) {
     __shared__ float sm[16];
     float acc = 0.f;
-    const float gs = 2.f * scale / (float)(B * 3);
+    const int nd = 3 + ncol;
+    const float gs = 2.f * scale / (float)(B * nd);
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         const float* r = o_real + (size_t)b * ld + c0;
         const float* t = o_trans + (size_t)b * ld + c0;
@@ -582,10 +599,22 @@ __global__ void affine_reg_pxy_kernel(const float* __restrict__ o_real, const fl
         for (int j = 0; j < 3; ++j) {
             d[j] = out[j] - code[(size_t)b * ldc + j];
             acc += d[j] * d[j];
-            if (pred_out) pred_out[(size_t)b * 3 + j] = out[j];
+            if (pred_out) pred_out[(size_t)b * nd + j] = out[j];
+        }
+        if (d_real && d_trans)
+            for (int j = 0; j < ld; ++j) { d_real[(size_t)b * ld + j] = 0.f; d_trans[(size_t)b * ld + j] = 0.f; }
+        for (int j = 0; j < ncol; ++j) {
+            const float gr = r[3 + j] * 0.1f + 1.f, gt = t[3 + j] * 0.1f + 1.f;
+            const float o = (gt / gr - 1.f) / 0.1f;
+            const float dj = o - code[(size_t)b * ldc + 3 + j];
+            acc += dj * dj;
+            if (pred_out) pred_out[(size_t)b * nd + 3 + j] = o;
+            if (d_real && d_trans) {
+                d_real[(size_t)b * ld + c0 + 3 + j] = gs * dj * (-gt / (gr * gr));
+                d_trans[(size_t)b * ld + c0 + 3 + j] = gs * dj / gr;
+            }
         }
         if (d_real && d_trans) {
-            for (int j = 0; j < ld; ++j) { d_real[(size_t)b * ld + j] = 0.f; d_trans[(size_t)b * ld + j] = 0.f; }
             // out0 = (pt/pr - 1)/.1 : d/dc0r = -pt/pr^2 (.1/.1), d/dc0t = 1/pr;  out1 = pr (xt - xr)/.1 : d/dc0r = .1 (xt - xr)/.1,
             // d/dc1r = -pr, d/dc1t = pr;  out2 likewise with y
             d_real[(size_t)b * ld + c0 + 0] = gs * (d[0] * (-pt / (pr * pr)) + d[1] * (xt - xr) + d[2] * (yt - yr));
@@ -597,12 +626,12 @@ __global__ void affine_reg_pxy_kernel(const float* __restrict__ o_real, const fl
         }
     }
     const float tot = block_sum(acc, sm);
-    if (threadIdx.x == 0 && loss) loss[0] += scale * tot / (float)(B * 3);
+    if (threadIdx.x == 0 && loss) loss[0] += scale * tot / (float)(B * nd);
 }
-extern "C" int eg_loss_affine_pxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc, float scale,
+extern "C" int eg_loss_affine_pxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc, int ncol, float scale,
                                   float* loss, float* d_real, float* d_trans, float* pred_out, eg_stream_t s) {
-    EG_REQUIRE(o_real && o_trans && code && B > 0 && ld >= c0 + 3 && ldc >= 3, "eg_loss_affine_pxy: bad argument");
-    hipLaunchKernelGGL(affine_reg_pxy_kernel, dim3(1), dim3(128), 0, (hipStream_t)s, o_real, o_trans, ld, c0, B, code, ldc, scale, loss, d_real, d_trans, pred_out);
+    EG_REQUIRE(o_real && o_trans && code && B > 0 && (ncol == 0 || ncol == 3) && ld >= c0 + 3 + ncol && ldc >= 3 + ncol, "eg_loss_affine_pxy: bad argument");
+    hipLaunchKernelGGL(affine_reg_pxy_kernel, dim3(1), dim3(128), 0, (hipStream_t)s, o_real, o_trans, ld, c0, B, code, ldc, scale, loss, d_real, d_trans, pred_out, ncol);
     EG_LAUNCH_CHECK();
     return 0;
 }

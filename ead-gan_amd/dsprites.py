@@ -504,19 +504,27 @@ class PxyTrainer:
         self.losses = z(4)
         self.img_u8 = torch.zeros(B, 64, 64, device=dev, dtype=torch.uint8)
         self.img, self.trans = z(B, C, 64, 64), z(B, C, 64, 64)
-        self.code = z(B, 3)
+        self.nd = encoder_pxy.fc1.weight.shape[0]           # 3 (p, x, y); the colored variant appends three colour gains
+        self.code = z(B, self.nd)
         self.theta = z(B, 2, 3)
-        self.dout = z(2 * B, 3)
+        self.dout = z(2 * B, self.nd)
         self.graph = None
 
-    def _step_body(self):
-        B, eng, ar = self.B, self.eng, self.arena
-        ops.fill_f32(self.losses)
+    # hooks the colored variant overrides (colored.PxyColorTrainer)
+    def _make_image(self):
         ops.u8_to_f32(self.img_u8, self.img)                                           # pxy.py:161-162
-        ops.theta_pxy(self.code, 3, B, self.theta)                                      # :176
-        ops.warp_affine(self.img, self.theta, self.trans, B, self.P.channels, 64, 64)   # :177 (padding_mode='border')
+
+    def _transform(self):
+        ops.warp_affine(self.img, self.theta, self.trans, self.B, self.P.channels, 64, 64)   # :177 (padding_mode='border')
+
+    def _step_body(self):
+        B, eng, ar, nd = self.B, self.eng, self.arena, self.nd
+        ops.fill_f32(self.losses)
+        self._make_image()
+        ops.theta_pxy(self.code, nd, B, self.theta)                                     # :176
+        self._transform()
         codes = eng.forward(self.img, self.trans)                                       # :174,178
-        ops.loss_affine_pxy(codes[:B], codes[B:], 3, 0, B, self.code, 3, 1.0, self.losses[0:1], self.dout[:B], self.dout[B:])   # :180-182
+        ops.loss_affine_pxy(codes[:B], codes[B:], nd, 0, B, self.code, nd, 1.0, self.losses[0:1], self.dout[:B], self.dout[B:], ncol=nd - 3)   # :180-182
         ops.fill_f32(ar.grad)
         eng.backward(self.dout, ar.grad)
         if self.allreduce is not None:

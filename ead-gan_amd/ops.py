@@ -466,6 +466,10 @@ def theta_pxy(code, ldc, B, theta):
     lib().call("eg_theta_pxy", _p(code), ldc, B, _p(theta), _stream())
 
 
-def loss_affine_pxy(o_real, o_trans, ld, c0, B, code, ldc, scale, loss, d_real, d_trans, pred_out=None):
-    lib().call("eg_loss_affine_pxy", _p(o_real), _p(o_trans), ld, c0, B, _p(code), ldc, float(scale), _p(loss), _p(d_real), _p(d_trans), _p(pred_out),
-               _stream())
+def loss_affine_pxy(o_real, o_trans, ld, c0, B, code, ldc, scale, loss, d_real, d_trans, pred_out=None, ncol=0):
+    lib().call("eg_loss_affine_pxy", _p(o_real), _p(o_trans), ld, c0, B, _p(code), ldc, ncol, float(scale), _p(loss), _p(d_real), _p(d_trans),
+               _p(pred_out), _stream())
+
+
+def warp_affine_zeros(img, theta, out, B, C, H, W):
+    lib().call("eg_warp_affine_zeros", _p(img), _p(theta), _p(out), B, C, H, W, _stream())

@@ -297,8 +297,11 @@ int eg_loss_affine_rpqxy(const float* o_real, const float* o_trans, int ld, int 
 /* stage-1 trainer of Encoder_pxy (dSprites/pxy.py:156-191, dSprites/utils_pxy.py:24-66,107-126): theta = rows 0,1 of
  * get_matrix_pxy(code); affine_regularzier_pxy + MSE with fused gradients w.r.t. both codes */
 int eg_theta_pxy(const float* code, int ldc, int B, float* theta, eg_stream_t s);
-int eg_loss_affine_pxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc, float scale,
+/* ncol = 3: three colour-gain entries follow (p, x, y) (colored_dSprites/utils_pxy.py:150-176, pxy_color.py:185-213) */
+int eg_loss_affine_pxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc, int ncol, float scale,
                        float* loss, float* d_real, float* d_trans, float* pred_out, eg_stream_t s);
+/* transformation_2D with grid_sample(padding_mode='zeros') (colored_dSprites/pxy_color.py:86-92) */
+int eg_warp_affine_zeros(const float* img, const float* theta, float* out, int B, int C, int H, int W, eg_stream_t s);
 
 /* --- device-side input pipeline: replaces the per-iteration host work of the reference loops -- DataLoader + PIL
  * RandomHorizontalFlip / ToTensor / Normalize (celebA/EAD-GAN_celebA.py:194-206, MNIST/EAD-GAN_rpqmnxy.py:235-246) and the numpy draws

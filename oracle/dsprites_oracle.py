@@ -323,3 +323,46 @@ class PxyOracle:
 def draw_pxy_inputs(rng: np.random.RandomState, B: int):
     """the loop's one numpy draw (pxy.py:166)"""
     return torch.from_numpy(rng.uniform(-1, 1, (B, 3))).float()
+
+
+# ---- colored stage-1 trainer (colored_dSprites/pxy_color.py) -------------------------------------------------------------------
+def warp_zeros(img, theta):
+    """transformation_2D of pxy_color.py:86-92: grid_sample(padding_mode='zeros')"""
+    grid = F.affine_grid(theta, list(img.shape), align_corners=False)
+    return F.grid_sample(img, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+
+
+def affine_regularzier_pxy_color(real_code, trans_code):
+    """colored_dSprites/utils_pxy.py:150-176: (p, x, y) as affine_regularzier_pxy + colour ratio (1+.1 t)/(1+.1 r) -> latent units."""
+    aff = affine_regularzier_pxy(real_code[:, :3], trans_code[:, :3])
+    col = ((trans_code[:, 3:] * 0.1 + 1) / (real_code[:, 3:] * 0.1 + 1) - 1) / 0.1
+    return torch.cat((aff, col), dim=1).float()
+
+
+class PxyColorOracle:
+    """colored_dSprites/pxy_color.py:160-216: sprites x U(.5,1) colour gains; code 6-d; trans = warp_zeros(img, A(code[:3])) x
+    (1 + .1 code[3:]); MSE(affine_regularzier_pxy(E(img), E(trans)), code); Adam(lr 2e-4, betas (.5,.999)) on Encoder_pxy(3 ch, 6 out)."""
+
+    def __init__(self, seed=0, lr=2e-4):
+        torch.manual_seed(seed)
+        P = _containers(ch=3, pxy_out=6)[0]
+        self.P = _to_dict(P)
+        self.opt = torch.optim.Adam(trainable(self.P), lr=lr, betas=(0.5, 0.999))
+
+    def train_step(self, img_u8, gains, code):
+        img = (img_u8.unsqueeze(1).repeat(1, 3, 1, 1) * gains.view(-1, 3, 1, 1)).float()       # :166-177 (float64 product, then .float())
+        real_code = encoder_pxy_forward(self.P, img)
+        trans = warp_zeros(img, get_matrix_pxy(code[:, :3])[:, 0:2]) * (code[:, 3:] * 0.1 + 1).view(-1, 3, 1, 1)
+        trans_code = encoder_pxy_forward(self.P, trans)
+        loss = F.mse_loss(affine_regularzier_pxy_color(real_code, trans_code), code)
+        self.opt.zero_grad()
+        loss.backward()
+        self.opt.step()
+        return {"affine_loss": float(loss.detach())}
+
+
+def draw_pxy_color_inputs(rng: np.random.RandomState, B: int):
+    """pxy_color.py:170-186: colour gains first, then the 6-d code"""
+    gains = torch.tensor(rng.uniform(0.5, 1, [B, 3, 1, 1]).reshape(B, 3), dtype=torch.float64)
+    code = torch.from_numpy(rng.uniform(-1, 1, (B, 6))).float()
+    return gains, code

@@ -231,8 +231,28 @@ def make_pxy(B=8, steps=3, seed=0):
     print("pxy golden:", {k: out[k] for k in names})
 
 
+def make_pxy_color(B=8, steps=3, seed=0):
+    """colored_dSprites/pxy_color.py loop (:160-216, stage-1 trainer of the colored Encoder_pxy) on synthetic uint8 sprites."""
+    torch.set_num_threads(8)
+    sprites = do.synthetic_sprites(B * steps, seed=97).view(steps, B, 64, 64)
+    opt = rh.colored_opt(B)
+    opt.lr, opt.code_dim = 0.0002, 6                 # argparse defaults pxy_color.py:34,39
+    out = {"B": np.array(B), "steps": np.array(steps), "seed": np.array(seed), "sprite_seed": np.array(97)}
+    names = ("affine_loss",)
+    for n in (1, steps):
+        batches = [sprites[i].clone() for i in range(n)]
+        g, recs = rh.run_script_loop("colored_dSprites/pxy_color.py", opt, batches, names, seed)
+        if n == 1:
+            probe_state("P1", g["encoder_pxy"].state_dict(), out)
+            probe_grads("gP1", g["encoder_pxy"], out)
+    for k in names:
+        out[k] = np.array([r[k] for r in recs], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, f"pxy_color_b{B}_s{steps}.npz"), **out)
+    print("pxy_color golden:", {k: out[k] for k in names})
+
+
 MAKERS = {"colored": make_colored, "dsprites": make_dsprites, "celeba": make_celeba, "celeba_affine": make_celeba_affine, "mnist": make_mnist, "mnist_affine": make_mnist_affine,
-          "celeba_curve": make_celeba_curve, "pxy": make_pxy}
+          "celeba_curve": make_celeba_curve, "pxy": make_pxy, "pxy_color": make_pxy_color}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

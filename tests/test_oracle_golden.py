@@ -157,3 +157,20 @@ def test_pxy_stage1_step_matches_reference():
         if i == 0:
             check_probes("gP1", {k: v.grad for k, v in orc.P.items() if getattr(v, "grad", None) is not None}, gold, 1e-2, 1e-9, noise_floor=1e-8)
             check_probes("P1", orc.P, gold, 2e-3, 3e-4)
+
+
+def test_pxy_color_stage1_step_matches_reference():
+    """colored_dSprites/pxy_color.py (stage-1 trainer of the colored Encoder_pxy): oracle vs the loop body run through the harness"""
+    from oracle import dsprites_oracle as do
+    gold = np.load(os.path.join(GOLDEN, "pxy_color_b8_s3.npz"))
+    B, steps, seed = int(gold["B"]), int(gold["steps"]), int(gold["seed"])
+    torch.set_num_threads(8)
+    orc = do.PxyColorOracle(seed=seed)
+    rng = np.random.RandomState(seed)
+    sprites = do.synthetic_sprites(B * steps, seed=int(gold["sprite_seed"])).view(steps, B, 64, 64)
+    for i in range(steps):
+        out = orc.train_step(sprites[i], *do.draw_pxy_color_inputs(rng, B))
+        assert abs(out["affine_loss"] - gold["affine_loss"][i]) < (2e-6, 3e-4, 2e-3)[i], (i, out, gold["affine_loss"][i])
+        if i == 0:
+            check_probes("gP1", {k: v.grad for k, v in orc.P.items() if getattr(v, "grad", None) is not None}, gold, 1e-2, 1e-9, noise_floor=1e-8)
+            check_probes("P1", orc.P, gold, 2e-3, 3e-4)
