@@ -771,15 +771,22 @@ class CelebATrainer:
             pend = ar_start(da.grad)
         ge.backward(dimg, ga.grad, side, sync=self.sync_bn)     # beside D's weight-gradient chains / the D-gradient all-reduce
         join()
-        if ar is not None:
-            ar(ga.grad)
-            if ar_async:
-                ar_finish(pend)
-            else:
+        if ar_async:
+            # G's all-reduce (the only exposed one) runs beside D's optimizer update and re-packing; optimizer_info's step counter is
+            # shared by both arenas: whichever Adam launch comes first ticks it
+            pend_g3 = ar.start(ga.grad)
+            ar_finish(pend)
+            self._adam(da, self.miD, self.viD, self.lr[2], 2, True)
+            on_side(de.repack, 0)
+            ar_finish(pend_g3)
+            self._adam(ga, self.miG, self.viG, self.lr[2], 2, False)
+        else:
+            if ar is not None:
+                ar(ga.grad)
                 ar(da.grad)
-        self._adam(ga, self.miG, self.viG, self.lr[2], 2, True)
-        self._adam(da, self.miD, self.viD, self.lr[2], 2, False)
-        on_side(de.repack, 0)
+            self._adam(ga, self.miG, self.viG, self.lr[2], 2, True)
+            self._adam(da, self.miD, self.viD, self.lr[2], 2, False)
+            on_side(de.repack, 0)
         ge.repack()
         join()
 
