@@ -635,3 +635,19 @@ extern "C" int eg_loss_affine_pxy(const float* o_real, const float* o_trans, int
     EG_LAUNCH_CHECK();
     return 0;
 }
+
+// from_latent_vector_2_affine_para of the MNIST code (MNIST/approximate_rpqmnxy.py:43-60 == utils_rpqmnxy.py:46-63): the regression
+// target of the approximator fit -- theta = c0 pi/9, p,q = 1 + .2 c, m,n = .2 c, x,y = .1 c
+__global__ void affine_para_rpqmnxy_kernel(const float* __restrict__ code, int ldc, int B, float* __restrict__ para) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 7) return;
+    const int b = i / 7, j = i - b * 7;
+    const float c = code[(size_t)b * ldc + j];
+    para[i] = j == 0 ? c * (3.14159265358979323846f / 9.f) : (j <= 2 ? c * 0.2f + 1.f : (j <= 4 ? c * 0.2f : c * 0.1f));
+}
+extern "C" int eg_affine_para_rpqmnxy(const float* code, int ldc, int B, float* para, eg_stream_t s) {
+    EG_REQUIRE(code && para && ldc >= 7 && B > 0, "eg_affine_para_rpqmnxy: bad argument");
+    hipLaunchKernelGGL(affine_para_rpqmnxy_kernel, dim3(cdiv(B * 7, 256)), dim3(256), 0, (hipStream_t)s, code, ldc, B, para);
+    EG_LAUNCH_CHECK();
+    return 0;
+}

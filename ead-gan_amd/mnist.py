@@ -15,7 +15,7 @@ from torch.nn.utils import spectral_norm
 
 from . import ops
 from .celeba import _HipModule, _require_cuda, transformation_2D      # noqa: F401  (same STN warp in both scripts)
-from .engine import ConvRec, Workspace, capture_step, parse_dtype
+from .engine import Arena, ConvRec, Workspace, capture_step, parse_dtype
 from .ops import ACT_LRELU, ACT_NONE, ACT_TANH, EG_F32, OUT_NCHW_F32
 from .trunk import Head, TrunkEngine
 
@@ -521,3 +521,108 @@ class MnistTrainer:
         self.load_inputs(real_imgs, z, code, labels)
         l = self.step_resident().tolist()
         return {"g_loss": l[0], "d_loss": l[1], "info_loss": l[2]}
+
+
+# ================================================================================================
+# Fit of the affine-inverse MLP (MNIST/approximate_rpqmnxy.py): produces the rpqmnxy_approximator.pt the MNIST loop loads frozen
+# ================================================================================================
+class Affine_classifier(nn.Module):
+    """Parameter container with the reference's keys (approximate_rpqmnxy.py:12-31 == utils_rpqmnxy.py:12-34): fc_block.{0,2,4,6,8}."""
+
+    def __init__(self):
+        super().__init__()
+        self.fc_block = nn.Sequential(nn.Linear(6, 256), nn.LeakyReLU(), nn.Linear(256, 256), nn.LeakyReLU(), nn.Linear(256, 256), nn.LeakyReLU(),
+                                      nn.Linear(256, 256), nn.LeakyReLU(), nn.Linear(256, 7))
+
+
+class ApproximatorTrainer:
+    """One call == one iteration of approximate_rpqmnxy.py:119-136: code ~ U(-1,1)^7 -> rows 0,1 of R Z S T (6 numbers) -> MLP
+    6-256-256-256-256-7 (LeakyReLU 0.01) -> MSE vs the affine parameters -> Adam(lr 2e-4, betas (.5,.999)).  The dense layers run as
+    1x1 convolutions over B "pixels" on the implicit-GEMM kernels, the 7-wide head on the dense-head kernels.  After fitting,
+    ``state_dict()`` of the module is the checkpoint; ``install()`` hands it to the regulariser kernel (load_approximator)."""
+
+    def __init__(self, mlp: Affine_classifier, batch_size=128, dtype="f32", lr=2e-4, betas=(0.5, 0.999)):
+        self.mlp, self.B = mlp, batch_size
+        self.dtype = dt = parse_dtype(dtype)
+        p = next(mlp.parameters())
+        _require_cuda(p)
+        dev = p.device
+        self.dev = dev
+        self.arena = Arena(mlp)
+        self.ws = ws = Workspace.get(dev)
+        tdt = ops.torch_dtype(dt)
+        B = batch_size
+        self.kin = 8                                    # 6 inputs padded to the 16-byte vector width
+        self.l = [ConvRec(dt, B, 1, 1, self.kin, 256, 1, 1, 0, device=dev, want_bwd=False, ws=ws)] + \
+                 [ConvRec(dt, B, 1, 1, 256, 256, 1, 1, 0, device=dev, ws=ws) for _ in range(3)]
+        self.head = ConvRec(dt, B, 1, 1, 256, 7, 1, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
+        z = lambda *n, d=torch.float32: torch.zeros(*n, device=dev, dtype=d)
+        self.code, self.theta, self.para = z(B, 7), z(B, 2, 3), z(B, 7)
+        self.x = z(B, self.kin, d=tdt)
+        self.a = [z(B, 256, d=tdt) for _ in range(4)]
+        self.dz = [z(B, 256, d=tdt) for _ in range(4)]
+        self.out, self.dout = z(B, 7), z(B, 7)
+        self.m, self.v = z(self.arena.numel), z(self.arena.numel)
+        self.steps = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.losses = z(4)
+        self.lr, self.betas = lr, betas
+        self.graph = None
+        self.repack()
+
+    def _lin(self, i):
+        return self.mlp.fc_block[2 * i]
+
+    def repack(self):
+        ops.pack_strided(self.dtype, self._lin(0).weight, self.l[0].wp_fwd, 256, 6, self.l[0].Kpad_fwd, 1, 6, 0, 1)
+        for i in (1, 2, 3):
+            self.l[i].pack(self._lin(i).weight)
+        self.head.pack(self._lin(4).weight)
+
+    def _step_body(self):
+        dt, B, ws, ar = self.dtype, self.B, self.ws, self.arena
+        gof = lambda name: ar.grad_of(name)
+        ops.fill_f32(self.losses)
+        ops.theta_rpqmnxy(self.code, 7, B, self.theta)                 # rows 0,1 of get_matrix_rpqmnxy == cat(A[:,0], A[:,1])  (:127-128)
+        ops.affine_para_rpqmnxy(self.code, 7, B, self.para)            # the target is code_input, the AFFINE PARAMETERS (:127,135)
+        ops.cast_pad(dt, self.theta, self.x, B, 6, self.kin)
+        x = self.x
+        for i in range(4):
+            ops.conv_fwd(self.l[i].c, dt, x, self.l[i].wp_fwd, self.a[i], ops.epilogue(bias=self._lin(i).bias, act=ACT_LRELU, slope=0.01))
+            x = self.a[i]
+        ops.dense_small_fwd(dt, x, self.head.wp_fwd, self._lin(4).bias, self.out, B, 256, self.head.Kpad_fwd, 7, ws.small)
+        ops.loss_mse(self.out, 7, 0, 7, B, self.para, 7, 0.0, 1.0, self.losses[0:1], self.dout)
+        ops.fill_f32(ar.grad)
+        ops.dense_small_wgrad(dt, self.dout, self.a[3], gof("fc_block.8.weight"), gof("fc_block.8.bias"), B, 256, 7, 256, 1)
+        ops.dense_small_bwd(dt, self.dout, self.head.wp_fwd, self.a[3], self.dz[3], B, 256, self.head.Kpad_fwd, 7, ACT_LRELU, 0.01)
+        for i in (3, 2, 1, 0):
+            x_in = self.a[i - 1] if i > 0 else self.x
+            ops.bias_grad(dt, self.dz[i], B, 256, ws.small, gof(f"fc_block.{2 * i}.bias"))
+            ns = ops.conv_wgrad(self.l[i].c, dt, x_in, self.dz[i], ws.slab)
+            if i > 0:
+                ops.wgrad_reduce(ws.slab, ns, 256, 256, 256, 1, gof(f"fc_block.{2 * i}.weight"))
+                ops.conv_bwd_data(self.l[i].c, dt, self.dz[i], self.l[i].wp_bwd, self.dz[i - 1], ops.epilogue(mask=self.a[i - 1], mask_act=ACT_LRELU, mask_slope=0.01))
+            else:
+                ops.wgrad_reduce_perm(ws.slab, ns, 256, 256, self.kin, 1, gof("fc_block.0.weight"), 0, 0, 6)
+        ops.adam_step(ar.flat, ar.grad, self.m, self.v, ar.numel, self.lr, self.betas[0], self.betas[1], 1e-8, self.steps[0:1], True)
+        self.repack()
+
+    def capture(self, warmup=False):
+        if warmup:
+            self._step_body()
+        return capture_step(self, self._step_body)
+
+    def step_resident(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._step_body()
+        return self.losses
+
+    def train_step(self, code):
+        """code [B,7] ~ U(-1,1) -> {'affine_loss'}"""
+        self.code.copy_(code, non_blocking=True)
+        return {"affine_loss": float(self.step_resident()[0])}
+
+    def install(self):
+        """hand the fitted weights to the regulariser kernel (what loading rpqmnxy_approximator.pt does in the reference)"""
+        return load_approximator(self.mlp.state_dict(), device=self.dev)

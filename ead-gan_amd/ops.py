@@ -473,3 +473,7 @@ def loss_affine_pxy(o_real, o_trans, ld, c0, B, code, ldc, scale, loss, d_real, 
 
 def warp_affine_zeros(img, theta, out, B, C, H, W):
     lib().call("eg_warp_affine_zeros", _p(img), _p(theta), _p(out), B, C, H, W, _stream())
+
+
+def affine_para_rpqmnxy(code, ldc, B, para):
+    lib().call("eg_affine_para_rpqmnxy", _p(code), ldc, B, _p(para), _stream())

@@ -294,6 +294,9 @@ int eg_u8_to_f32(const unsigned char* x, float* y, size_t n, eg_stream_t s);    
 int eg_loss_affine_rpqxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc,
                          float scale, float* loss, float* d_real, float* d_trans, float* pred_out, eg_stream_t s);
 
+/* regression target of the approximator fit (MNIST/approximate_rpqmnxy.py:43-60,119-136): affine parameters of a code */
+int eg_affine_para_rpqmnxy(const float* code, int ldc, int B, float* para, eg_stream_t s);
+
 /* stage-1 trainer of Encoder_pxy (dSprites/pxy.py:156-191, dSprites/utils_pxy.py:24-66,107-126): theta = rows 0,1 of
  * get_matrix_pxy(code); affine_regularzier_pxy + MSE with fused gradients w.r.t. both codes */
 int eg_theta_pxy(const float* code, int ldc, int B, float* theta, eg_stream_t s);

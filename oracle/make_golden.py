@@ -251,8 +251,21 @@ def make_pxy_color(B=8, steps=3, seed=0):
     print("pxy_color golden:", {k: out[k] for k in names})
 
 
+def make_approximator_fit(steps=5, seed=0):
+    """MNIST/approximate_rpqmnxy.py __main__ (:109-153): losses of the first iterations + 1-step gradient/state fingerprints."""
+    torch.set_num_threads(8)
+    out = {"steps": np.array(steps), "seed": np.array(seed), "B": np.array(128)}
+    g1, _ = rh.run_approximator_main(1, seed)
+    probe_state("M1", g1["affine_classifier"].state_dict(), out)
+    probe_grads("gM1", g1["affine_classifier"], out)
+    _, losses = rh.run_approximator_main(steps, seed)
+    out["affine_loss"] = np.array(losses, dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, f"approximator_fit_s{steps}.npz"), **out)
+    print("approximator fit golden:", out["affine_loss"])
+
+
 MAKERS = {"colored": make_colored, "dsprites": make_dsprites, "celeba": make_celeba, "celeba_affine": make_celeba_affine, "mnist": make_mnist, "mnist_affine": make_mnist_affine,
-          "celeba_curve": make_celeba_curve, "pxy": make_pxy, "pxy_color": make_pxy_color}
+          "celeba_curve": make_celeba_curve, "pxy": make_pxy, "pxy_color": make_pxy_color, "approximator_fit": make_approximator_fit}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

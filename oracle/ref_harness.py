@@ -189,3 +189,33 @@ def colored_opt(batch_size):
     """argparse defaults of colored_dSprites/rp_color.py:40-51 with n_epochs=1."""
     return argparse.Namespace(n_epochs=1, batch_size=batch_size, lr=0.0002, b1=0.5, b2=0.999, n_cpu=8, latent_dim=200, code_dim=7, n_classes=3,
                               img_size=64, channels=3, sample_interval=1000)
+
+
+def run_approximator_main(steps: int, seed: int):
+    """MNIST/approximate_rpqmnxy.py: its ``__main__`` block (:109-153) fits the affine-inverse MLP.  The module is executed with the loop
+    bound 20001 replaced by ``steps`` and a recorder call appended to the loop body; returns (globals, [affine_loss per iteration])."""
+    path = os.path.join(REF_ROOT, "MNIST/approximate_rpqmnxy.py")
+    tree = ast.parse(open(path).read())
+    losses = []
+    hits = 0
+    for node in ast.walk(tree):
+        if isinstance(node, ast.For) and isinstance(node.iter, ast.Call) and getattr(node.iter.func, "id", "") == "range" \
+                and node.iter.args and isinstance(node.iter.args[0], ast.Constant) and node.iter.args[0].value == 20001:
+            node.iter.args[0] = ast.Constant(steps)
+            node.body.append(ast.parse("__record__(affine_loss)").body[0])
+            hits += 1
+    assert hits == 1, "training loop of approximate_rpqmnxy.py not found"
+    ast.fix_missing_locations(tree)
+    g = _base_globals(None)
+    g.update(__name__="__main__", __record__=lambda v: losses.append(float(v)))
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp(prefix="eadgan_ref_")
+    try:
+        os.chdir(tmp)
+        with _cpu_only_patches():
+            torch.manual_seed(seed)
+            np.random.seed(seed)
+            exec(compile(tree, path, "exec"), g)
+    finally:
+        os.chdir(cwd)
+    return g, losses

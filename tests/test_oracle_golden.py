@@ -174,3 +174,18 @@ def test_pxy_color_stage1_step_matches_reference():
         if i == 0:
             check_probes("gP1", {k: v.grad for k, v in orc.P.items() if getattr(v, "grad", None) is not None}, gold, 1e-2, 1e-9, noise_floor=1e-8)
             check_probes("P1", orc.P, gold, 2e-3, 3e-4)
+
+
+def test_approximator_fit_matches_reference():
+    """MNIST/approximate_rpqmnxy.py (fit of the affine-inverse MLP): oracle vs the script's __main__ loop run through the harness"""
+    gold = np.load(os.path.join(GOLDEN, "approximator_fit_s5.npz"))
+    steps, seed, B = int(gold["steps"]), int(gold["seed"]), int(gold["B"])
+    torch.set_num_threads(8)
+    orc = mo.ApproximatorOracle(seed=seed)
+    rng = np.random.RandomState(seed)
+    for i in range(steps):
+        out = orc.train_step(mo.draw_approximator_inputs(rng, B))
+        assert abs(out["affine_loss"] - gold["affine_loss"][i]) < (2e-6, 1e-4, 3e-4, 1e-3, 2e-3)[i], (i, out, gold["affine_loss"][i])
+        if i == 0:
+            check_probes("gM1", {k: v.grad for k, v in orc.mlp.items()}, gold, 1e-2, 1e-9, noise_floor=1e-8)
+            check_probes("M1", {k: v.detach() for k, v in orc.mlp.items()}, gold, 2e-3, 3e-4)
