@@ -6,6 +6,6 @@ hyphen, so import it with ``importlib.import_module("ead-gan_amd")`` or through 
 ``eadgan`` (``import eadgan``).
 """
 from . import _lib, engine, ops            # noqa: F401
-from . import celeba, colored, dp, dsprites, mnist, trunk     # noqa: F401
+from . import celeba, colored, dp, dsprites, mnist, sampling, trunk     # noqa: F401
 
 __all__ = ["ops", "engine", "celeba", "mnist", "dsprites", "colored", "trunk", "dp"]

@@ -477,3 +477,19 @@ def warp_affine_zeros(img, theta, out, B, C, H, W):
 
 def affine_para_rpqmnxy(code, ldc, B, para):
     lib().call("eg_affine_para_rpqmnxy", _p(code), ldc, B, _p(para), _stream())
+
+
+def make_grid(img, B, C, H, W, nrow, padding, pad_value, rng2, grid):
+    lib().call("eg_make_grid", _p(img), B, C, H, W, nrow, padding, pad_value, _p(rng2), _p(grid), _stream())
+
+
+def minmax_ws_floats():
+    return lib().query("eg_minmax_ws_floats")
+
+
+def minmax_f32(x, n, ws, out2):
+    lib().call("eg_minmax_f32", _p(x), n, _p(ws), _p(out2), _stream())
+
+
+def quantize_u8(x, C, H, W, rng2, out):
+    lib().call("eg_quantize_u8", _p(x), C, H, W, _p(rng2), _p(out), _stream())

@@ -306,6 +306,21 @@ int eg_loss_affine_pxy(const float* o_real, const float* o_trans, int ld, int c0
 /* transformation_2D with grid_sample(padding_mode='zeros') (colored_dSprites/pxy_color.py:86-92) */
 int eg_warp_affine_zeros(const float* img, const float* theta, float* out, int B, int C, int H, int W, eg_stream_t s);
 
+/* --- image grids of the sampling tools: torchvision.utils.make_grid / save_image (0.8.2, not vendored) as the reference
+ * calls them -- MNIST/EAD-GAN_rpqmnxy.py:281-330, MNIST/generate_image.py:122-138, celebA/EAD-GAN_celebA.py:238-287,
+ * celebA/gen_imgs.py:183-199, dSprites/rp.py:299-353, colored_dSprites/rp_color.py:297-353.
+ * eg_make_grid : img [B,C,H,W] fp32 -> grid [Cg][ymaps*(H+padding)+padding][xmaps*(W+padding)+padding] fp32, xmaps = min(nrow,B),
+ *   ymaps = ceil(B/xmaps), Cg = 3 when C == 1 (replicated) else C; gaps and unused cells = pad_value.  range != NULL ({lo, hi} on the
+ *   device, e.g. from eg_minmax_f32): image pixels are normalised like eg_quantize_u8 does while tiling (make_grid(normalize=True)).
+ * eg_minmax_f32: out2 = {min, max} of x[0..n) (the normalize=True range); ws: eg_minmax_ws_floats() floats.
+ * eg_quantize_u8: x [C][H][W] fp32 -> out [H][W][C] uint8 = clamp(v' * 255 + 0.5, 0, 255) truncated, v' = v or, with range = {lo, hi}
+ *   on the device, (clamp(v, lo, hi) - lo) / (hi - lo + 1e-5).  Every step separately rounded: bytes equal the CPU restatement's. */
+int eg_make_grid(const float* img, int B, int C, int H, int W, int nrow, int padding, float pad_value, const float* range,
+                 float* grid, eg_stream_t s);
+size_t eg_minmax_ws_floats(void);
+int eg_minmax_f32(const float* x, size_t n, float* ws, float* out2, eg_stream_t s);
+int eg_quantize_u8(const float* x, int C, int H, int W, const float* range, unsigned char* out, eg_stream_t s);
+
 /* --- device-side input pipeline: replaces the per-iteration host work of the reference loops -- DataLoader + PIL
  * RandomHorizontalFlip / ToTensor / Normalize (celebA/EAD-GAN_celebA.py:194-206, MNIST/EAD-GAN_rpqmnxy.py:235-246) and the numpy draws
  * of z / code / labels (:308-317; :351-357) -- so that a captured hipGraph feeds itself.  Philox4x32-10, counter = (element, *step,

@@ -264,8 +264,34 @@ def make_approximator_fit(steps=5, seed=0):
     print("approximator fit golden:", out["affine_loss"])
 
 
+SAMPLE_SCRIPTS = {"mnist_train": ("MNIST/EAD-GAN_rpqmnxy.py", "mnist", (1, 32, 32), "train"),
+                  "mnist_tool": ("MNIST/generate_image.py", "mnist", (1, 32, 32), "tool2"),
+                  "celeba_train": ("celebA/EAD-GAN_celebA.py", "celeba", (3, 64, 64), "train"),
+                  "celeba_tool": ("celebA/gen_imgs.py", "celeba", (3, 64, 64), "tool0"),
+                  "dsprites_train": ("dSprites/rp.py", "dsprites", (1, 64, 64), "train"),
+                  "colored_train": ("colored_dSprites/rp_color.py", "colored", (3, 64, 64), "train")}
+
+
+def make_sample_plans(n=10):
+    """What each script's own sample_image feeds its generator and writer: the functions are run with recording stand-ins
+    (np.random seeded 0 for the static-sample z draw); stored per kind: every generator input and the (path, nrow, normalize, gridded) list."""
+    import json
+    out = {"n": np.array(n)}
+    for kind, (path, optname, shape, call) in SAMPLE_SCRIPTS.items():
+        opt = getattr(rh, optname + "_opt")(16)
+        real = torch.zeros(n * n, *shape)
+        args = {"train": (real, real, n, 0), "tool2": (n, 0), "tool0": ()}[call]
+        calls, saves = rh.record_sample_image(path, opt, args, shape)
+        for i, c in enumerate(calls):
+            for j, t in enumerate(c):
+                out[f"{kind}/call{i}/in{j}"] = t.numpy()
+        out[f"{kind}/saves"] = np.array(json.dumps([[s[0], s[1], s[2], s[3].startswith("grid")] for s in saves]))
+        print("sample plan", kind, len(calls), "generator calls,", len(saves), "files")
+    np.savez_compressed(os.path.join(GOLD, "sample_plans.npz"), **out)
+
+
 MAKERS = {"colored": make_colored, "dsprites": make_dsprites, "celeba": make_celeba, "celeba_affine": make_celeba_affine, "mnist": make_mnist, "mnist_affine": make_mnist_affine,
-          "celeba_curve": make_celeba_curve, "pxy": make_pxy, "pxy_color": make_pxy_color, "approximator_fit": make_approximator_fit}
+          "celeba_curve": make_celeba_curve, "pxy": make_pxy, "pxy_color": make_pxy_color, "approximator_fit": make_approximator_fit, "sample_plans": make_sample_plans}
 
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)

@@ -219,3 +219,51 @@ def run_approximator_main(steps: int, seed: int):
     finally:
         os.chdir(cwd)
     return g, losses
+
+
+def record_sample_image(rel_path: str, opt, call_args, img_shape):
+    """Run the reference's ``sample_image`` (the PNG visualisation of the training scripts / generate_image.py / gen_imgs.py) with
+    recording stand-ins for the generator and the torchvision writers.  Only ``sample_image`` / ``to_categorical`` and the module-level
+    ``static_*`` definitions of the file are executed.  Returns (generator inputs per call, save_image calls as (path, nrow,
+    normalize, source) where source names which tensor was written)."""
+    path = os.path.join(REF_ROOT, rel_path)
+    keep = []
+    for n in ast.parse(open(path).read()).body:
+        if isinstance(n, ast.FunctionDef) and n.name in ("sample_image", "to_categorical"):
+            keep.append(n)
+        elif isinstance(n, ast.Assign) and any(isinstance(t, ast.Name) and t.id.startswith("static_") for t in n.targets):
+            keep.append(n)
+        elif isinstance(n, ast.For) and "static_label.append" in ast.unparse(n):
+            keep.append(n)
+    gen_calls, saves = [], []
+
+    class _Tagged(torch.Tensor):
+        pass
+
+    def tag(t, name):
+        t = t.as_subclass(_Tagged)
+        t.src = name
+        return t
+
+    def generator(*inputs):
+        gen_calls.append([i.detach().clone().float() for i in inputs])
+        return tag(torch.zeros(inputs[0].shape[0], *img_shape), f"gen{len(gen_calls) - 1}")
+
+    def src_of(t):
+        return getattr(t, "src", None) or getattr(getattr(t, "data", None), "src", "arg")
+
+    def make_grid(t, nrow=8, **k):
+        return tag(torch.zeros(1), f"grid({src_of(t)},nrow={nrow})")
+
+    def save_image(t, fp, nrow=8, normalize=False, **k):
+        saves.append((str(fp), int(nrow), bool(normalize), src_of(t)))
+
+    g = _base_globals(opt)
+    g.update(generator=generator, make_grid=make_grid, save_image=save_image)
+    state = np.random.get_state()
+    with _cpu_only_patches():
+        exec(compile(ast.Module(keep, []), path, "exec"), g)
+        np.random.seed(0)
+        g["sample_image"](*call_args)
+    np.random.set_state(state)
+    return gen_calls, saves

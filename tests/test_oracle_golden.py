@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import GOLDEN
@@ -189,3 +190,64 @@ def test_approximator_fit_matches_reference():
         if i == 0:
             check_probes("gM1", {k: v.grad for k, v in orc.mlp.items()}, gold, 1e-2, 1e-9, noise_floor=1e-8)
             check_probes("M1", {k: v.detach() for k, v in orc.mlp.items()}, gold, 2e-3, 3e-4)
+
+
+def _plan_matches_golden(plan_of, gold, kind):
+    import json
+    n = int(gold["n"])
+    plan = plan_of(kind, n)
+    saves = json.loads(str(gold[f"{kind}/saves"]))
+    assert [p[0] for p in plan] == [s[0].rsplit("/", 1)[0] for s in saves]
+    assert [p[2] for p in plan] == [s[3] for s in saves]
+    assert all(s[1] == n and s[2] is True for s in saves)           # every file: nrow = n, normalize=True
+    calls = [p[1] for p in plan if p[1] is not None]
+    assert len(calls) == len([k for k in gold.files if k.startswith(kind + "/call") and k.endswith("/in0")])
+    for i, inputs in enumerate(calls):
+        for j, a in enumerate(inputs):
+            g = gold[f"{kind}/call{i}/in{j}"]
+            assert tuple(a.shape) == g.shape and np.array_equal(np.asarray(a, dtype=np.float32), g), (kind, i, j)
+        assert f"{kind}/call{i}/in{len(inputs)}" not in gold.files
+
+
+@pytest.mark.parametrize("kind", ["mnist_train", "mnist_tool", "celeba_train", "celeba_tool", "dsprites_train", "colored_train"])
+def test_sample_plans_match_reference(kind):
+    """sample_image of the six scripts: the oracle's plan AND the product's host-side plan equal what the reference functions
+    fed their generator / writer (recorded by oracle/ref_harness.record_sample_image into tests/golden/sample_plans.npz)"""
+    import importlib
+    from oracle import sampling_oracle as so
+    gold = np.load(os.path.join(GOLDEN, "sample_plans.npz"))
+    _plan_matches_golden(lambda k, n: [(p["path"], p["inputs"], p["gridded"]) for p in so.sample_plan(k, n, np.random.RandomState(0))], gold, kind)
+    sampling = importlib.import_module("ead-gan_amd.sampling")
+    _plan_matches_golden(lambda k, n: sampling.sample_inputs(k, n, np.random.RandomState(0)), gold, kind)
+
+
+def test_grid_oracle_hand_checked():
+    """make_grid / save_image restatement (torchvision 0.8.2, parity unpinned: see oracle/sampling_oracle.py) on cases small enough to
+    verify by hand: geometry, single-channel replication, where normalisation applies, rounding of the quantiser"""
+    from oracle import sampling_oracle as so
+    t = torch.arange(5 * 1 * 2 * 3, dtype=torch.float32).view(5, 1, 2, 3)
+    g = so.make_grid(t, nrow=3, padding=2)
+    assert g.shape == (3, 2 * 4 + 2, 3 * 5 + 2)
+    assert torch.equal(g[0], g[1]) and torch.equal(g[1], g[2])
+    assert torch.equal(g[0, 2:4, 2:5], t[0, 0]) and torch.equal(g[0, 6:8, 7:10], t[4, 0])
+    assert float(g[0, :2].abs().sum()) == 0 and float(g[0, 6:8, 12:15].abs().sum()) == 0      # border and the unused sixth cell
+    assert so.make_grid(t[:1], nrow=3).shape == (3, 2, 3)                                           # one image: no border
+    # 4-D + normalize: images span [0, 1), gaps stay 0 -> black; value k/29 -> floor(k/(29+1e-5)*255 + .5)
+    b = so.to_uint8_hwc(t, nrow=3, normalize=True)
+    assert b.shape == (10, 17, 3) and b[0, 0, 0] == 0 and b[2, 2, 0] == 0 and b[7, 9, 0] == 255 and b[7, 8, 0] == int(28 / (29 + 1e-5) * 255 + 0.5) and b[2, 4, 1] == int(2 / (29 + 1e-5) * 255 + 0.5)
+    # grid first, then normalize=True: the gaps take part -> with images in [1, 2] the gaps (0) are the minimum, images start at 127/128
+    b2 = so.to_uint8_hwc(so.make_grid(t / 29 + 1, nrow=3), nrow=3, normalize=True)
+    assert b2[0, 0, 0] == 0 and b2[2, 2, 0] == int(np.float32(1) / np.float32(2 + 1e-5) * 255 + 0.5) and b2[7, 9, 0] == 255
+
+
+def test_png_encoder_roundtrip():
+    """host logic: the PNG container written for the grids decodes (PIL, independent decoder) to the same bytes"""
+    import importlib
+    import io
+    PIL = pytest.importorskip("PIL.Image")
+    sampling = importlib.import_module("ead-gan_amd.sampling")
+    rng = np.random.RandomState(0)
+    for shape in ((7, 5, 3), (64, 33, 3), (9, 4, 1)):
+        a = rng.randint(0, 256, shape).astype(np.uint8)
+        im = np.asarray(PIL.open(io.BytesIO(sampling.encode_png(a))))
+        assert np.array_equal(im.reshape(shape), a)
