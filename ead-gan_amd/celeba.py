@@ -135,13 +135,12 @@ class _GenEngine:
         dt, B, W, ws, gen = self.dtype, self.B, G_WIDTHS, self.ws, self.gen
         gof = lambda name: gen.arena.grad_of(name, grad)
         C, S = gen.channels, self.img.shape[-1]
-        def wgrad_side(fn, lane):
+        def wgrad_side(fn, lane):                       # issued by the flush() that follows the next main-stream kernel (engine.SideStream)
             if side is None:
                 fn(ws)
             else:
-                ln = side.fork(lane)
-                with ln:
-                    fn(ln.ws)
+                side.defer(lane, fn)
+        flush = side.flush if side is not None else (lambda: None)
 
         # tanh backward fused with the bias gradient of the last ConvTranspose2d
         ops.act_grad_mul_bias_nchw(dimg, self.img, self.dimg_z, B, C, S * S, ACT_TANH, 0.0, ws.small, gof("conv_blocks.10.bias"))
@@ -153,6 +152,7 @@ class _GenEngine:
             ops.wgrad_reduce(wsw.slab, ns, W[3], W[3], self.kp, 1, gof("conv_blocks.10.weight"))
         wgrad_side(l4_wgrad, 0)
         ops.conv_fwd(self.l4p.c, dt, self.patches, self.l4p.wp_fwd, self.da[2], None)
+        flush()
         # L3..L1
         for i, idx in ((2, 7), (1, 4), (0, 1)):
             r = self.mid[i]
@@ -175,13 +175,14 @@ class _GenEngine:
                 ops.bias_grad(dt, self.dz[i], M, W[i + 1], wsw.small, gof(f"conv_blocks.{idx}.bias"))
             wgrad_side(mid_wgrad, i + 1)
             ops.conv_fwd(r.c, dt, self.dz[i], r.wp_fwd, self.da[i - 1] if i > 0 else self.dh0, None)
+            flush()
 
         # L0
         def l0_wgrad(wsw):
             ns = ops.conv_wgrad(self.l0w.c, dt, self.dh0, self.inp, wsw.slab)
             ops.wgrad_reduce(wsw.slab, ns, self.cpad, self.cin, W[0], 16, gof("conv_blocks.0.weight"))
             ops.bias_grad(dt, self.dh0, B * 16, W[0], wsw.small, gof("conv_blocks.0.bias"))
-        wgrad_side(l0_wgrad, 0)
+        wgrad_side(l0_wgrad, 0)                         # stays pending: the caller's next main-stream kernel goes first
 
 
 class _HipModule(nn.Module):
@@ -414,13 +415,12 @@ class _DiscEngine:
         g = self.geo[T]
         sl = lambda buf: buf[t0 * (buf.shape[0] // self.NT):]
         K = 16 * W[3]
-        def wgrad_side(fn, lane):
+        def wgrad_side(fn, lane):                       # issued by the flush() that follows the next main-stream kernel (engine.SideStream)
             if side is None:
                 fn(ws)
             else:
-                ln = side.fork(lane)
-                with ln:
-                    fn(ln.ws)
+                side.defer(lane, fn)
+        flush = side.flush if side is not None else (lambda: None)
 
         if need_wgrad:
             def head_wgrad(wsw):
@@ -432,6 +432,7 @@ class _DiscEngine:
         # dzs_3 = (W5^T dout) * lrelu'(a3) / sigma_3[tape]
         ops.dense_small_bwd(dt, dout, self.head.wp_fwd, sl(self.a[3]), sl(self.dz[3]), T * B, K, self.head.Kpad_fwd, self.nout, ACT_LRELU, LRELU_SLOPE,
                             self.sigma[3][t0:], B)
+        flush()
         for i in (3, 2, 1, 0):
             m = self._m(i)
             geo = g["mid"][i - 1] if i > 0 else g["l1p"]
@@ -450,10 +451,12 @@ class _DiscEngine:
                 ops.conv_bwd_data(geo, dt, sl(self.dz[i]), self.mid[i - 1].wp_bwd, sl(self.dz[i - 1]),
                                   ops.epilogue(sigma=self.sigma[i - 1][t0:], sigma_rows=self.rows(i), mask=sl(self.a[i - 1]), mask_act=ACT_LRELU,
                                                mask_slope=LRELU_SLOPE))
+                flush()
         if need_dimg:
             ops.conv_bwd_data(self.l1.c, dt, sl(self.dz[0]), self.l1.wp_bwd, self.dimg, ops.epilogue(out_mode=OUT_NCHW_F32))
+            flush()
             return self.dimg
-        return None
+        return None                                     # layer 0's chain stays pending: the caller's next main-stream kernel goes first
 
 
 class Discriminator(_HipModule):
@@ -674,121 +677,143 @@ class CelebATrainer:
         ops.adam_step(arena.flat, arena.grad, m, v, arena.numel, lr, self.betas[0], self.betas[1], 1e-8, self.steps[slot:slot + 1], tick)
 
     def _step_body(self):
+        if self.side is not None:
+            return self._step_body_pipelined()
+        return self._step_body_serial()
+
+    def _inputs_head(self):
+        G, B = self.G, self.B
+        ops.fill_f32(self.losses)
+        # A = get_matrix(code[:, :5]); scaled = trans_2D(real, A[:, 0:2])           (:325-327)
+        ops.theta_rpqxy(self.code, G.code_dim, B, self.theta)
+        ops.warp_affine(self.real, self.theta, self.scaled, B, G.channels, G.img_size, G.img_size)
+
+    def _reduce(self, flat):
+        """gradient average over the ranks, on the CURRENT stream (the optimizer lane: only that lane waits for the collective)"""
+        ar = self.allreduce
+        if ar is None:
+            return
+        if hasattr(ar, "start"):
+            ar.finish(ar.start(flat))
+        else:
+            ar(flat)
+
+    def _step_body_serial(self):
+        """one stream, program order of the reference loop body (overlap=False; the pipelined body below is bit-identical)"""
         G, D, ge, de, B = self.G, self.D, self.ge, self.de, self.B
         ga, da = G.arena, D.arena
         cd, nc = G.code_dim, G.n_classes
         lcat, lcon, laff = self.lam
-        ops.fill_f32(self.losses)
-        # A = get_matrix(code[:, :5]); scaled = trans_2D(real, A[:, 0:2])           (:325-327)
-        ops.theta_rpqxy(self.code, cd, B, self.theta)
-        ops.warp_affine(self.real, self.theta, self.scaled, B, G.channels, G.img_size, G.img_size)
+        self._inputs_head()
+        # ---- 1) generator adversarial step (:334-345) ----
+        ops.fill_f32(ga.grad)
+        gen = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
+        out = de.forward([gen], 2)
+        ops.loss_bce_sigmoid(out, 19, 0, B, 1.0, 1.0, self.losses[0:1], self.dout[2 * B:])
+        dimg = de.backward(2, 1, self.dout[2 * B:], da.grad, need_wgrad=False, need_dimg=True)
+        ge.backward(dimg, ga.grad, None, sync=self.sync_bn)
+        self._reduce(ga.grad)
+        self._adam(ga, self.mG, self.vG, self.lr[0], 0, True)
+        ge.repack()
+        # ---- 2) discriminator step (:353-366); gen is the (detached) output of step 1; D(scaled) then D(gen), batched ----
+        ops.fill_f32(da.grad)
+        out = de.forward([self.scaled, gen], 0)
+        ops.loss_bce_sigmoid(out[:B], 19, 0, B, 1.0, 0.5, self.losses[1:2], self.dout[:B])
+        ops.loss_bce_sigmoid(out[B:], 19, 0, B, 0.0, 0.5, self.losses[1:2], self.dout[B:2 * B])
+        de.backward(0, 2, self.dout[:2 * B], da.grad)
+        self._reduce(da.grad)
+        self._adam(da, self.mD, self.vD, self.lr[1], 1, True)
+        de.repack()
+        ops.fill_f32(da.grad)
+        # ---- 3) info + affine step (:375-401): D(gen), D(scaled), D(real) batched as tapes 0,1,2 ----
+        ops.fill_f32(ga.grad)
+        gen = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
+        out = de.forward([gen, self.scaled, self.real], 0)
+        o_gen, o_trans, o_real = out[:B], out[B:2 * B], out[2 * B:]
+        ops.loss_mse(o_gen, 19, 1, cd, B, self.code, cd, 0.0, lcon, self.losses[2:3], self.dout[:B])
+        ops.loss_ce_softmaxed(o_gen, 19, cd + 1, nc, B, self.labels, lcat, self.losses[2:3], self.dout[:B])
+        ops.loss_affine_rpqxy(o_real, o_trans, 19, 1, B, self.code, cd, laff, self.losses[2:3], self.dout[2 * B:], self.dout[B:2 * B])
+        dimg = de.backward(0, 3, self.dout, da.grad, need_dimg=True)
+        ge.backward(dimg, ga.grad, None, sync=self.sync_bn)
+        self._reduce(da.grad)
+        self._reduce(ga.grad)
+        self._adam(da, self.miD, self.viD, self.lr[2], 2, True)     # optimizer_info's step counter is shared by both arenas
+        self._adam(ga, self.miG, self.viG, self.lr[2], 2, False)
+        de.repack()
+        ge.repack()
+
+    def _step_body_pipelined(self):
+        """The same iteration on five streams.  Main stream: the forward / backward-data chain of the three sub-steps, back to back.
+        Lanes 0,1: weight-gradient GEMMs with their reductions.  Preparation lane: the next sub-step's power iterations and patch
+        rows.  Optimizer lane:
+        per network, behind ALL of its weight-gradient chains: (all-reduce over the ranks ->) Adam -> gradient zeroing -> re-packing.
+        The main stream never waits for an optimizer update it does not need: step 2 neither reads nor writes G, step 3 starts with
+        the generator forward, which does not read D; it waits for single events (``mark`` / ``wait``) instead of joining every lane."""
+        G, D, ge, de, B = self.G, self.D, self.ge, self.de, self.B
+        ga, da = G.arena, D.arena
+        cd, nc = G.code_dim, G.n_classes
+        lcat, lcon, laff = self.lam
         side = self.side
-        prep = side is not None
+        side.begin_step()
+        evs = {}
 
-        def on_side(fn, lane=0):                        # fn's launches go to a side lane, behind everything enqueued so far
-            if side is None:
-                fn()
-            else:
-                with side.fork(lane):
-                    fn()
+        def update(arena, m, v, lr, slot, tick, zero, repack, key=None, key_w=None):
+            def fn(_ws):
+                self._reduce(arena.grad)
+                self._adam(arena, m, v, lr, slot, tick)
+                if key_w:
+                    evs[key_w] = side.mark()            # master weights are new
+                if zero:
+                    ops.fill_f32(arena.grad)
+                repack()
+                if key:
+                    evs[key] = side.mark()              # panels are new, gradients zeroed
+            return fn
 
-        join = side.join if side is not None else (lambda: None)
-        # Data parallel: every gradient all-reduce is started asynchronously (RCCL's own stream) and finished as late as the data
-        # flow allows: G's of step 1 runs beside the whole of step 2 (which neither reads nor writes G), D's of step 2 beside the
-        # generator forward of step 3, D's of step 3 beside the generator backward.  Only the last one (G, step 3) is exposed.
-        ar = self.allreduce
-        ar_async = ar is not None and hasattr(ar, "start")
-
-        def ar_start(flat):
-            if ar is None:
-                return None
-            if ar_async:
-                return ar.start(flat)
-            ar(flat)
-            return None
-
-        def ar_finish(h):
-            if h is not None:
-                ar.finish(h)
-
+        self._inputs_head()
         # ---- 1) generator adversarial step (:334-345); D(gen) lives in tape slot 2 so that step 2's tapes can be prepared meanwhile ----
         ops.fill_f32(ga.grad)
         gen = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
         out = de.forward([gen], 2)
-        # step 2's power iterations (they follow step 1's in the u/v chain) and patch rows, beside the rest of step 1
-        if prep:
-            on_side(lambda: de.prepare(0, [self.scaled, gen]), 1)
+
+        def prep2(_ws):                                 # step 2's power iterations (after step 1's in the u/v chain) and patch rows
+            de.prepare(0, [self.scaled, gen])
+            evs["prep2"] = side.mark()
+        side.defer_prep(prep2)
         ops.loss_bce_sigmoid(out, 19, 0, B, 1.0, 1.0, self.losses[0:1], self.dout[2 * B:])
+        side.flush()
         dimg = de.backward(2, 1, self.dout[2 * B:], da.grad, need_wgrad=False, need_dimg=True)
         ge.backward(dimg, ga.grad, side, sync=self.sync_bn)
-        join()
-        pend_g = ar_start(ga.grad)
-
-        def update_g():
-            ar_finish(pend_g)
-            self._adam(ga, self.mG, self.vG, self.lr[0], 0, True)
-            on_side(ge.repack, 0)                       # G's panels are next read in step 3
-        if not ar_async:
-            update_g()
+        side.defer_opt(update(ga, self.mG, self.vG, self.lr[0], 0, True, True, ge.repack, key="g"))     # beside the whole of step 2
         # ---- 2) discriminator step (:353-366); gen is the (detached) output of step 1; D(scaled) then D(gen), batched ----
         ops.fill_f32(da.grad)
-        out = de.forward([self.scaled, gen], 0, prepared=(True, True) if prep else None)
+        side.flush()
+        side.wait(evs["prep2"])
+        out = de.forward([self.scaled, gen], 0, prepared=(True, True))
         ops.loss_bce_sigmoid(out[:B], 19, 0, B, 1.0, 0.5, self.losses[1:2], self.dout[:B])
         ops.loss_bce_sigmoid(out[B:], 19, 0, B, 0.0, 0.5, self.losses[1:2], self.dout[B:2 * B])
         de.backward(0, 2, self.dout[:2 * B], da.grad, side=side)
-        join()
-        if ar_async:
-            update_g()
-        pend_d = ar_start(da.grad)
+        side.defer_opt(update(da, self.mD, self.vD, self.lr[1], 1, True, True, de.repack, key_w="dw"))  # beside step 3's generator forward
 
-        def update_d():
-            ar_finish(pend_d)
-            self._adam(da, self.mD, self.vD, self.lr[1], 1, True)
-            # beside what follows on the main stream: D's panels, step 3's three power iterations, the patch rows of scaled / real
-            on_side(de.repack, 0)
-            if prep:
-                on_side(lambda: de.prepare(0, [None, self.scaled, self.real]), 1)
-            ops.fill_f32(da.grad)
-        if not ar_async:
-            update_d()
+        def prep3(_ws):                                 # step 3's three power iterations (new weights), patch rows of scaled / real
+            side.wait(evs["dw"])
+            de.prepare(0, [None, self.scaled, self.real])
+        side.defer_prep(prep3)
         # ---- 3) info + affine step (:375-401): D(gen), D(scaled), D(real) batched as tapes 0,1,2 ----
-        ops.fill_f32(ga.grad)
-        if ar_async:
-            join()                                      # G's panels were re-packed a moment ago (update_g)
+        side.wait(evs["g"])                             # G's panels and zeroed gradients (optimizer lane, step 1)
         gen = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
-        if ar_async:
-            update_d()
-        join()
-        out = de.forward([gen, self.scaled, self.real], 0, prepared=(False, True, True) if prep else None)
+        side.join()                                     # D's panels, power iterations, patch rows
+        out = de.forward([gen, self.scaled, self.real], 0, prepared=(False, True, True))
         o_gen, o_trans, o_real = out[:B], out[B:2 * B], out[2 * B:]
         ops.loss_mse(o_gen, 19, 1, cd, B, self.code, cd, 0.0, lcon, self.losses[2:3], self.dout[:B])
         ops.loss_ce_softmaxed(o_gen, 19, cd + 1, nc, B, self.labels, lcat, self.losses[2:3], self.dout[:B])
         ops.loss_affine_rpqxy(o_real, o_trans, 19, 1, B, self.code, cd, laff, self.losses[2:3], self.dout[2 * B:], self.dout[B:2 * B])
         dimg = de.backward(0, 3, self.dout, da.grad, need_dimg=True, side=side)
-        pend = None
-        if ar_async:
-            join()                                      # D's weight gradients are complete
-            pend = ar_start(da.grad)
-        ge.backward(dimg, ga.grad, side, sync=self.sync_bn)     # beside D's weight-gradient chains / the D-gradient all-reduce
-        join()
-        if ar_async:
-            # G's all-reduce (the only exposed one) runs beside D's optimizer update and re-packing; optimizer_info's step counter is
-            # shared by both arenas: whichever Adam launch comes first ticks it
-            pend_g3 = ar.start(ga.grad)
-            ar_finish(pend)
-            self._adam(da, self.miD, self.viD, self.lr[2], 2, True)
-            on_side(de.repack, 0)
-            ar_finish(pend_g3)
-            self._adam(ga, self.miG, self.viG, self.lr[2], 2, False)
-        else:
-            if ar is not None:
-                ar(ga.grad)
-                ar(da.grad)
-            self._adam(ga, self.miG, self.viG, self.lr[2], 2, True)
-            self._adam(da, self.miD, self.viD, self.lr[2], 2, False)
-            on_side(de.repack, 0)
-        ge.repack()
-        join()
+        # D's update beside the generator backward; it ticks optimizer_info's counter (shared by both arenas), G's does not
+        side.defer_opt(update(da, self.miD, self.viD, self.lr[2], 2, True, False, de.repack))
+        ge.backward(dimg, ga.grad, side, sync=self.sync_bn)
+        side.defer_opt(update(ga, self.miG, self.viG, self.lr[2], 2, False, False, ge.repack))
+        side.join()
 
     # -- public API -----------------------------------------------------------------------------------
     def import_adam_state(self, opt_G, opt_D, opt_info):

@@ -2,6 +2,8 @@
 workspace, and conv-layer records (geometry + packed weight panels) over the C ABI in :mod:`ops`."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import ops
@@ -116,6 +118,19 @@ class SideStream:
 
     def __init__(self, device, like: "Workspace", lanes: int = 2):
         self.lanes = [_Lane(device, like) for _ in range(lanes)]
+        # optimizer lane: (gradient all-reduce ->) Adam -> gradient zeroing -> panel re-packing of one network, behind ALL of its
+        # weight-gradient chains, while the main stream is already in the next sub-step.  Not part of the round robin.
+        self.opt = _Lane(device, like)
+        # preparation lane: the next sub-step's power iterations and patch rows.  It waits for optimizer-lane events (new weights), so
+        # the optimizer lane must never wait for it: hipStreamEndCapture of ROCm 7.2 segfaults on such a stream-level back edge
+        # (X waited for Y, later Y waits for X) even though the node graph is acyclic -- profiles/scripts/capture_patterns.py.
+        self.prep = _Lane(device, like)
+        self._pending = []
+        self._flushing = False
+        # issue order of forked work (see defer()): "0" at once (side work captured before the main stream's next kernel), "1" always
+        # after it, "once" at once for a lane's first fork of the step and after it from then on
+        self.deferred = os.environ.get("EG_DEFER", "0")
+        self._entered = set()
 
     def lane(self, i: int) -> _Lane:
         return self.lanes[i % len(self.lanes)]
@@ -127,9 +142,83 @@ class SideStream:
         ln.stream.wait_event(ev)
         return ln
 
-    def join(self):
-        cur = torch.cuda.current_stream()
+    # Deferred issue.  hipGraph's executor keeps the FIRST-created child of a node on the node's own HW queue; every other child moves to
+    # another queue behind a cross-queue wait (10-18 us on MI355X, measured: profiles/r01_timeline_notes.md).  A fork therefore records
+    # its event at once but its launches are issued by the next flush(), which the caller places right AFTER the next main-stream
+    # kernel: the critical chain stays on one queue and the hop lands on the side work.  Dependencies are unchanged (the events).
+    def defer(self, i: int, fn):
+        """lane i runs fn(lane_workspace) behind everything enqueued on the current stream so far"""
+        self._pending.append(("lane", self.lane(i), self.mark(), fn))
+        self._issue(("lane", i % len(self.lanes)))
+
+    def defer_opt(self, fn):
+        """the optimizer lane runs fn(ws) behind the current stream AND every weight-gradient chain forked so far"""
+        self._pending.append(("opt", self.opt, self.mark(), fn))
+        self._issue("opt")
+
+    def defer_prep(self, fn):
+        self._pending.append(("prep", self.prep, self.mark(), fn))
+        self._issue("prep")
+
+    def _issue(self, key):
+        if self.deferred == "0" or (self.deferred == "once" and key not in self._entered):
+            self._entered.add(key)
+            self.flush()
+
+    def begin_step(self):
+        self._entered.clear()
+
+    def flush(self):
+        if self._flushing or not self._pending:
+            return
+        self._flushing = True
+        try:
+            while self._pending:
+                kind, ln, ev, fn = self._pending.pop(0)
+                ln.stream.wait_event(ev)
+                if kind == "opt":
+                    for other in self.lanes:
+                        e2 = torch.cuda.Event()
+                        e2.record(other.stream)
+                        ln.stream.wait_event(e2)
+                with ln:
+                    fn(ln.ws)
+        finally:
+            self._flushing = False
+
+    def fork_prep(self) -> _Lane:
+        ev = torch.cuda.Event()
+        ev.record()
+        self.prep.stream.wait_event(ev)
+        return self.prep
+
+    def fork_opt(self) -> _Lane:
+        """the optimizer lane waits for the current stream AND for everything the weight-gradient lanes hold so far"""
+        ev = torch.cuda.Event()
+        ev.record()
+        self.opt.stream.wait_event(ev)
         for ln in self.lanes:
+            ev = torch.cuda.Event()
+            ev.record(ln.stream)
+            self.opt.stream.wait_event(ev)
+        return self.opt
+
+    @staticmethod
+    def mark() -> "torch.cuda.Event":
+        """an event at the current position of the current stream (inside ``with lane:`` -- of that lane)"""
+        ev = torch.cuda.Event()
+        ev.record()
+        return ev
+
+    @staticmethod
+    def wait(ev):
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
+    def join(self):
+        self.flush()
+        cur = torch.cuda.current_stream()
+        for ln in self.lanes + [self.opt, self.prep]:
             ev = torch.cuda.Event()
             ev.record(ln.stream)
             cur.wait_event(ev)
