@@ -84,10 +84,24 @@ __device__ __forceinline__ float eg_act_grad_from_out(float a, int act, float sl
 }
 
 // wave (64 lanes) and block reductions
+// Lane distances 1, 2, 4, 8 as DPP adds (register to register: quad_perm, row_half_mirror, row_mirror -- after each step all lanes of a
+// group hold the group's sum, so the mirrored partner carries the same value the xor partner would), then row_bcast:15 into rows 1 and 3,
+// row_bcast:31 into rows 2 and 3, and lane 63's total broadcast through an SGPR.  The __shfl_xor form is six dependent ds_bpermute round
+// trips through LDS and made the reduction-heavy small kernels latency chains.  (gfx950's v_permlane16/32_swap would do the last two steps
+// symmetrically, but hipcc 7.2 lowers __builtin_amdgcn_permlane*_swap with both results in one register.)  Every lane returns the same
+// value; all 64 lanes must be active.
+template <int CTRL, int ROWMASK = 0xf>
+__device__ __forceinline__ float eg_dpp(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += eg_dpp<0xB1>(v);             // quad_perm [1,0,3,2]
+    v += eg_dpp<0x4E>(v);             // quad_perm [2,3,0,1]
+    v += eg_dpp<0x141>(v);            // row_half_mirror
+    v += eg_dpp<0x140>(v);            // row_mirror
+    v += eg_dpp<0x142, 0xA>(v);       // row_bcast:15 -> rows 1, 3
+    v += eg_dpp<0x143, 0xC>(v);       // row_bcast:31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 // deterministic block sum for blockDim.x <= 1024 (multiple of 64); result valid in all threads
 __device__ __forceinline__ float block_sum(float v, float* sm /* >= 16 floats */) {

@@ -373,26 +373,29 @@ __global__ __launch_bounds__(256) void dense_small_fwd_kernel(const T* __restric
 #pragma unroll
             for (int q = 0; q < 8; ++q) a[r][q] = 0.f;
         for (int k0 = kbeg + threadIdx.x * VEC; k0 < kend; k0 += 256 * VEC) {
+            // every request of this step (R rows of x, 8 weight rows) is issued before the first value is used; the weight row index is
+            // clamped instead of branching around the load.  Written the obvious way the compiler waited for each 16-byte load in turn
+            // (vmcnt(0) after every row) and the kernel was a chain of ~12 dependent round trips per workgroup.
+            uint4 xv[R], wv[8];
+#pragma unroll
+            for (int r = 0; r < R; ++r) xv[r] = *reinterpret_cast<const uint4*>(x + (size_t)min(b0 + r, B - 1) * K + k0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wv[q] = *reinterpret_cast<const uint4*>(wp + (size_t)min(n0 + q, N - 1) * Kpad + k0);
             float xf[R][VEC];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int b = min(b0 + r, B - 1);
-                const uint4 xv = *reinterpret_cast<const uint4*>(x + (size_t)b * K + k0);
-                const T* xe = reinterpret_cast<const T*>(&xv);
+                const T* xe = reinterpret_cast<const T*>(&xv[r]);
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) xf[r][j] = Elt<T>::ld(xe + j);
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                if (n0 + q < N) {
-                    const uint4 wv = *reinterpret_cast<const uint4*>(wp + (size_t)(n0 + q) * Kpad + k0);
-                    const T* we = reinterpret_cast<const T*>(&wv);
+                const T* we = reinterpret_cast<const T*>(&wv[q]);
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) {
-                        const float wf = Elt<T>::ld(we + j);
+                for (int j = 0; j < VEC; ++j) {
+                    const float wf = Elt<T>::ld(we + j);
 #pragma unroll
-                        for (int r = 0; r < R; ++r) a[r][q] += xf[r][j] * wf;
-                    }
+                    for (int r = 0; r < R; ++r) a[r][q] += xf[r][j] * wf;
                 }
             }
         }
@@ -448,39 +451,72 @@ static void launch_dense_small_fwd(const T* x, const T* wp, const float* bias, f
     hipLaunchKernelGGL(dense_small_combine_kernel, dim3(cdiv(B * N, 256)), dim3(256), 0, st, ws, ns, bias, y, B, N, sigma, sigma_rows);
 }
 
-// dx[b][k] = (sum_n dy[b][n] * Wp[n][k]) * act'(mask[b][k])
+// dx[b][k] = (sum_n dy[b][n] * Wp[n][k]) * act'(mask[b][k]);  EG_DS_ROWS batch rows per workgroup share every weight vector (one row per
+// workgroup re-read the whole N x K panel from L2 per row: 240 MB for 384 rows of the 19 x 16384 head)
 template <typename T>
 __global__ __launch_bounds__(256) void dense_small_bwd_kernel(const float* __restrict__ dy, const T* __restrict__ wp, const T* __restrict__ mask,
-                                                              T* __restrict__ dx, int K, int Kpad, int N, int mask_act, float mask_slope,
+                                                              T* __restrict__ dx, int B, int K, int Kpad, int N, int mask_act, float mask_slope,
                                                               const float* __restrict__ sigma, int sigma_rows) {
     constexpr int VEC = Elt<T>::VEC;
-    __shared__ float dl[64];
-    const int b = blockIdx.x;
-    const float post = sigma ? 1.f / sigma[sigma_rows ? b / sigma_rows : 0] : 1.f;
-    if (threadIdx.x < N) dl[threadIdx.x] = dy[(size_t)b * N + threadIdx.x];
+    constexpr int R = EG_DS_ROWS;
+    __shared__ float dl[R][64];
+    const int b0 = blockIdx.x * R;
+    for (int i = threadIdx.x; i < R * 64; i += 256) {
+        const int r = i >> 6, n = i & 63;
+        dl[r][n] = (n < N && b0 + r < B) ? dy[(size_t)(b0 + r) * N + n] : 0.f;
+    }
     __syncthreads();
-    for (int k0 = threadIdx.x * VEC; k0 < K; k0 += 256 * VEC) {
-        float a[VEC];
+    float post[R];
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) a[j] = 0.f;
-        for (int n = 0; n < N; ++n) {
-            const uint4 wv = *reinterpret_cast<const uint4*>(wp + (size_t)n * Kpad + k0);
-            const T* we = reinterpret_cast<const T*>(&wv);
-            const float g = dl[n];
+    for (int r = 0; r < R; ++r) {
+        const int b = min(b0 + r, B - 1);
+        post[r] = sigma ? 1.f / sigma[sigma_rows ? b / sigma_rows : 0] : 1.f;
+    }
+    for (int k0 = (blockIdx.y * 256 + threadIdx.x) * VEC; k0 < K; k0 += gridDim.y * 256 * VEC) {
+        float a[R][VEC];
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) a[j] += g * Elt<T>::ld(we + j);
-        }
-        uint4 ov;
-        T* oe = reinterpret_cast<T*>(&ov);
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) a[r][j] = 0.f;
+        uint4 mv[R];
         if (mask) {
-            const uint4 mv = *reinterpret_cast<const uint4*>(mask + (size_t)b * K + k0);
-            const T* me = reinterpret_cast<const T*>(&mv);
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) a[j] *= eg_act_grad_from_out(Elt<T>::ld(me + j), mask_act, mask_slope);
+            for (int r = 0; r < R; ++r) mv[r] = *reinterpret_cast<const uint4*>(mask + (size_t)min(b0 + r, B - 1) * K + k0);
+        }
+        for (int n0 = 0; n0 < N; n0 += 8) {            // 8 weight rows in flight at a time; summation order n = 0..N-1 as before
+            uint4 wv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) wv[q] = *reinterpret_cast<const uint4*>(wp + (size_t)min(n0 + q, N - 1) * Kpad + k0);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (n0 + q < N) {
+                    const T* we = reinterpret_cast<const T*>(&wv[q]);
+                    float wf[VEC];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) wf[j] = Elt<T>::ld(we + j);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const float g = dl[r][n0 + q];
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) a[r][j] += g * wf[j];
+                    }
+                }
+            }
         }
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) Elt<T>::st(oe + j, a[j] * post);
-        *reinterpret_cast<uint4*>(dx + (size_t)b * K + k0) = ov;
+        for (int r = 0; r < R; ++r) {
+            if (b0 + r >= B) break;
+            uint4 ov;
+            T* oe = reinterpret_cast<T*>(&ov);
+            if (mask) {
+                const T* me = reinterpret_cast<const T*>(&mv[r]);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) a[r][j] *= eg_act_grad_from_out(Elt<T>::ld(me + j), mask_act, mask_slope);
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) Elt<T>::st(oe + j, a[r][j] * post[r]);
+            *reinterpret_cast<uint4*>(dx + (size_t)(b0 + r) * K + k0) = ov;
+        }
     }
 }
 
@@ -569,10 +605,15 @@ extern "C" int eg_head_prep_sn(int dtype, const float* dy, int ldy, const float*
 
 extern "C" int eg_dense_small_bwd(int dtype, const float* dy, const void* wp, const void* mask, void* dx, int B, int K, int Kpad, int N,
                                   int mask_act, float mask_slope, const float* sigma, int sigma_rows, eg_stream_t s) {
-    EG_REQUIRE(dy && wp && dx && N <= 64 && K % (dtype == EG_F32 ? 4 : 8) == 0, "eg_dense_small_bwd: bad argument");
-    if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_bwd_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)s, dy, (const float*)wp, (const float*)mask, (float*)dx, K, Kpad, N, mask_act, mask_slope, sigma, sigma_rows);
-    else if (dtype == EG_F16) hipLaunchKernelGGL(dense_small_bwd_kernel<f16_t>, dim3(B), dim3(256), 0, (hipStream_t)s, dy, (const f16_t*)wp, (const f16_t*)mask, (f16_t*)dx, K, Kpad, N, mask_act, mask_slope, sigma, sigma_rows);
-    else hipLaunchKernelGGL(dense_small_bwd_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)s, dy, (const bf16_t*)wp, (const bf16_t*)mask, (bf16_t*)dx, K, Kpad, N, mask_act, mask_slope, sigma, sigma_rows);
+    EG_REQUIRE(dy && wp && dx && B > 0 && N > 0 && N <= 64 && K > 0 && K % (dtype == EG_F32 ? 4 : 8) == 0, "eg_dense_small_bwd: bad argument");
+    const int vec = dtype == EG_F32 ? 4 : 8;
+    const int groups = cdiv(B, EG_DS_ROWS), kblocks = cdiv(K, 256 * vec);
+    int gy = 1;                                       // enough workgroups for 256 CUs: split the K sweep (every output has one owner)
+    while (gy * 2 <= kblocks && groups * gy < 512) gy *= 2;
+    const dim3 grid(groups, gy);
+    if (dtype == EG_F32) hipLaunchKernelGGL(dense_small_bwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, dy, (const float*)wp, (const float*)mask, (float*)dx, B, K, Kpad, N, mask_act, mask_slope, sigma, sigma_rows);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(dense_small_bwd_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)s, dy, (const f16_t*)wp, (const f16_t*)mask, (f16_t*)dx, B, K, Kpad, N, mask_act, mask_slope, sigma, sigma_rows);
+    else hipLaunchKernelGGL(dense_small_bwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, dy, (const bf16_t*)wp, (const bf16_t*)mask, (bf16_t*)dx, B, K, Kpad, N, mask_act, mask_slope, sigma, sigma_rows);
     EG_LAUNCH_CHECK();
     return 0;
 }
