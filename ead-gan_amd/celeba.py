@@ -757,9 +757,25 @@ class CelebATrainer:
         side.begin_step()
         evs = {}
 
+        ar = self.allreduce
+        ar_async = ar is not None and hasattr(ar, "start")
+
         def update(arena, m, v, lr, slot, tick, zero, repack, key=None, key_w=None):
+            """Queue one network's optimizer update on the optimizer lane.  Data parallel: the gradient all-reduce is STARTED here, on the
+            main stream, once the weight-gradient lanes are done (RCCL's stream must only ever wait for the capture's origin stream: a
+            lane that RCCL waited for and that later waits for RCCL is the stream-level back edge hipStreamEndCapture crashes on), and
+            FINISHED on the optimizer lane, so the main stream waits neither for the collective nor for Adam / re-packing."""
+            h = None
+            if ar is not None:
+                side.join_lanes()
+                if ar_async:
+                    h = ar.start(arena.grad)
+                else:
+                    ar(arena.grad)
+
             def fn(_ws):
-                self._reduce(arena.grad)
+                if h is not None:
+                    ar.finish(h)
                 self._adam(arena, m, v, lr, slot, tick)
                 if key_w:
                     evs[key_w] = side.mark()            # master weights are new

@@ -215,6 +215,15 @@ class SideStream:
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
 
+    def join_lanes(self):
+        """the current stream waits for the weight-gradient lanes only (not for the optimizer / preparation lanes)"""
+        self.flush()
+        cur = torch.cuda.current_stream()
+        for ln in self.lanes:
+            ev = torch.cuda.Event()
+            ev.record(ln.stream)
+            cur.wait_event(ev)
+
     def join(self):
         self.flush()
         cur = torch.cuda.current_stream()

@@ -63,3 +63,19 @@ def test_sync_batchnorm_two_ranks_equal_one_rank_at_the_same_global_batch():
         assert err < 2e-2, (key, err)
     for key in ("rm", "rv"):
         assert torch.allclose(r0[key], w[key], rtol=1e-4, atol=1e-6) and torch.equal(r0[key], r1[key]), key
+
+
+def test_rccl_allreduce_inside_the_captured_step_child_process():
+    """The data-parallel step with a real RCCL process group (one rank) captured into the hipGraph.  Run in a child process: the failure this
+    guards against is a segfault inside hipStreamEndCapture (a side lane that RCCL's stream waited for and that later waits for RCCL's
+    stream -- profiles/r01_timeline_notes.md), which no in-process assertion can catch."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 200))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--no-cpu-baseline", "--no-roofline", "--steps", "3", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+    assert "hipGraph replay" in line["config"]["workload"], (line["config"], r.stderr[-2000:])     # captured, not the eager fallback
