@@ -1428,19 +1428,21 @@ __global__ __launch_bounds__(512) void igemm_nt_big_kernel(const NtParams p) {
     }
 }
 
-// sum of the split-K partial tiles + the fused epilogue (1/sigma, bias, activation, activation-gradient mask), NHWC store
+// sum of the split-K partial tiles + the fused epilogue (1/sigma, bias, activation, activation-gradient mask), NHWC store.
+// blockIdx.y = phase; 32-bit index arithmetic (M * N / VEC < 2^31, checked by the planner's size limits), shifts when N / VEC is a power
+// of two (lvpr >= 0), one bias modulo per vector: with 64-bit divisions and a modulo per element this copy was ALU-bound.
 template <typename T>
-__global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(const NtParams p, int nphase, int Mpad) {
+__global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(const NtParams p, int nphase, int Mpad, int lvpr) {
     constexpr int VEC = Elt<T>::VEC;
-    const int vpr = p.N / VEC;
-    const long long total = (long long)nphase * p.M * vpr;
+    const unsigned vpr = p.N / VEC;
+    const unsigned total = (unsigned)p.M * vpr;
+    const int phase = blockIdx.y;
     const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
     const T* __restrict__ mask = reinterpret_cast<const T*>(p.mask);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int vc = (int)(i % vpr);
-        const long long r = i / vpr;
-        const int m = (int)(r % p.M), phase = (int)(r / p.M);
-        const int n = vc * VEC;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const unsigned vc = lvpr >= 0 ? (i & (vpr - 1)) : (i % vpr);
+        const int m = (int)(lvpr >= 0 ? (i >> lvpr) : (i / vpr));
+        const int n = (int)vc * VEC;
         float f[VEC];
 #pragma unroll
         for (int q = 0; q < VEC; ++q) f[q] = 0.f;
@@ -1457,10 +1459,13 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(const NtParams 
         const int y = ((m >> p.lOW) & OHm) * p.osy + p.ph[phase].ooy;
         const int x = (m & OWm) * p.osx + p.ph[phase].oox;
         const size_t o = (((size_t)b * p.DH + y) * p.DW + x) * p.N + n;
+        // bias index of element q: (n + q) % bias_mod; n is a multiple of VEC, so when VEC divides bias_mod it is (n % bias_mod) + q
+        const bool bias_vec = p.bias_mod == 0 || (p.bias_mod % VEC) == 0;
+        const int nb = p.bias_mod ? n % p.bias_mod : n;
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
             float v = __fmul_rn(f[q], inv_sigma);
-            if (p.bias) v = __fadd_rn(v, p.bias[p.bias_mod ? (n + q) % p.bias_mod : n + q]);
+            if (p.bias) v = __fadd_rn(v, p.bias[bias_vec ? nb + q : (n + q) % p.bias_mod]);
             f[q] = eg_act(v, p.act, p.slope);
         }
         if (mask) {
@@ -1649,9 +1654,13 @@ static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
         } else
             hipLaunchKernelGGL((igemm_nt_buf_kernel<T>), dim3(cdiv(p.M, 128), p.N / 128, nphase * ns), dim3(256), lds, st, q);
         if (ns > 1) {
-            const long long vecs = (long long)nphase * p.M * (p.N / Elt<T>::VEC);
-            const int blocks = (int)std::min<long long>((vecs + 255) / 256, 256 * 16);
-            hipLaunchKernelGGL((nt_splitk_epilogue_kernel<T>), dim3(blocks), dim3(256), 0, st, q, nphase, cdiv(p.M, 128) * 128);
+            // split launches have < g_splitk_target (<= a few thousand) tiles of 128 x 128: M * N / VEC is far below 2^31
+            const int vpr = p.N / Elt<T>::VEC;
+            const long long vecs = (long long)p.M * vpr;
+            const int blocks = (int)std::min<long long>((vecs + 255) / 256, std::max(1, 256 * 16 / nphase));
+            int lvpr = -1;
+            if ((vpr & (vpr - 1)) == 0) { lvpr = 0; while ((1 << lvpr) < vpr) ++lvpr; }
+            hipLaunchKernelGGL((nt_splitk_epilogue_kernel<T>), dim3(blocks, nphase), dim3(256), 0, st, q, nphase, cdiv(p.M, 128) * 128, lvpr);
         }
         return;
     }

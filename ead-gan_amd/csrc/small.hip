@@ -294,42 +294,57 @@ extern "C" int eg_flat_reduce_sn(const float* slab, int nslab, int rows, int Kdi
 // t = (ci*k + kh)*k + kw == the master weight order, so the first/last image-side layers run on the MFMA kernels
 // as 1x1 convolutions with K = CI*k*k (48 for CelebA) instead of scalar FMAs.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ void im2col_img_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int CI, int H, int W, int k, int stride, int pad,
+// KK: filter size as a compile-time constant (4: CelebA / dSprites, 3: MNIST; 0: run-time k).  With a run-time k the ~24 integer divisions
+// per thread made this copy ALU-bound (17.7 us for 23 MB); constants turn them into shifts and multiplies.
+template <typename T, int KK>
+__global__ void im2col_img_kernel(const float* __restrict__ img, T* __restrict__ out, int B, int CI, int H, int W, int k_rt, int stride, int pad,
                                   int OH, int OW, int K, int Kp) {
     constexpr int VEC = Elt<T>::VEC;
-    const int cpr = Kp / VEC;
-    const size_t total = (size_t)B * OH * OW * cpr;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int j = (int)(i % cpr);
-        const size_t m = i / cpr;
-        const int ox = (int)(m % OW), oy = (int)((m / OW) % OH), b = (int)(m / ((size_t)OW * OH));
+    const int k = KK ? KK : k_rt;
+    const unsigned cpr = Kp / VEC;
+    const unsigned total = (unsigned)B * OH * OW * cpr;                 // < 2^31 (checked by the launcher)
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned j = i % cpr, m = i / cpr;
+        const unsigned ox = m % OW, oyb = m / OW;
+        const unsigned oy = oyb % OH, b = oyb / OH;
+        const int iy0 = (int)oy * stride - pad, ix0 = (int)ox * stride - pad;
+        const float* base = img + (size_t)b * CI * H * W;
         uint4 v;
         T* e = reinterpret_cast<T*>(&v);
 #pragma unroll
         for (int q = 0; q < VEC; ++q) {
-            const int t = j * VEC + q;
+            const int t = (int)j * VEC + q;
             float f = 0.f;
             if (t < K) {
                 const int kw = t % k, kh = (t / k) % k, ci = t / (k * k);
-                const int iy = oy * stride - pad + kh, ix = ox * stride - pad + kw;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W) f = img[(((size_t)b * CI + ci) * H + iy) * W + ix];
+                const int iy = iy0 + kh, ix = ix0 + kw;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) f = base[((size_t)ci * H + iy) * W + ix];
             }
             Elt<T>::st(e + q, f);
         }
-        *reinterpret_cast<uint4*>(out + i * VEC) = v;
+        *reinterpret_cast<uint4*>(out + (size_t)i * VEC) = v;
     }
+}
+
+template <typename T>
+static void launch_im2col_img(const float* img, T* out, int B, int CI, int H, int W, int k, int stride, int pad, int OH, int OW, int Kp, int blocks,
+                              hipStream_t st) {
+    if (k == 4) hipLaunchKernelGGL((im2col_img_kernel<T, 4>), dim3(blocks), dim3(256), 0, st, img, out, B, CI, H, W, k, stride, pad, OH, OW, CI * k * k, Kp);
+    else if (k == 3) hipLaunchKernelGGL((im2col_img_kernel<T, 3>), dim3(blocks), dim3(256), 0, st, img, out, B, CI, H, W, k, stride, pad, OH, OW, CI * k * k, Kp);
+    else hipLaunchKernelGGL((im2col_img_kernel<T, 0>), dim3(blocks), dim3(256), 0, st, img, out, B, CI, H, W, k, stride, pad, OH, OW, CI * k * k, Kp);
 }
 
 extern "C" int eg_im2col_img(int dtype, const float* img, void* out, int B, int CI, int H, int W, int k, int stride, int pad, int Kp,
                              eg_stream_t s) {
-    EG_REQUIRE(img && out && Kp >= CI * k * k && Kp % (dtype == EG_F32 ? 4 : 8) == 0, "eg_im2col_img: bad argument");
+    EG_REQUIRE(img && out && B > 0 && CI > 0 && k > 0 && stride > 0 && Kp >= CI * k * k && Kp % (dtype == EG_F32 ? 4 : 8) == 0, "eg_im2col_img: bad argument");
     const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+    EG_REQUIRE(OH > 0 && OW > 0, "eg_im2col_img: empty output");
     const size_t total = (size_t)B * OH * OW * (Kp / (dtype == EG_F32 ? 4 : 8));
+    EG_REQUIRE(total < 0x7fffffffull, "eg_im2col_img: more than 2^31 output vectors");
     const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-    if (dtype == EG_F32) hipLaunchKernelGGL(im2col_img_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, img, (float*)out, B, CI, H, W, k, stride, pad, OH, OW, CI * k * k, Kp);
-    else if (dtype == EG_F16) hipLaunchKernelGGL(im2col_img_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, img, (f16_t*)out, B, CI, H, W, k, stride, pad, OH, OW, CI * k * k, Kp);
-    else hipLaunchKernelGGL(im2col_img_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, img, (bf16_t*)out, B, CI, H, W, k, stride, pad, OH, OW, CI * k * k, Kp);
+    if (dtype == EG_F32) launch_im2col_img<float>(img, (float*)out, B, CI, H, W, k, stride, pad, OH, OW, Kp, blocks, (hipStream_t)s);
+    else if (dtype == EG_F16) launch_im2col_img<f16_t>(img, (f16_t*)out, B, CI, H, W, k, stride, pad, OH, OW, Kp, blocks, (hipStream_t)s);
+    else launch_im2col_img<bf16_t>(img, (bf16_t*)out, B, CI, H, W, k, stride, pad, OH, OW, Kp, blocks, (hipStream_t)s);
     EG_LAUNCH_CHECK();
     return 0;
 }
