@@ -788,9 +788,15 @@ class CelebATrainer:
 
         self._inputs_head()
         # ---- 1) generator adversarial step (:334-345); D(gen) lives in tape slot 2 so that step 2's tapes can be prepared meanwhile ----
+
+        def sn1(_ws):                                   # D(gen)'s power iteration only needs D's weights: beside the generator forward
+            de._sn_tape(2)
+            evs["sn1"] = side.mark()
+        side.defer_prep(sn1)
         ops.fill_f32(ga.grad)
         gen = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
-        out = de.forward([gen], 2)
+        side.wait(evs["sn1"])
+        out = de.forward([gen], 2, prepared=(False,))
 
         def prep2(_ws):                                 # step 2's power iterations (after step 1's in the u/v chain) and patch rows
             de.prepare(0, [self.scaled, gen])
