@@ -2202,7 +2202,8 @@ static void tn_plan(const eg_conv* c, int* nsplit, int* rps) {
     int bnt, bct;
     tn_tiles(c, &bnt, &bct);
     const long long base = (long long)cdiv(c->Cout, bnt) * cdiv(c->Cin, bct) * c->k * c->k;
-    long long want = base >= 768 ? 1 : (768 + base - 1) / base;
+    static const int target = [] { const char* e = getenv("EG_TN_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 768; }();   // workgroups per launch
+    long long want = base >= target ? 1 : (target + base - 1) / base;
     long long cap = M / 256 > 0 ? M / 256 : 1;
     if (want > cap) want = cap;
     if (want > 128) want = 128;
