@@ -10,8 +10,10 @@ parameter containers so that ``state_dict()`` keys, shapes and default initialis
 from __future__ import annotations
 
 import argparse
+import os
 
 import numpy as np
+
 import torch
 import torch.nn as nn
 from torch.nn.utils import spectral_norm
@@ -23,6 +25,9 @@ from .ops import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, EG_BF16, EG_F32, OUT_
 # module-level hyper-parameters, mirroring the reference's global ``opt`` (argparse defaults, :39-51)
 opt = argparse.Namespace(n_epochs=50, batch_size=16, lr=0.0002, b1=0.5, b2=0.999, n_cpu=8, latent_dim=200, code_dim=8,
                          n_classes=10, img_size=64, channels=3, sample_interval=4000)
+
+# image-side transposed convolutions (128 -> C) as one GEMM + col2im gather (1) or as the 4-phase implicit GEMM (0)
+IMG_GEMM = os.environ.get("EG_IMG_GEMM", "1") == "1"
 
 G_WIDTHS = (1024, 512, 256, 128)
 D_WIDTHS = (128, 256, 512, 1024)
@@ -66,6 +71,10 @@ class _GenEngine:
         self.kp = gen.channels * 16
         self.l4p = ConvRec(dtype, B, s * 8, s * 8, self.kp, W[3], 1, 1, 0, device=dev, want_bwd=False, ws=ws)
         self.patches = torch.empty(B * (s * 8) ** 2, self.kp, device=dev, dtype=tdt)
+        # forward of the same layer as ONE GEMM over the input pixels with N = 16 taps x C columns + a col2im gather (eg_col2im_img): every
+        # activation is read once instead of 16 times (4 phases x 4 taps of the implicit transposed convolution)
+        self.l4g = ConvRec(dtype, B, s * 8, s * 8, W[3], self.kp, 1, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
+        self.cols4 = torch.empty(B * (s * 8) ** 2, self.kp, device=dev, dtype=tdt)
         ws.need_small(B * gen.channels)
         # activations
         e = lambda *shape, dt=tdt: torch.empty(shape, device=dev, dtype=dt)
@@ -100,6 +109,8 @@ class _GenEngine:
             self.mid[i].pack(self._p(idx, "weight"))
         self.l4.pack(self._p(10, "weight"))
         ops.pack_strided(dt, self._p(10, "weight"), self.l4p.wp_fwd, G_WIDTHS[3], self.kp, self.l4p.Kpad_fwd, 1, self.kp, 0, 1)
+        # wp[t*C + c][ci] = W[ci][c][t]   (master [128][C][4][4])
+        ops.pack_strided(dt, self._p(10, "weight"), self.l4g.wp_fwd, self.kp, G_WIDTHS[3], self.l4g.Kpad_fwd, g.channels, 1, 16, self.kp)
 
     def forward(self, noise, labels, code, training=True, sync=None):
         """``training=False``: BatchNorm with the running statistics, nothing updated (module.eval()).  ``sync`` (a dp.SyncBN):
@@ -124,8 +135,12 @@ class _GenEngine:
             else:
                 ops.bn_fwd_eval(dt, self.z[i], self.a[i], M, W[i + 1], bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, self.ws.small, ACT_RELU)
             x = self.a[i]
-        ops.conv_bwd_data(self.l4.c, dt, x, self.l4.wp_bwd, self.img,
-                          ops.epilogue(bias=self._p(10, "bias"), act=ACT_TANH, out_mode=OUT_NCHW_F32))
+        if IMG_GEMM:
+            ops.conv_fwd(self.l4g.c, dt, x, self.l4g.wp_fwd, self.cols4, None)
+            ops.col2im_img(dt, self.cols4, B, self.gen.channels, self.l4g.H, self.l4g.W, 4, 2, 1, self._p(10, "bias"), ACT_TANH, 0.0, self.img)
+        else:
+            ops.conv_bwd_data(self.l4.c, dt, x, self.l4.wp_bwd, self.img,
+                              ops.epilogue(bias=self._p(10, "bias"), act=ACT_TANH, out_mode=OUT_NCHW_F32))
         return self.img
 
     def backward(self, dimg, grad, side=None, sync=None):
@@ -306,6 +321,9 @@ class _DiscEngine:
         # packed panels live in per-layer records built for the largest batch; geometry structs per tape count
         self.l1 = ConvRec(dtype, B, S, S, C, W[0], 4, 2, 1, device=dev, want_fwd=False, want_wgrad=False, ws=ws)       # d(img), tape 0 only
         self.l1p = ConvRec(dtype, NT * B, S // 2, S // 2, self.kp, W[0], 1, 1, 0, device=dev, want_bwd=False, ws=ws)  # image side as 1x1 conv over patches
+        # d(img) as one GEMM over the layer-0 lattice with N = 16 taps x C columns + eg_col2im_img (see _GenEngine.l4g)
+        self.l1g = ConvRec(dtype, B, S // 2, S // 2, W[0], self.kp, 1, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
+        self.cols1 = torch.empty(B * (S // 2) ** 2, self.kp, device=dev, dtype=tdt)
         self.mid = [ConvRec(dtype, NT * B, S >> (i + 1), S >> (i + 1), W[i], W[i + 1], 4, 2, 1, device=dev, ws=ws) for i in range(3)]
         self.head = ConvRec(dtype, NT * B, 4, 4, W[3], self.nout, 4, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
         self.headw = ConvRec(dtype, NT * B, 1, 1, 16 * W[3], 32, 1, 1, 0, device=dev, want_fwd=False, want_bwd=False, ws=ws)
@@ -352,6 +370,8 @@ class _DiscEngine:
 
     def repack(self):
         self.l1.pack(self._m(0).weight_orig)
+        # wp[t*C + c][co] = W[co][c][t]   (Conv2d master [128][C][4][4]; the transposed convolution reads it as [in = 128][out = C])
+        ops.pack_strided(self.dtype, self._m(0).weight_orig, self.l1g.wp_fwd, self.kp, D_WIDTHS[0], self.l1g.Kpad_fwd, self.C, 1, 16, self.kp)
         ops.pack_strided(self.dtype, self._m(0).weight_orig, self.l1p.wp_fwd, D_WIDTHS[0], self.kp, self.l1p.Kpad_fwd, 1, self.kp, 0, 1)
         for i in range(3):
             self.mid[i].pack(self._m(i + 1).weight_orig)
@@ -453,7 +473,11 @@ class _DiscEngine:
                                                mask_slope=LRELU_SLOPE))
                 flush()
         if need_dimg:
-            ops.conv_bwd_data(self.l1.c, dt, sl(self.dz[0]), self.l1.wp_bwd, self.dimg, ops.epilogue(out_mode=OUT_NCHW_F32))
+            if IMG_GEMM:
+                ops.conv_fwd(self.l1g.c, dt, sl(self.dz[0]), self.l1g.wp_fwd, self.cols1, None)
+                ops.col2im_img(dt, self.cols1, B, self.C, self.S // 2, self.S // 2, 4, 2, 1, None, ACT_NONE, 0.0, self.dimg)
+            else:
+                ops.conv_bwd_data(self.l1.c, dt, sl(self.dz[0]), self.l1.wp_bwd, self.dimg, ops.epilogue(out_mode=OUT_NCHW_F32))
             flush()
             return self.dimg
         return None                                     # layer 0's chain stays pending: the caller's next main-stream kernel goes first

@@ -669,3 +669,65 @@ extern "C" int eg_dense_small_wgrad(int dtype, const float* dy, const void* x, f
     EG_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// col2im of a transposed convolution with few output channels (ConvTranspose2d(128 -> 3, 4, 2, 1): the generator's last layer,
+// celebA/EAD-GAN_celebA.py:90-91, and the backward-to-image of the discriminator's first Conv2d(3 -> 128, 4, 2, 1), :110).
+// The layer runs as ONE GEMM over the input pixels with N = k*k*C columns, cols[m][t*C + c] = sum_ci x[m][ci] W[ci][c][t] (every
+// activation read once; as 4 phases x 4 taps of an implicit GEMM each one was fetched 16 times through L2), then this gather:
+//   out[b][c][oy][ox] = act(bias[c] + sum over taps (kh,kw) with oy = iy*stride - pad + kh, ox = ix*stride - pad + kw of cols[(b,iy,ix)][t*C + c])
+// One thread per output pixel; every cols element is read exactly once; out is fp32 NCHW (the image / image gradient).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int C>
+__global__ __launch_bounds__(256) void col2im_img_kernel(const T* __restrict__ cols, int B, int Hin, int Win, int k, int stride, int pad, int OH, int OW,
+                                                         const float* __restrict__ bias, int act, float slope, float* __restrict__ out) {
+    const unsigned total = (unsigned)B * OH * OW;
+    const unsigned i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const unsigned ox = i % OW, r = i / OW;
+    const unsigned oy = r % OH, b = r / OH;
+    float acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = bias ? bias[c] : 0.f;
+    const int ncol = k * k * C;
+    // taps of one axis that reach output coordinate o: kh = (o + pad) % stride + j * stride, input coordinate (o + pad - kh) / stride
+    for (int kh = (int)(oy + pad) % stride; kh < k; kh += stride) {
+        const int iy = ((int)oy + pad - kh) / stride;
+        if (iy < 0 || iy >= Hin) continue;
+        for (int kw = (int)(ox + pad) % stride; kw < k; kw += stride) {
+            const int ix = ((int)ox + pad - kw) / stride;
+            if (ix < 0 || ix >= Win) continue;
+            const T* src = cols + ((size_t)(b * Hin + iy) * Win + ix) * ncol + (kh * k + kw) * C;
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] += Elt<T>::ld(src + c);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) out[(((size_t)b * C + c) * OH + oy) * OW + ox] = eg_act(acc[c], act, slope);
+}
+
+template <typename T>
+static int launch_col2im_img(const T* cols, int B, int C, int Hin, int Win, int k, int stride, int pad, int OH, int OW, const float* bias, int act,
+                             float slope, float* out, hipStream_t st) {
+    const unsigned blocks = (unsigned)(((size_t)B * OH * OW + 255) / 256);
+    if (C == 1) hipLaunchKernelGGL((col2im_img_kernel<T, 1>), dim3(blocks), dim3(256), 0, st, cols, B, Hin, Win, k, stride, pad, OH, OW, bias, act, slope, out);
+    else if (C == 3) hipLaunchKernelGGL((col2im_img_kernel<T, 3>), dim3(blocks), dim3(256), 0, st, cols, B, Hin, Win, k, stride, pad, OH, OW, bias, act, slope, out);
+    else return -1;
+    return 0;
+}
+
+extern "C" int eg_col2im_img(int dtype, const void* cols, int B, int C, int Hin, int Win, int k, int stride, int pad, const float* bias, int act,
+                             float slope, float* out, eg_stream_t s) {
+    EG_REQUIRE(cols && out && B > 0 && Hin > 0 && Win > 0 && k > 0 && stride > 0 && pad >= 0, "eg_col2im_img: bad argument");
+    EG_REQUIRE(C == 1 || C == 3, "eg_col2im_img: image channels must be 1 or 3");
+    EG_REQUIRE(dtype == EG_F32 || dtype == EG_BF16 || dtype == EG_F16, "dtype must be EG_F32, EG_BF16 or EG_F16");
+    const int OH = (Hin - 1) * stride - 2 * pad + k, OW = (Win - 1) * stride - 2 * pad + k;
+    EG_REQUIRE(OH > 0 && OW > 0 && (size_t)B * OH * OW < 0x7fffffffull, "eg_col2im_img: bad output size");
+    int rc;
+    if (dtype == EG_F32) rc = launch_col2im_img<float>((const float*)cols, B, C, Hin, Win, k, stride, pad, OH, OW, bias, act, slope, out, (hipStream_t)s);
+    else if (dtype == EG_F16) rc = launch_col2im_img<f16_t>((const f16_t*)cols, B, C, Hin, Win, k, stride, pad, OH, OW, bias, act, slope, out, (hipStream_t)s);
+    else rc = launch_col2im_img<bf16_t>((const bf16_t*)cols, B, C, Hin, Win, k, stride, pad, OH, OW, bias, act, slope, out, (hipStream_t)s);
+    EG_REQUIRE(rc == 0, "eg_col2im_img: unsupported channel count");
+    EG_LAUNCH_CHECK();
+    return 0;
+}

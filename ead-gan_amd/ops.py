@@ -493,3 +493,7 @@ def minmax_f32(x, n, ws, out2):
 
 def quantize_u8(x, C, H, W, rng2, out):
     lib().call("eg_quantize_u8", _p(x), C, H, W, _p(rng2), _p(out), _stream())
+
+
+def col2im_img(dtype, cols, B, C, Hin, Win, k, stride, pad, bias, act, slope, out):
+    lib().call("eg_col2im_img", dtype, _p(cols), B, C, Hin, Win, k, stride, pad, _p(bias), act, slope, _p(out), _stream())

@@ -158,6 +158,13 @@ int eg_conv_img_wgrad(int dtype, const void* dz, const float* img, float* slab, 
 int eg_im2col_img(int dtype, const float* img, void* out, int B, int CI, int H, int W, int k, int stride, int pad, int Kp,
                   eg_stream_t s);
 int eg_cast_pad(int dtype, const float* src, void* dst, int rows, int n, int npad, eg_stream_t s);
+/* col2im of a transposed convolution with C = 1 or 3 output channels (ConvTranspose2d(128 -> 3, 4, 2, 1): celebA/EAD-GAN_celebA.py:90-91; the
+ * backward-to-image of Conv2d(3 -> 128, 4, 2, 1): :110).  cols [B*Hin*Win][k*k*C] (dtype T; column t*C + c, t = kh*k + kw) is the output of
+ * ONE GEMM over the input pixels (eg_conv_fwd on a 1x1 geometry with Cout = k*k*C), so every activation is read once:
+ *   out[b][c][oy][ox] = act(bias[c] + sum of cols[(b,iy,ix)][t*C + c] over the taps with oy = iy*stride - pad + kh, ox = ix*stride - pad + kw)
+ * out: fp32 NCHW [B][C][(Hin-1)*stride - 2*pad + k][(Win-1)*stride - 2*pad + k]; bias may be NULL. */
+int eg_col2im_img(int dtype, const void* cols, int B, int C, int Hin, int Win, int k, int stride, int pad, const float* bias, int act,
+                  float slope, float* out, eg_stream_t s);
 /* out = g * act'(a) over an NCHW fp32 tensor and gb[c] += sum_{b,hw} out  (partial: B*C floats) */
 int eg_act_grad_mul_bias_nchw(const float* g, const float* a, float* out, int B, int C, int HW, int act, float slope,
                               float* partial, float* gb, eg_stream_t s);

@@ -366,6 +366,41 @@ def test_image_side_layers_via_im2col(dtype):
     torch.testing.assert_close(grad.cpu(), w.grad, rtol=rt * 5, atol=at * math.sqrt(B * OH * OH) / 4)   # 3072-term fp32 sums
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,B,Hin,k,s,p", [(3, 3, 32, 4, 2, 1), (1, 2, 16, 4, 2, 1), (3, 2, 7, 3, 1, 1), (1, 5, 5, 4, 1, 0)])
+def test_transposed_conv_as_gemm_plus_col2im(dtype, C, B, Hin, k, s, p):
+    """ConvTranspose2d(128 -> C) as one GEMM over the input pixels (N = k*k*C columns, eg_conv_fwd on a 1x1 geometry) + eg_col2im_img:
+    the gather alone is exact against F.fold; the pair against F.conv_transpose2d (+ bias, tanh)."""
+    CI = 128
+    g = torch.Generator().manual_seed(21)
+    tdt = ops.torch_dtype(dtype)
+    OH = (Hin - 1) * s - 2 * p + k
+    ncol = k * k * C
+    # (1) the gather: out = fold(cols); cols[m][t*C + c]  <->  fold input [B, C*k*k (c-major), L]
+    cols = rq(torch.randn(B * Hin * Hin, ncol, generator=g), dtype)
+    out = torch.empty(B, C, OH, OH, device=DEV)
+    ops.col2im_img(dtype, cols.to(DEV).to(tdt), B, C, Hin, Hin, k, s, p, None, ops.ACT_NONE, 0.0, out)
+    fin = cols.view(B, Hin * Hin, k * k, C).permute(0, 3, 2, 1).reshape(B, C * k * k, Hin * Hin)
+    want = F.fold(fin, (OH, OH), k, padding=p, stride=s)
+    torch.testing.assert_close(out.cpu(), want, rtol=1e-6, atol=1e-6)
+    # (2) the layer (the GEMM engine wants power-of-two lattices and N a multiple of the vector width)
+    if Hin & (Hin - 1) or ncol % 8:
+        return
+    x = rq(torch.randn(B, CI, Hin, Hin, generator=g), dtype)
+    w = rq(torch.randn(CI, C, k, k, generator=g) * 0.1, dtype)
+    bias = torch.randn(C, generator=g)
+    c = ops.make_conv(B, Hin, Hin, CI, ncol, 1, 1, 0)
+    Kpad = ops.round_up(CI, ops.bk(dtype))
+    wp = torch.empty(ncol * Kpad, device=DEV, dtype=tdt)
+    ops.pack_strided(dtype, w.to(DEV), wp, ncol, CI, Kpad, C, 1, k * k, k * k * C)        # wp[t*C + c][ci] = w[ci][c][t]
+    colsd = torch.empty(B * Hin * Hin, ncol, device=DEV, dtype=tdt)
+    ops.conv_fwd(c, dtype, nhwc(x, dtype), wp, colsd, None)
+    ops.col2im_img(dtype, colsd, B, C, Hin, Hin, k, s, p, bias.to(DEV), ops.ACT_TANH, 0.0, out)
+    want = torch.tanh(F.conv_transpose2d(x, w, bias, s, p))
+    rt, at = tol(dtype, CI * k * k // (s * s))
+    torch.testing.assert_close(out.cpu(), want, rtol=rt, atol=at * 2)        # + one rounding of the per-tap partial sums to the compute dtype
+
+
 def test_tanh_backward_with_bias_gradient_and_cast_pad():
     g = torch.Generator().manual_seed(12)
     B, C, HW = 5, 3, 4096
