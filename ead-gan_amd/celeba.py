@@ -694,7 +694,7 @@ class CelebATrainer:
         self.inputs = None
         # weight-gradient chains and re-packing run on a second stream beside the backward-data chain (same arithmetic, same order
         # inside every chain -> bit-identical results with and without)
-        self.side = SideStream(dev, Workspace.get(dev)) if overlap else None
+        self.side = SideStream(dev, Workspace.get(dev), lanes=int(os.environ.get("EG_LANES", "4"))) if overlap else None
 
     # -- the hot path ---------------------------------------------------------------------------------
     def _adam(self, arena, m, v, lr, slot, tick):
