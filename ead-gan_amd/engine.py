@@ -123,7 +123,8 @@ class SideStream:
         self.opt = _Lane(device, like)
         # preparation lane: the next sub-step's power iterations and patch rows.  It waits for optimizer-lane events (new weights), so
         # the optimizer lane must never wait for it: hipStreamEndCapture of ROCm 7.2 segfaults on such a stream-level back edge
-        # (X waited for Y, later Y waits for X) even though the node graph is acyclic -- profiles/scripts/capture_patterns.py.
+        # (X waited for Y, later Y waits for X) even though the node graph is acyclic -- profiles/scripts/capture_patterns.py.  The same
+        # holds for longer cycles: the waits among the non-origin streams must form a DAG (profiles/r01_timeline_notes.md item 10).
         self.prep = _Lane(device, like)
         self._pending = []
         self._flushing = False
