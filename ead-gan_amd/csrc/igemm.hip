@@ -1867,12 +1867,13 @@ struct PackTileParams {
     long long off[16];     // element offset of (c = 0, n = 0) of combination q inside wp_bwd
 };
 
-template <typename T>
+// TTC: taps (k*k) as a compile-time constant (16 for every 4x4 layer; 0 = run time): the index arithmetic below divides by it per element
+template <typename T, int TTC>
 __global__ __launch_bounds__(256) void pack_conv_tile_kernel(const PackTileParams p) {
     constexpr int VEC = Elt<T>::VEC;
     constexpr int TN = 16, TC = 32;
     extern __shared__ float tile[];                 // [TN][TC][T + 1]
-    const int TT = p.T, TP = p.T + 1;
+    const int TT = TTC ? TTC : p.T, TP = TT + 1;
     const int n0 = blockIdx.x * TN, c0 = blockIdx.y * TC;
     const int tid = threadIdx.x;
     for (int e = tid; e < TN * TC * TT; e += 256) {
@@ -1944,9 +1945,12 @@ extern "C" int eg_pack_conv(const eg_conv* c, int dtype, const float* w, void* w
     }
     const dim3 grid(c->Cout / 16, c->Cin / 32);
     const size_t lds = (size_t)16 * 32 * (T + 1) * sizeof(float);
-    if (dtype == EG_F32) hipLaunchKernelGGL(pack_conv_tile_kernel<float>, grid, dim3(256), lds, (hipStream_t)s, p);
-    else if (dtype == EG_F16) hipLaunchKernelGGL(pack_conv_tile_kernel<f16_t>, grid, dim3(256), lds, (hipStream_t)s, p);
-    else hipLaunchKernelGGL(pack_conv_tile_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)s, p);
+#define EG_PACK_TILE(TY) do { if (T == 16) hipLaunchKernelGGL((pack_conv_tile_kernel<TY, 16>), grid, dim3(256), lds, (hipStream_t)s, p); \
+                              else hipLaunchKernelGGL((pack_conv_tile_kernel<TY, 0>), grid, dim3(256), lds, (hipStream_t)s, p); } while (0)
+    if (dtype == EG_F32) EG_PACK_TILE(float);
+    else if (dtype == EG_F16) EG_PACK_TILE(f16_t);
+    else EG_PACK_TILE(bf16_t);
+#undef EG_PACK_TILE
     EG_LAUNCH_CHECK();
     return 0;
 }
