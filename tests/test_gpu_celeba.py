@@ -394,3 +394,30 @@ def test_ragged_batch_sizes_through_the_drop_in_modules(B):
     (wc.sum() + (wo * wo).sum() + wv.sum()).backward()
     for k, p in D.named_parameters():
         assert rel_err(p.grad, orc.D[k].grad) < 2e-2, k          # flip-bounded (see the three-tape test); typically 1e-6
+
+
+@pytest.mark.parametrize("dtype,tol", [("f32", 2e-6), ("bf16", 2e-2)])
+def test_image_side_layers_both_formulations_agree(dtype, tol, monkeypatch):
+    """The 128 -> 3 transposed convolutions (G's last layer forward, D's first-layer backward-to-image) as one GEMM + col2im gather (the
+    default) and as the 4-phase implicit GEMM (EG_IMG_GEMM=0, kept as an A/B switch) are the same function: fp32 up to summation order,
+    bf16 up to one extra rounding of the per-tap partial sums."""
+    B = 4
+    orc, G, D = build_pair(2, dtype)
+    rng = np.random.RandomState(6)
+    z, code, labels = co.draw_step_inputs(rng, B)
+    onehot = F.one_hot(labels, 10).float()
+    img = torch.rand(B, 3, 64, 64, generator=torch.Generator().manual_seed(3)) * 2 - 1
+    outs = {}
+    G.eval()
+    D.eval()                                             # frozen spectral-norm vectors: a training-mode forward would move sigma between the two runs
+    for flag in (True, False):
+        monkeypatch.setattr(eg.celeba, "IMG_GEMM", flag)
+        with torch.no_grad():
+            gen = G(z.to(DEV), onehot.to(DEV), code.to(DEV)).float().cpu().clone()
+        x = img.to(DEV).requires_grad_(True)
+        cat, cont, val = D(x)
+        (val.sum() + cont.sum()).backward()
+        outs[flag] = (gen, x.grad.float().cpu().clone())
+    assert rel_err(outs[True][0], outs[False][0]) < tol
+    assert rel_err(outs[True][1], outs[False][1]) < tol
+    assert float(outs[False][1].abs().max()) > 0
