@@ -15,7 +15,7 @@ from torch.nn.utils import spectral_norm
 
 from . import ops
 from .celeba import _HipModule, _require_cuda, transformation_2D      # noqa: F401  (same STN warp in both scripts)
-from .engine import Arena, ConvRec, Workspace, capture_step, parse_dtype
+from .engine import Arena, ConvRec, SideStream, Workspace, capture_step, parse_dtype
 from .ops import ACT_LRELU, ACT_NONE, ACT_TANH, EG_F32, OUT_NCHW_F32
 from .trunk import Head, TrunkEngine
 
@@ -127,43 +127,70 @@ class _GenEngine:
         ops.conv_fwd(self.c3f.c, dt, self.a2, self.c3f.wp_fwd, self.img, ops.epilogue(bias=cb[9].bias, act=ACT_TANH, out_mode=OUT_NCHW_F32))
         return self.img
 
-    def backward(self, dimg, grad):
+    def backward(self, dimg, grad, side=None):
+        """Accumulates d(loss)/d(params) into ``grad``.  With ``side`` (engine.SideStream) every layer's weight-gradient chain (TN GEMM, slab
+        reduce, bias sums) is forked onto a lane as soon as the layer's output gradient exists, beside the backward-data chain of the
+        layers below; the caller joins before it reads ``grad``.  Same kernels, same order inside every chain: bit-identical."""
         dt, B, g, ws = self.dtype, self.B, self.gen, self.ws
         cb = g.conv_blocks
         gof = lambda name: g.arena.grad_of(name, grad)
         s = g.init_size
         S = 4 * s
+
+        def wgrad_side(fn, lane):
+            if side is None:
+                fn(ws)
+            else:
+                side.defer(lane, fn)
+        flush = side.flush if side is not None else (lambda: None)
+
         ops.act_grad_mul_bias_nchw(dimg, self.img, self.dimg_z, B, self.CH, S * S, ACT_TANH, 0.0, ws.small, gof("conv_blocks.9.bias"))
         ops.cast_pad(dt, self.dimg_z, self.p8, B * S * S, self.CH, 8)          # [M][1] fp32 (== NCHW with C=1) -> [M][8]
-        ns = ops.conv_wgrad(self.c3.c, dt, self.a2, self.p8, ws.slab)
-        ops.wgrad_reduce(ws.slab, ns, 8, self.CH, 64, 9, gof("conv_blocks.9.weight"))
+
+        def c3_wgrad(wsw):
+            ns = ops.conv_wgrad(self.c3.c, dt, self.a2, self.p8, wsw.slab)
+            ops.wgrad_reduce(wsw.slab, ns, 8, self.CH, 64, 9, gof("conv_blocks.9.weight"))
+        wgrad_side(c3_wgrad, 0)
         ops.conv_bwd_data(self.c3.c, dt, self.p8, self.c3.wp_bwd, self.da2, None)
+        flush()
 
         def bn_bwd(z, da, dz, mod, i, M, C, act, name):
             ops.bn_bwd(dt, z, da, dz, M, C, mod.weight, mod.bias, self.mean[i], self.invstd[i], act, SLOPE, gof(name + ".weight"), gof(name + ".bias"),
                        ws.sums, ws.small)
         # conv2 (128 -> 64 on the 2x-upsampled a1)
         bn_bwd(self.z2, self.da2, self.dz2, cb[7], 2, B * S * S, 64, ACT_LRELU, "conv_blocks.7")
-        ns = ops.conv_wgrad(self.c2.c, dt, self.a1, self.dz2, ws.slab)
-        ops.wgrad_reduce(ws.slab, ns, 64, 64, 128, 9, gof("conv_blocks.6.weight"))
-        ops.bias_grad(dt, self.dz2, B * S * S, 64, ws.small, gof("conv_blocks.6.bias"))
+
+        def c2_wgrad(wsw):
+            ns = ops.conv_wgrad(self.c2.c, dt, self.a1, self.dz2, wsw.slab)
+            ops.wgrad_reduce(wsw.slab, ns, 64, 64, 128, 9, gof("conv_blocks.6.weight"))
+            ops.bias_grad(dt, self.dz2, B * S * S, 64, wsw.small, gof("conv_blocks.6.bias"))
+        wgrad_side(c2_wgrad, 1)
         ops.conv_bwd_data(self.c2.c, dt, self.dz2, self.c2.wp_bwd, self.dup, None)
+        flush()
         ops.sumpool2x2(dt, self.dup, self.da1, B, 2 * s, 2 * s, 128)
         # conv1 (128 -> 128 on the 2x-upsampled a0)
         bn_bwd(self.z1, self.da1, self.dz1, cb[3], 1, B * 4 * s * s, 128, ACT_LRELU, "conv_blocks.3")
-        ns = ops.conv_wgrad(self.c1.c, dt, self.a0, self.dz1, ws.slab)
-        ops.wgrad_reduce(ws.slab, ns, 128, 128, 128, 9, gof("conv_blocks.2.weight"))
-        ops.bias_grad(dt, self.dz1, B * 4 * s * s, 128, ws.small, gof("conv_blocks.2.bias"))
+
+        def c1_wgrad(wsw):
+            ns = ops.conv_wgrad(self.c1.c, dt, self.a0, self.dz1, wsw.slab)
+            ops.wgrad_reduce(wsw.slab, ns, 128, 128, 128, 9, gof("conv_blocks.2.weight"))
+            ops.bias_grad(dt, self.dz1, B * 4 * s * s, 128, wsw.small, gof("conv_blocks.2.bias"))
+        wgrad_side(c1_wgrad, 2)
         ops.conv_bwd_data(self.c1.c, dt, self.dz1, self.c1.wp_bwd, self.dup, None)     # [B,16,16,128] in the front of dup
+        flush()
         ops.sumpool2x2(dt, self.dup, self.da0, B, s, s, 128)
         bn_bwd(self.h, self.da0, self.dh, cb[0], 0, B * s * s, 128, ACT_NONE, "conv_blocks.0")
         # l1: dW[f][k] = sum_b dh[b][n'(f)] * x[b][k]
         hw = s * s
-        ns = ops.conv_wgrad(self.l1.c, dt, self.inp, self.dh, ws.slab)
-        ops.wgrad_reduce_perm(ws.slab, ns, self.nl1, self.nl1, self.cpad, 1, gof("l1.0.weight"), 128, hw, self.cin)
-        ops.fill_f32(self.gb_perm)
-        ops.bias_grad(dt, self.dh, B, self.nl1, ws.small, self.gb_perm)
-        ops.gather_add(gof("l1.0.bias"), self.gb_perm, self.nl1, hw, 1, 128)
+
+        def l1_wgrad(wsw):
+            ns = ops.conv_wgrad(self.l1.c, dt, self.inp, self.dh, wsw.slab)
+            ops.wgrad_reduce_perm(wsw.slab, ns, self.nl1, self.nl1, self.cpad, 1, gof("l1.0.weight"), 128, hw, self.cin)
+            ops.fill_f32(self.gb_perm)
+            ops.bias_grad(dt, self.dh, B, self.nl1, wsw.small, self.gb_perm)
+            ops.gather_add(gof("l1.0.bias"), self.gb_perm, self.nl1, hw, 1, 128)
+        wgrad_side(l1_wgrad, 3)
+        flush()
 
 
 class Generator(_HipModule):
@@ -408,7 +435,7 @@ class MnistTrainer:
     info+affine step over G+E (lambda_cat 1, lambda_con .1, lambda_affine .1, :201-203), three Adams (:249-255)."""
 
     def __init__(self, generator, discriminator, encoder, batch_size, dtype="f32", allreduce=None, lr=1e-4, betas=(0.5, 0.999),
-                 lambda_cat=1.0, lambda_con=0.1, lambda_affine=0.1, lrs=None):
+                 lambda_cat=1.0, lambda_con=0.1, lambda_affine=0.1, lrs=None, overlap=False):
         self.G, self.D, self.E, self.B = generator, discriminator, encoder, batch_size
         dt = parse_dtype(dtype)
         for m in (generator, discriminator, encoder):
@@ -439,6 +466,11 @@ class MnistTrainer:
         self.labels = torch.empty(B, device=dev, dtype=torch.int64)
         self.mlp = _approx(dev)
         self.graph = None
+        self.dev = dev
+        # overlap=True: the generator's weight-gradient chains on side lanes beside its backward-data chain (engine.SideStream).  Bit-identical,
+        # but measured SLOWER here (fp32 B=256 7.33 -> 7.60 ms, bf16 B=128 3.32 -> 3.64 ms): this backward is almost all GEMM, so forked chains
+        # only compete with the main chain and add queue hops -- unlike the CelebA step, whose small-kernel phases they fill.  Default off.
+        self.side = SideStream(dev, Workspace.get(dev), lanes=4) if overlap else None
 
     def _adam(self, arena, m, v, lr, slot, tick):
         ops.adam_step(arena.flat, arena.grad, m, v, arena.numel, lr, self.betas[0], self.betas[1], 1e-8, self.steps[slot:slot + 1], tick)
@@ -457,7 +489,10 @@ class MnistTrainer:
         out = de.forward([gen])["adv_layer.0"]
         ops.loss_mse(out, 1, 0, 1, B, None, 0, 1.0, 1.0, self.losses[0:1], self.dout_d[:B])
         dimg = de.backward(0, 1, {"adv_layer.0": self.dout_d[:B]}, da.grad, need_wgrad=False, need_dimg=True)
-        ge.backward(dimg, ga.grad)
+        side = self.side
+        join = side.join if side is not None else (lambda: None)
+        ge.backward(dimg, ga.grad, side)
+        join()
         if self.allreduce is not None:
             self.allreduce(ga.grad)
         self._adam(ga, self.mG, self.vG, self.lr[0], 0, True)
@@ -485,7 +520,8 @@ class MnistTrainer:
                                 self.d_code[B:2 * B], None, self.ws_aff)
         dimg = ee.backward(0, 3, {"aux_layer.0": self.d_cat, "latent_layer.0": self.d_code}, ea.grad, need_dimg=True)
         pending = self.allreduce.start(ea.grad) if (self.allreduce is not None and hasattr(self.allreduce, "start")) else None
-        ge.backward(dimg, ga.grad)                      # overlaps with the encoder-gradient all-reduce
+        ge.backward(dimg, ga.grad, side)                # overlaps with the encoder-gradient all-reduce
+        join()
         if self.allreduce is not None:
             self.allreduce(ga.grad)
             if pending is not None:

@@ -226,3 +226,29 @@ def test_graph_replay_equals_eager():
         torch.cuda.synchronize()
         res.append(torch.stack(out).cpu())
     assert torch.equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_side_lanes_are_bit_identical_to_one_stream(dtype):
+    """the generator's weight-gradient chains on side lanes (overlap=True; off by default for this trainer, where it measured slower) vs everything on one stream: same kernels, same
+    order inside every chain -> identical losses and parameters, eager and replayed"""
+    B = 16
+    res = []
+    for overlap in (False, True):
+        orc, G, D, E = build(5, dtype)
+        tr = eg.mnist.MnistTrainer(G, D, E, B, dtype=dtype, overlap=overlap)
+        assert (tr.side is not None) == overlap
+        rng = np.random.RandomState(2)
+        real = mo.synthetic_real(B, seed=6).to(DEV)
+        out = []
+        for i in range(4):
+            z, code, labels = mo.draw_step_inputs(rng, B)
+            tr.load_inputs(real, z.to(DEV), code.to(DEV), labels.to(DEV))
+            if i == 2:
+                tr.capture()
+                assert tr.graph is not None
+            out.append(tr.step_resident().clone())
+        torch.cuda.synchronize()
+        res.append((torch.stack(out).cpu(), G.arena.flat.clone().cpu(), E.arena.flat.clone().cpu()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
