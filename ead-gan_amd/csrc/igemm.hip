@@ -2210,7 +2210,8 @@ static void tn_plan(const eg_conv* c, int* nsplit, int* rps) {
     long long want = base >= target ? 1 : (target + base - 1) / base;
     long long cap = M / 256 > 0 ? M / 256 : 1;
     if (want > cap) want = cap;
-    if (want > 128) want = 128;
+    static const int max_split = [] { const char* e = getenv("EG_TN_MAXSPLIT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+    if (want > max_split) want = max_split;
     int r = round_up((int)((M + want - 1) / want), 32);
     *rps = r;
     *nsplit = cdiv(M, r);
