@@ -2224,13 +2224,10 @@ extern "C" size_t eg_conv_wgrad_ws_bytes(const eg_conv* c, int dtype) {
     return (size_t)ns * c->Cout * c->k * c->k * c->Cin * sizeof(float);
 }
 
-template <typename T, int BNT, int BCT>
-static void launch_tn_cfg(TnParams& p, int nsplit, hipStream_t st) {
-    p.ntn = cdiv(p.N, BNT); p.ntc = cdiv(p.C, BCT);
-    dim3 grid(p.ntn * p.ntc, p.ntaps, nsplit);
-    constexpr int KR = 32;     // 64 rows per step (half the barriers, same 64 KiB of LDS for bf16) measured 10-20 % slower on the CelebA layers
+template <typename T, int BNT, int BCT, int KR>
+static void launch_tn_kr(TnParams& p, const dim3& grid, hipStream_t st) {
     const size_t lds = 2 * KR * (BNT + BCT) * sizeof(T);
-    if (KR == 64) {
+    if (lds > 65536) {
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_tn_kernel<T, BNT, BCT, KR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2238,6 +2235,21 @@ static void launch_tn_cfg(TnParams& p, int nsplit, hipStream_t st) {
         }
     }
     hipLaunchKernelGGL((igemm_tn_kernel<T, BNT, BCT, KR>), grid, dim3(256), lds, st, p);
+}
+
+template <typename T, int BNT, int BCT>
+static void launch_tn_cfg(TnParams& p, int nsplit, hipStream_t st) {
+    p.ntn = cdiv(p.N, BNT); p.ntc = cdiv(p.C, BCT);
+    dim3 grid(p.ntn * p.ntc, p.ntaps, nsplit);
+    // 32 rows per pipeline step; 64 (half the barriers) measured 10-20 % slower on the CelebA layers.  Launches with ONE output tile (the
+    // image-side layers: the grid is just the split count, <= 128 workgroups streaming the whole activation) are latency-bound on bytes in
+    // flight per workgroup: those get 64 rows per step (colored dSprites B=512: 5.22 -> 5.00 ms; CelebA, dSprites, MNIST neutral to +1 %;
+    // EG_TN_KR64=0 restores 32).
+    static const bool kr64 = [] { const char* e = getenv("EG_TN_KR64"); return !(e && atoi(e) == 0); }();
+    if (kr64 && p.ntn * p.ntc * p.ntaps == 1 && sizeof(T) == 2 && BNT + BCT <= 192)
+        launch_tn_kr<T, BNT, BCT, 64>(p, grid, st);
+    else
+        launch_tn_kr<T, BNT, BCT, 32>(p, grid, st);
 }
 
 template <typename T>
