@@ -600,10 +600,23 @@ __global__ void head_prep_sn_kernel(const float* __restrict__ dy, int ldy, const
         const float tot = block_sum(dot, sm);
         if (threadIdx.x == 0 && coef) coef[t] = tot;
     }
-    if (gb && threadIdx.x < N) {
+    if (gb) {
+        // column sums with all 256 threads: Np = N rounded up to a power of two columns x 256/Np row lanes, combined through LDS in lane
+        // order (deterministic).  N threads walking all rows one dependent load at a time took 60 us for 1536 rows.
+        __shared__ float cs[256];
+        int Np = 1;
+        while (Np < N) Np <<= 1;
+        const int L = 256 / Np, n = threadIdx.x % Np, l = threadIdx.x / Np;
         float a = 0.f;
-        for (int r = 0; r < rows; ++r) a += dy[(size_t)r * ldy + threadIdx.x];
-        gb[threadIdx.x] += a;
+        if (n < N)
+            for (int r = l; r < rows; r += L) a += dy[(size_t)r * ldy + n];
+        cs[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x < N) {
+            float t = 0.f;
+            for (int q = 0; q < L; ++q) t += cs[q * Np + threadIdx.x];
+            gb[threadIdx.x] += t;
+        }
     }
 }
 
