@@ -233,18 +233,29 @@ __global__ void act_grad_mul_rowsum_kernel(const float* __restrict__ g, const fl
     const float tot = block_sum(acc, sm);
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
-__global__ void rowsum_final_kernel(const float* __restrict__ partial, int B, int C, float* __restrict__ gb) {
-    const int c = threadIdx.x;
-    if (c >= C) return;
+// gb[c] += sum_b partial[b][c]: 256 threads = Cp (C rounded up to a power of two) channels x 256/Cp batch lanes, combined through LDS in lane
+// order (deterministic).  One thread per channel walking all B partials was a chain of B dependent loads (40 us at B = 512).
+__global__ __launch_bounds__(256) void rowsum_final_kernel(const float* __restrict__ partial, int B, int C, float* __restrict__ gb) {
+    __shared__ float cs[256];
+    int Cp = 1;
+    while (Cp < C) Cp <<= 1;
+    const int L = 256 / Cp, c = threadIdx.x % Cp, l = threadIdx.x / Cp;
     float a = 0.f;
-    for (int b = 0; b < B; ++b) a += partial[b * C + c];
-    gb[c] += a;
+    if (c < C)
+        for (int b = l; b < B; b += L) a += partial[b * C + c];
+    cs[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        float t = 0.f;
+        for (int q = 0; q < L; ++q) t += cs[q * Cp + threadIdx.x];
+        gb[threadIdx.x] += t;
+    }
 }
 extern "C" int eg_act_grad_mul_bias_nchw(const float* g, const float* a, float* out, int B, int C, int HW, int act, float slope, float* partial,
                                          float* gb, eg_stream_t s) {
     EG_REQUIRE(g && a && out && partial && gb && C <= 64, "eg_act_grad_mul_bias_nchw: bad argument");
     hipLaunchKernelGGL(act_grad_mul_rowsum_kernel, dim3(B * C), dim3(256), 0, (hipStream_t)s, g, a, out, HW, act, slope, partial);
-    hipLaunchKernelGGL(rowsum_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, partial, B, C, gb);
+    hipLaunchKernelGGL(rowsum_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, partial, B, C, gb);
     EG_LAUNCH_CHECK();
     return 0;
 }

@@ -13,7 +13,7 @@ import torch.nn as nn
 from torch.nn.utils import spectral_norm
 
 from . import ops
-from .celeba import _HipModule, _require_cuda, transformation_2D      # noqa: F401
+from .celeba import IMG_GEMM, _HipModule, _require_cuda, transformation_2D      # noqa: F401
 from .engine import Arena, ConvRec, Workspace, capture_step, parse_dtype
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, EG_F32, OUT_NCHW_F32
 from .trunk import Head, TrunkEngine
@@ -202,6 +202,10 @@ class _GenEngine:
         self.k0 = self.CH * 16
         self.kp = ops.round_up(self.k0, 8)
         self.l4p = ConvRec(dtype, B, 32, 32, self.kp, 64, 1, 1, 0, device=dev, want_bwd=False, ws=ws)
+        # forward of the last ConvTranspose2d(64 -> C) as ONE GEMM over the 32x32 lattice with N = 16 taps x C columns + the col2im gather
+        # (eg_col2im_img): every activation read once instead of 16 times (see celeba._GenEngine.l4g)
+        self.l4g = ConvRec(dtype, B, 32, 32, 64, self.k0, 1, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
+        self.cols4 = torch.empty(B * 32 * 32, self.k0, device=dev, dtype=tdt)
         e = lambda *s, dt=tdt: torch.empty(s, device=dev, dtype=dt)
         f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
         self.inp = e(B, self.cpad)
@@ -240,6 +244,7 @@ class _GenEngine:
             self.mid[i].pack(cb[idx].weight)
         self.l4.pack(cb[9].weight)
         ops.pack_strided(dt, cb[9].weight, self.l4p.wp_fwd, 64, self.k0, self.l4p.Kpad_fwd, 1, self.k0, 0, 1)
+        ops.pack_strided(dt, cb[9].weight, self.l4g.wp_fwd, self.k0, 64, self.l4g.Kpad_fwd, self.CH, 1, 16, self.k0)     # wp[t*C + c][ci] = W[ci][c][t]
 
     def forward(self, labels, code, training=True):
         """z_c = cat(one-hot labels, code)  (rp.py:404-405).  ``training=False``: running-stat BatchNorm (module.eval())."""
@@ -259,7 +264,11 @@ class _GenEngine:
             else:
                 ops.bn_fwd_eval(dt, self.z[i], self.a[i], B * (8 << i) ** 2, 64, bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, ws.small, ACT_RELU)
             x = self.a[i]
-        ops.conv_bwd_data(self.l4.c, dt, x, self.l4.wp_bwd, self.img, ops.epilogue(bias=cb[9].bias, act=ACT_SIGMOID, out_mode=OUT_NCHW_F32))
+        if IMG_GEMM:
+            ops.conv_fwd(self.l4g.c, dt, x, self.l4g.wp_fwd, self.cols4, None)
+            ops.col2im_img(dt, self.cols4, B, self.CH, 32, 32, 4, 2, 1, cb[9].bias, ACT_SIGMOID, 0.0, self.img)
+        else:
+            ops.conv_bwd_data(self.l4.c, dt, x, self.l4.wp_bwd, self.img, ops.epilogue(bias=cb[9].bias, act=ACT_SIGMOID, out_mode=OUT_NCHW_F32))
         return self.img
 
     def backward(self, dimg, grad):

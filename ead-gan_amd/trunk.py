@@ -8,6 +8,7 @@ ONE weight-gradient GEMM covers all tapes and the spectral-norm rank-1 terms are
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 
 import torch
@@ -15,6 +16,8 @@ import torch
 from . import ops
 from .engine import ConvRec, Workspace
 from .ops import ACT_LRELU, ACT_NONE, EG_F32, OUT_NCHW_F32
+
+IMG_GEMM = os.environ.get("EG_IMG_GEMM", "1") == "1"     # as in celeba.py
 
 SN_EPS = 1e-12
 
@@ -54,6 +57,13 @@ class TrunkEngine:
         # records (packed panels) for the largest batch; per-tape-count geometries
         self.l0img = ConvRec(dtype, B, size, size, in_ch, self.W[0], k, 2, pad, device=dev, want_fwd=False, want_wgrad=False, ws=ws)
         self.l0p = ConvRec(dtype, NT * B, size // 2, size // 2, self.kp, self.W[0], 1, 1, 0, device=dev, want_bwd=False, ws=ws)
+        # d(img) as ONE GEMM over the layer-0 lattice with N = k*k*C columns + the col2im gather (eg_col2im_img; see celeba._DiscEngine.l1g) where
+        # the GEMM engine takes that N (a multiple of 8: the 4x4 dSprites trunks; the 3x3 single-channel MNIST trunk keeps the implicit form)
+        self.l0g = None
+        if self.k0 % 8 == 0 and in_ch in (1, 3) and size // 2 == (size + 2 * pad - k) // 2 + 1:
+            self.l0g = ConvRec(dtype, B, size // 2, size // 2, self.W[0], self.k0, 1, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
+            self.cols0 = torch.empty(B * (size // 2) ** 2, self.k0, device=dev, dtype=ops.torch_dtype(dtype))
+        self.in_ch, self.k_img, self.pad_img = in_ch, k, pad
         self.mid = [ConvRec(dtype, NT * B, self.hw[i], self.hw[i], self.W[i], self.W[i + 1], k, 2, pad, device=dev, ws=ws) for i in range(L - 1)]
         self.hk = self.hw[-1]
         self.Kc = self.hk * self.hk * self.W[-1]                    # flattened conv-trunk features
@@ -132,6 +142,9 @@ class TrunkEngine:
     def repack(self):
         dt = self.dtype
         self.l0img.pack(self.convs[0].weight_orig)
+        if self.l0g is not None:                        # wp[t*C + c][co] = W[co][c][t]   (Conv2d master [W0][C][k][k])
+            kk = self.k_img * self.k_img
+            ops.pack_strided(dt, self.convs[0].weight_orig, self.l0g.wp_fwd, self.k0, self.W[0], self.l0g.Kpad_fwd, self.in_ch, 1, kk, self.k0)
         ops.pack_strided(dt, self.convs[0].weight_orig, self.l0p.wp_fwd, self.W[0], self.k0, self.l0p.Kpad_fwd, 1, self.k0, 0, 1)
         for i in range(self.L - 1):
             self.mid[i].pack(self.convs[i + 1].weight_orig)
@@ -304,7 +317,11 @@ class TrunkEngine:
                                       ops.epilogue(sigma=self.sigma[i - 1][t0:], sigma_rows=self.rows(i), mask=self._sl(self.a[i - 1], t0), mask_act=ACT_LRELU,
                                                    mask_slope=self.slope))
         if need_dimg:
-            ops.conv_bwd_data(self.l0img.c, dt, self._sl(self.dz[0], t0), self.l0img.wp_bwd, self.dimg, ops.epilogue(out_mode=OUT_NCHW_F32))
+            if self.l0g is not None and IMG_GEMM:
+                ops.conv_fwd(self.l0g.c, dt, self._sl(self.dz[0], t0), self.l0g.wp_fwd, self.cols0, None)
+                ops.col2im_img(dt, self.cols0, B, self.in_ch, self.l0g.H, self.l0g.W, self.k_img, 2, self.pad_img, None, ACT_NONE, 0.0, self.dimg)
+            else:
+                ops.conv_bwd_data(self.l0img.c, dt, self._sl(self.dz[0], t0), self.l0img.wp_bwd, self.dimg, ops.epilogue(out_mode=OUT_NCHW_F32))
             return self.dimg
         return None
 
