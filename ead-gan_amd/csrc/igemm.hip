@@ -49,6 +49,7 @@ struct NtParams {
     int sigma_rows;
     int M;
     float* part;      // split-K partial tiles [split][phase][Mpad][N] fp32 (nsplit > 1)
+    int xcd_remap;    // igemm_nt_buf: 1 = every XCD gets a contiguous range of M tiles (workgroups are dispatched round robin over the 8 XCDs)
     size_t part_bytes;
     int nsplit;
     NtPhase ph[4];
@@ -737,7 +738,10 @@ __global__ __launch_bounds__(256) void igemm_nt_buf_kernel(const NtParams p, uns
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // XCD-aware tile order: workgroup ids go round robin over the 8 XCDs (each with its own L2), so neighbouring M tiles -- which share input
+    // halo rows in an implicit convolution -- would sit on different L2s.  With gridDim.x a multiple of 8, XCD c takes tiles [c, c+1) * gridDim.x / 8.
+    const int bx = (p.xcd_remap && (gridDim.x & 7) == 0) ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int m0 = bx * BM, n0 = blockIdx.y * BN;
     const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
     const int HU = p.H << p.up, WU = p.W << p.up;
     const int rsub = lane >> 3, pos = lane & 7;
@@ -1623,6 +1627,8 @@ static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
         }
         NtParams q = p;
         q.nsplit = ns;
+        static const int xcd = [] { const char* e = getenv("EG_XCD_REMAP"); return e ? atoi(e) : 1; }();   // default on: +1.5 % on the dominant kernel
+        q.xcd_remap = xcd;
         // diagnostic (EG_NT_PROF=1 in the environment): run the instrumented instantiation synchronously and print the per-wave averages of
         // its phase timers (wait+barrier / LDS-DMA issue / ds_read+MFMA / epilogue) -- how DESIGN.md section 6's breakdown was measured
         static const char* prof_env = getenv("EG_NT_PROF");
