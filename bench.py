@@ -48,8 +48,6 @@ def parse():
                     "counter-based z / code / labels): the timed iteration then includes the whole input pipeline")
     ap.add_argument("--sync-bn", action="store_true", help="data parallel: BatchNorm statistics over the global batch (dp.SyncBN); default per-rank")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no side lanes for weight-gradient chains / re-packing")
-    ap.add_argument("--igemm-tuning", default="", help="buf_min_tiles,splitk_target,big_min_tiles,persistent,wide_min_tiles for eg_set_igemm_tuning (experiments)")
-    ap.add_argument("--igemm-dma", type=int, default=4, help="LDS-DMA staged NT kernel variant for large launches (0 off, 1 = 256x128x3, 2 = 128x128x2, 3 = 128x128x3, 4 = buffer-descriptor 128x128x2 [default])")
     ap.add_argument("--workload", default="celeba", choices=["celeba", "mnist", "dsprites", "colored", "pxy"],
                     help="celeba = the headline metric (default); mnist = BASELINE config[1] (use --batch 256 --dtype f32); "
                          "dsprites = config[2] (--batch 128); colored = config[4] (--batch 512)")
@@ -256,9 +254,6 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local)
-    eg._lib.lib().query("eg_set_igemm_dma", a.igemm_dma)
-    if a.igemm_tuning:
-        eg._lib.lib().query("eg_set_igemm_tuning", *[int(v) for v in a.igemm_tuning.split(",")])
     dev = torch.device("cuda", local)
     B = a.batch
     if a.workload == "mnist":

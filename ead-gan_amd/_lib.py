@@ -18,6 +18,8 @@ LIB_PATH = os.path.join(_HERE, "libeadgan_hip.so")
 EG_F32, EG_BF16, EG_F16 = 0, 1, 2
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = range(5)
 OUT_NHWC, OUT_NCHW_F32 = 0, 1
+# eg_epilogue.nt_variant (include/eadgan_hip.h: EG_NT_*)
+NT_AUTO, NT_REG, NT_BUF128, NT_PERS, NT_P8_128, NT_P8_256 = range(6)
 
 
 class EgConv(ctypes.Structure):
@@ -28,7 +30,8 @@ class EgEpilogue(ctypes.Structure):
     _fields_ = [("bias", ctypes.c_void_p), ("bias_mod", ctypes.c_int), ("sigma", ctypes.c_void_p),
                 ("act", ctypes.c_int), ("slope", ctypes.c_float), ("mask", ctypes.c_void_p),
                 ("mask_act", ctypes.c_int), ("mask_slope", ctypes.c_float), ("out_mode", ctypes.c_int), ("sigma_rows", ctypes.c_int),
-                ("splitk_ws", ctypes.c_void_p), ("splitk_ws_bytes", ctypes.c_size_t)]
+                ("splitk_ws", ctypes.c_void_p), ("splitk_ws_bytes", ctypes.c_size_t),
+                ("nt_variant", ctypes.c_int), ("nt_splitk", ctypes.c_int)]
 
 
 class EgSnLayer(ctypes.Structure):

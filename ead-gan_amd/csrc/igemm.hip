@@ -13,51 +13,12 @@
 #include <type_traits>
 
 #include "eg_common.h"
+#include "igemm_nt.h"
 
 // This file is compiled with -ffp-contract=off (Makefile): every NT variant must round the epilogue (acc / sigma + bias) alike -- the
 // variants are tested bit for bit against each other -- and clang contracts `a * b + c` depending on where the operands come from.
 
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
-typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-// ------------------------------------------------------------------------------------------------
-// geometry derived from eg_conv
-// ------------------------------------------------------------------------------------------------
-struct NtPhase {
-    int TH, TW, dy0, dys, dx0, dxs, ooy, oox, K, Kpad;
-    long long w_off;   // element offset of this phase's packed weights
-};
-struct NtParams {
-    const void* src;
-    const void* wp;
-    void* dst;
-    const float* bias;
-    const float* sigma;
-    const void* mask;
-    int B, H, W, C;   // gathered source tensor (NHWC)
-    int lOH, lOW;     // log2 of the output lattice
-    int sy, sx, up;
-    int N, bias_mod;
-    int DH, DW, osy, osx;
-    int act;
-    float slope;
-    int mask_act;
-    float mask_slope;
-    int out_mode;
-    int sigma_rows;
-    int M;
-    float* part;      // split-K partial tiles [split][phase][Mpad][N] fp32 (nsplit > 1)
-    int xcd_remap;    // igemm_nt_buf: 1 = every XCD gets a contiguous range of M tiles (workgroups are dispatched round robin over the 8 XCDs)
-    size_t part_bytes;
-    int nsplit;
-    NtPhase ph[4];
-};
-
-static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
-static inline int bk_of(int dtype) { return dtype == EG_F32 ? 32 : 64; }
-static inline int vec_of(int dtype) { return dtype == EG_F32 ? 4 : 8; }
 
 // K extent of a packed weight panel row: K rounded up to the K tile.  (Skewing pitches that are multiples of 2 KiB by one extra tile
 // was tried against L2 channel aliasing of the 128-byte column slices: no effect on MI355X.)
@@ -131,26 +92,6 @@ static int geom_bwd(const eg_conv* c, int dtype, NtParams& p, int* nphase) {
     return 0;
 }
 
-// ------------------------------------------------------------------------------------------------
-// LDS helpers: rows of 128 bytes, 16-byte chunk c of row r lives at chunk (c ^ ((r>>1)&7))
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-
-// D = B-fragment x A-fragment: the weight-panel rows (n) land on the accumulator ROW index (4 consecutive n per lane),
-// the gathered rows (m) on the lane -> the epilogue packs 4 consecutive output channels per lane.
-template <typename T>
-__device__ __forceinline__ void mfma_step(const uint4& a, const uint4& b, f32x4& acc) {
-    if constexpr (std::is_same<T, float>::value) {
-        const float* af = reinterpret_cast<const float*>(&a);
-        const float* bf = reinterpret_cast<const float*>(&b);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[e], af[e], acc, 0, 0, 0);
-    } else if constexpr (std::is_same<T, f16_t>::value) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, b), __builtin_bit_cast(f16x8_t, a), acc, 0, 0, 0);
-    } else {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b), __builtin_bit_cast(bf16x8_t, a), acc, 0, 0, 0);
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // igemm_nt
@@ -364,311 +305,6 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
 
 
 // ------------------------------------------------------------------------------------------------
-// igemm_nt_dma: 256x128 block tile (4 waves x 128x64), operands staged by LDS-DMA (global_load_lds, no VGPR round trip, no
-// ds_write) into a 3-stage ring; one raw s_barrier per K step with a counted vmcnt so the next stage stays in flight.
-// Compared with the 128x128 register-staged kernel it moves 45 % fewer LDS bytes per MFMA (the 128x128 kernel is LDS-bound:
-// ds_write + ds_read cycles ~= MFMA cycles).  The swizzle lives on the SOURCE address (LDS-DMA writes lane-linear).
-// ------------------------------------------------------------------------------------------------
-__device__ uint4 eg_zero_line[8];     // 128 zero bytes: DMA source for padded / out-of-range rows
-
-// one LDS-DMA piece: 64 lanes x 16 bytes from per-lane global addresses to LDS [lds_base, lds_base + 1 KiB).  Issued through
-// inline asm so that hipcc does not count it (it would otherwise drain vmcnt(0) before the next ds_read); the caller owns the
-// waits (counted s_waitcnt vmcnt + s_barrier before any wave reads the bytes).  M0 is saved/restored inside the statement.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(lds_base)
-                 : "memory");
-}
-
-// shared epilogue of the LDS-DMA kernels: a BM x BNW window of the fp32 tile goes through LDS (XOR-swizzled 16-byte chunks), then 16-byte
-// vector stores with the fused 1/sigma, bias, activation and activation-gradient mask.  Callers __syncthreads() before (the K loop's LDS
-// is reused).  row0 / col0: first row / first window column of the calling wave's accumulators (col0 < 0: wave outside the window);
-// nw0: global column of the window's first column; NT threads per workgroup.
-template <typename T, int BM, int BNW, int TM, int TN, int NT>
-__device__ __forceinline__ void nt_epilogue_lds(const NtParams& p, const NtPhase& ph, f32x4 (&acc)[TM][TN], char* smem, int m0, int nw0, int row0,
-                                                int col0, int tid, int frow, int fq) {
-    constexpr int VEC = Elt<T>::VEC;
-    const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
-    constexpr int SW = 31;
-    float* ct = reinterpret_cast<float*>(smem);
-    if (col0 >= 0) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = row0 + i * 16 + frow;
-            const int mrow = min(m0 + row, p.M - 1);
-            const float inv_sigma = p.sigma ? 1.f / p.sigma[p.sigma_rows ? mrow / p.sigma_rows : 0] : 1.f;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nl = col0 + j * 16 + fq * 4;
-                float4 v;
-                float* ve = reinterpret_cast<float*>(&v);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = __fmul_rn(acc[i][j][r], inv_sigma);
-                    const int n = nw0 + nl + r;
-                    if (p.bias && n < p.N) x = __fadd_rn(x, p.bias[p.bias_mod ? n % p.bias_mod : n]);
-                    ve[r] = eg_act(x, p.act, p.slope);
-                }
-                *reinterpret_cast<float4*>(ct + row * BNW + (((nl >> 2) ^ (row & SW)) << 2)) = v;
-            }
-        }
-    }
-    __syncthreads();
-    constexpr int VPR = BNW / VEC;
-    constexpr int RPP = NT / VPR;
-    const int vc = tid % VPR, vr = tid / VPR;
-    const T* __restrict__ mask = reinterpret_cast<const T*>(p.mask);
-    const int n = nw0 + vc * VEC;
-    if (n < p.N) {
-#pragma unroll 4
-        for (int row = vr; row < BM; row += RPP) {
-            const int m = m0 + row;
-            if (m >= p.M) break;
-            const int b = m >> (p.lOW + p.lOH);
-            const int y = ((m >> p.lOW) & OHm) * p.osy + ph.ooy;
-            const int x = (m & OWm) * p.osx + ph.oox;
-            const size_t o = (((size_t)b * p.DH + y) * p.DW + x) * p.N + n;
-            float f[VEC];
-#pragma unroll
-            for (int q = 0; q < VEC / 4; ++q) {
-                const int chunk = (vc * (VEC / 4) + q) ^ (row & SW);
-                const float4 v = *reinterpret_cast<const float4*>(ct + row * BNW + (chunk << 2));
-                f[q * 4 + 0] = v.x; f[q * 4 + 1] = v.y; f[q * 4 + 2] = v.z; f[q * 4 + 3] = v.w;
-            }
-            if (mask) {
-                const uint4 mv = *reinterpret_cast<const uint4*>(mask + o);
-                const T* me = reinterpret_cast<const T*>(&mv);
-#pragma unroll
-                for (int q = 0; q < VEC; ++q) f[q] *= eg_act_grad_from_out(Elt<T>::ld(me + q), p.mask_act, p.mask_slope);
-            }
-            uint4 ov;
-            T* oe = reinterpret_cast<T*>(&ov);
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) Elt<T>::st(oe + q, f[q]);
-            *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.dst) + o) = ov;
-        }
-    }
-}
-
-// Epilogue operands fetched ahead of the last K step (igemm_nt_buf): 1/sigma per accumulator row block, the bias of the lane's 4 x TN
-// columns and the activation-gradient mask vectors of the first PF store iterations -- their global-load latency (the epilogue's
-// critical path: ~40 % of a 16-step launch) overlaps the last MFMA block and the LDS staging.
-template <typename T, int TM, int TN, int PF>
-struct NtEpiPre {
-    float inv_sigma[TM];
-    float bias[TN][4];
-    uint4 mask[PF];
-};
-
-template <typename T, int BM, int BNW, int TM, int TN, int NT, int PF>
-__device__ __forceinline__ void nt_epi_prefetch(NtEpiPre<T, TM, TN, PF>& e, const NtParams& p, const NtPhase& ph, int m0, int nw0, int row0, int col0,
-                                                int tid, int frow, int fq) {
-    constexpr int VEC = Elt<T>::VEC;
-    constexpr int VPR = BNW / VEC, RPP = NT / VPR;
-    const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int mrow = min(m0 + row0 + i * 16 + frow, p.M - 1);
-        e.inv_sigma[i] = p.sigma ? p.sigma[p.sigma_rows ? mrow / p.sigma_rows : 0] : 1.f;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = nw0 + col0 + j * 16 + fq * 4 + r;
-            e.bias[j][r] = (p.bias && n < p.N) ? p.bias[p.bias_mod ? n % p.bias_mod : n] : 0.f;
-        }
-    const T* __restrict__ mask = reinterpret_cast<const T*>(p.mask);
-    const int vc = tid % VPR, vr = tid / VPR;
-    const int n = nw0 + vc * VEC;
-#pragma unroll
-    for (int it = 0; it < PF; ++it) {
-        const int m = m0 + vr + it * RPP;
-        e.mask[it] = make_uint4(0, 0, 0, 0);
-        if (mask && n < p.N && m < p.M) {
-            const int b = m >> (p.lOW + p.lOH);
-            const int y = ((m >> p.lOW) & OHm) * p.osy + ph.ooy;
-            const int x = (m & OWm) * p.osx + ph.oox;
-            e.mask[it] = *reinterpret_cast<const uint4*>(mask + (((size_t)b * p.DH + y) * p.DW + x) * p.N + n);
-        }
-    }
-}
-
-// nt_epilogue_lds with the operands of NtEpiPre (same arithmetic, same results)
-template <typename T, int BM, int BNW, int TM, int TN, int NT, int PF>
-__device__ __forceinline__ void nt_epilogue_lds_pre(const NtEpiPre<T, TM, TN, PF>& e, const NtParams& p, const NtPhase& ph, f32x4 (&acc)[TM][TN],
-                                                    char* smem, int m0, int nw0, int row0, int col0, int tid, int frow, int fq) {
-    constexpr int VEC = Elt<T>::VEC;
-    const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
-    constexpr int SW = 31;
-    float* ct = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = row0 + i * 16 + frow;
-        const float inv_sigma = p.sigma ? 1.f / e.inv_sigma[i] : 1.f;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nl = col0 + j * 16 + fq * 4;
-            float4 v;
-            float* ve = reinterpret_cast<float*>(&v);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = __fmul_rn(acc[i][j][r], inv_sigma);
-                if (p.bias && nw0 + nl + r < p.N) x = __fadd_rn(x, e.bias[j][r]);
-                ve[r] = eg_act(x, p.act, p.slope);
-            }
-            *reinterpret_cast<float4*>(ct + row * BNW + (((nl >> 2) ^ (row & SW)) << 2)) = v;
-        }
-    }
-    __syncthreads();
-    constexpr int VPR = BNW / VEC;
-    constexpr int RPP = NT / VPR;
-    constexpr int NIT = BM / RPP;
-    const int vc = tid % VPR, vr = tid / VPR;
-    const T* __restrict__ mask = reinterpret_cast<const T*>(p.mask);
-    const int n = nw0 + vc * VEC;
-    if (n < p.N) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int row = vr + it * RPP;
-            const int m = m0 + row;
-            if (m >= p.M) break;
-            const int b = m >> (p.lOW + p.lOH);
-            const int y = ((m >> p.lOW) & OHm) * p.osy + ph.ooy;
-            const int x = (m & OWm) * p.osx + ph.oox;
-            const size_t o = (((size_t)b * p.DH + y) * p.DW + x) * p.N + n;
-            float f[VEC];
-#pragma unroll
-            for (int q = 0; q < VEC / 4; ++q) {
-                const int chunk = (vc * (VEC / 4) + q) ^ (row & SW);
-                const float4 v = *reinterpret_cast<const float4*>(ct + row * BNW + (chunk << 2));
-                f[q * 4 + 0] = v.x; f[q * 4 + 1] = v.y; f[q * 4 + 2] = v.z; f[q * 4 + 3] = v.w;
-            }
-            if (mask) {
-                const uint4 mv = it < PF ? e.mask[it < PF ? it : 0] : *reinterpret_cast<const uint4*>(mask + o);
-                const T* me = reinterpret_cast<const T*>(&mv);
-#pragma unroll
-                for (int q = 0; q < VEC; ++q) f[q] *= eg_act_grad_from_out(Elt<T>::ld(me + q), p.mask_act, p.mask_slope);
-            }
-            uint4 ov;
-            T* oe = reinterpret_cast<T*>(&ov);
-#pragma unroll
-            for (int q = 0; q < VEC; ++q) Elt<T>::st(oe + q, f[q]);
-            *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.dst) + o) = ov;
-        }
-    }
-}
-
-#define EG_DMA_BN 128
-
-template <typename T, int BM, int NST>
-__global__ __launch_bounds__(256) void igemm_nt_dma_kernel(const NtParams p) {
-    constexpr int VEC = Elt<T>::VEC;
-    constexpr int BK = 8 * VEC;
-    constexpr int BN = EG_DMA_BN;
-    constexpr int EG_DMA_STAGE = (BM + BN) * 128;
-    constexpr int EG_DMA_NST = NST;
-    constexpr int TM = BM / 32, TN = 4;           // waves 2 x 2, wave tile (BM/2) x 64
-    constexpr int A_SL = BM / 32, B_SL = BN / 32; // 16-byte DMA slots per thread per stage
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const NtPhase ph = p.ph[blockIdx.z];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
-    const int HU = p.H << p.up, WU = p.W << p.up;
-    // DMA slot j of wave w covers tile rows (j*4+w)*8 .. +7, lane -> (row = base + lane/8, position = lane%8).
-    // (row>>1)&7 == ((w&1)*4 + lane/16) & 7 for every slot, so one source chunk / tap state per thread.
-    const int rsub = lane >> 3, pos = lane & 7;
-    const int srcchunk = pos ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
-
-    int a_pix0[A_SL], a_y[A_SL], a_x[A_SL];
-#pragma unroll
-    for (int j = 0; j < A_SL; ++j) {
-        const int m = m0 + (j * 4 + wave) * 8 + rsub;
-        const int b = m >> (p.lOW + p.lOH);
-        a_pix0[j] = (m < p.M) ? b * p.H * p.W : -1;
-        a_y[j] = ((m >> p.lOW) & OHm) * p.sy + ph.dy0;
-        a_x[j] = (m & OWm) * p.sx + ph.dx0;
-    }
-    int kc = srcchunk * VEC, ty = 0, tx = 0;
-    while (kc >= p.C) { kc -= p.C; if (++tx == ph.TW) { tx = 0; ++ty; } }
-
-    const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
-    const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp) + ph.w_off;
-    const T* zero = reinterpret_cast<const T*>(eg_zero_line);
-    const int nk = ph.Kpad / BK;
-
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    auto issue = [&](int kt, int stage) {
-        const unsigned sa = lds0 + stage * EG_DMA_STAGE;
-        const unsigned sb = sa + BM * 128;
-        const bool tap_ok = ty < ph.TH;
-        const int oy = ty * ph.dys, ox = tx * ph.dxs;
-#pragma unroll
-        for (int j = 0; j < A_SL; ++j) {
-            const int iy = a_y[j] + oy, ix = a_x[j] + ox;
-            const bool ok = tap_ok && a_pix0[j] >= 0 && iy >= 0 && iy < HU && ix >= 0 && ix < WU;
-            const T* g = zero;
-            if (ok) g = src + ((size_t)a_pix0[j] + (size_t)((iy >> p.up) * p.W + (ix >> p.up))) * p.C + kc;
-            glds16(g, __builtin_amdgcn_readfirstlane(sa + (j * 4 + wave) * 8 * 128));
-        }
-#pragma unroll
-        for (int j = 0; j < B_SL; ++j) {
-            const int n = n0 + (j * 4 + wave) * 8 + rsub;
-            const T* g = zero;
-            if (n < p.N) g = wp + (size_t)n * ph.Kpad + (size_t)kt * BK + srcchunk * VEC;
-            glds16(g, __builtin_amdgcn_readfirstlane(sb + (j * 4 + wave) * 8 * 128));
-        }
-        kc += BK;
-        while (kc >= p.C) { kc -= p.C; if (++tx == ph.TW) { tx = 0; ++ty; } }
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int frow = lane & 15, fq = lane >> 4;
-    constexpr int AHEAD = NST - 1;                // stages issued ahead of the one being consumed
-    for (int q = 0; q < AHEAD; ++q)
-        if (q < nk) issue(q, q);
-    for (int kt = 0; kt < nk; ++kt) {
-        // this wave's stage-kt DMA has landed once at most the loads of the (AHEAD-1) younger stages are still outstanding
-        if (NST == 3 && kt + 1 < nk) {
-            if (BM == 256) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                 // everyone's stage kt landed; everyone finished reading stage kt-1
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + AHEAD < nk) issue(kt + AHEAD, (kt + AHEAD) % EG_DMA_NST);
-        const char* sa = smem + (kt % EG_DMA_NST) * EG_DMA_STAGE;
-        const char* sb = sa + BM * 128;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 bfr[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(sb + lds_off((wn * TN + j) * 16 + frow, ks * 4 + fq));
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const uint4 af = *reinterpret_cast<const uint4*>(sa + lds_off((wm * TM + i) * 16 + frow, ks * 4 + fq));
-#pragma unroll
-                for (int j = 0; j < TN; ++j) mfma_step<T>(af, bfr[j], acc[i][j]);
-            }
-        }
-    }
-    __syncthreads();
-
-    nt_epilogue_lds<T, BM, BN, TM, TN, 256>(p, ph, acc, smem, m0, n0, wm * TM * 16, wn * TN * 16, tid, frow, fq);
-}
-
-// ------------------------------------------------------------------------------------------------
 // igemm_nt_buf: 128x128 tile, 2-stage LDS-DMA ring like igemm_nt_dma<.,128,2>, but the gather goes through buffer descriptors
 // (`buffer_load_dwordx4 ... offen lds`): the per-lane part of every address is a 32-bit byte offset that only changes when the
 // K loop moves to the next filter tap, the walk along the channels of a tap is the instruction's SGPR offset, and padded /
@@ -676,17 +312,6 @@ __global__ __launch_bounds__(256) void igemm_nt_dma_kernel(const NtParams p) {
 // address math and no EXEC juggling in the K loop.  Needs C % BK == 0 (every lane of a K step sits in the same tap) and
 // tensors below 2 GiB; the dispatcher falls back to igemm_nt_dma otherwise.
 // ------------------------------------------------------------------------------------------------
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ u32x4_t eg_make_srd(const void* base, unsigned bytes) {
-    const unsigned long long a = (unsigned long long)base;
-    u32x4_t r;
-    r.x = __builtin_amdgcn_readfirstlane((unsigned)a);
-    r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
-    r.z = __builtin_amdgcn_readfirstlane(bytes);
-    r.w = 0x00020000u;
-    return r;
-}
 
 // four 1-KiB LDS-DMA pieces (tile rows (j*4+wave)*8 .. +7, j = 0..3) from one descriptor: LDS bases lds, lds+4K, lds+8K, lds+12K
 __device__ __forceinline__ void eg_bufdma4(const u32x4_t srd, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned soff, unsigned lds) {
@@ -719,7 +344,6 @@ __device__ __forceinline__ void eg_bufdma1(const u32x4_t srd, unsigned v0, unsig
         : "memory");
 }
 
-#define EG_OOB 0x80000000u
 
 template <typename T, bool PROF = false, bool SPLITK = false>   // SPLITK: its own instantiation so that profilers list the split launches apart
 __global__ __launch_bounds__(256) void igemm_nt_buf_kernel(const NtParams p, unsigned long long* prof = nullptr) {
@@ -871,163 +495,6 @@ __global__ __launch_bounds__(256) void igemm_nt_buf_kernel(const NtParams p, uns
         t1 = __builtin_amdgcn_s_memtime();
         unsigned long long* o = prof + ((size_t)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
         o[0] = t1 - t_begin; o[1] = t_wait; o[2] = t_issue; o[3] = t_comp; o[4] = t1 - t0; o[5] = t_begin; o[6] = t1; o[7] = 0;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// igemm_nt_w: 256 x 128 tile, 4 waves x (128 x 64), K steps of 64 BYTES per row (32 bf16 / 16 fp32), 3-stage LDS-DMA ring of 24 KiB
-// stages (72 KiB -> still two workgroups per CU).  The K loop of igemm_nt_buf is bound by the LDS-DMA issue path, not by MFMA: this
-// shape needs 6 pieces and 12 ds_read_b128 per 32 MFMAs and wave where 128x128 needs 8 and 16 (87 vs 64 FLOP per staged byte), and the
-// third stage keeps two K steps in flight.  LDS image: 64-byte rows, 16-byte chunk c of row r at chunk c ^ g((r >> 2) & 3),
-// g = {0,3,2,1}: every 16-lane group of a fragment ds_read_b128 covers 16 different rows and lands on 16 different bank quads.
-// DMA piece = 16 rows x 64 B; slot j of wave w covers tile rows (j*4+w)*16 .. +15 (A: j < 4, B: j < 2).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int eg_g4(int h) { return (4 - h) & 3; }
-__device__ __forceinline__ int lds_off64(int row, int chunk) { return row * 64 + ((chunk ^ eg_g4((row >> 2) & 3)) << 4); }
-
-__device__ __forceinline__ void eg_bufdma2(const u32x4_t srd, unsigned v0, unsigned v1, unsigned soff, unsigned lds) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
-        "buffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
-        "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\t"
-        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(v0), "v"(v1), "s"(srd), "s"(soff), "s"(lds)
-        : "memory", "scc");
-}
-
-template <typename T, bool SPLITK = false>
-__global__ __launch_bounds__(256, 2) void igemm_nt_w_kernel(const NtParams p) {
-    constexpr int VEC = Elt<T>::VEC;
-    constexpr int BK = 4 * VEC;                    // 64 bytes of K per row and step
-    constexpr int BM = 256, BN = 128;
-    constexpr int STAGE = (BM + BN) * 64;          // 24 KiB
-    constexpr int NST = 3;
-    constexpr int TM = 8, TN = 4;                  // waves 2 x 2, wave tile 128 x 64
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int nsplit = SPLITK && p.nsplit > 1 ? p.nsplit : 1;
-    const int phase = blockIdx.z / nsplit, split = blockIdx.z - phase * nsplit;
-    const NtPhase ph = p.ph[phase];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
-    const int HU = p.H << p.up, WU = p.W << p.up;
-    const int rsub = lane >> 2, pos = lane & 3;                  // row inside the 16-row piece, 16-byte slot inside the row
-    const int srcchunk = pos ^ eg_g4((lane >> 4) & 3);           // piece bases are multiples of 16 rows: (row >> 2) & 3 == lane >> 4
-
-    int a_pix0[4], a_y[4], a_x[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + (j * 4 + wave) * 16 + rsub;
-        const int b = m >> (p.lOW + p.lOH);
-        a_pix0[j] = (m < p.M) ? b * p.H * p.W : -1;
-        a_y[j] = ((m >> p.lOW) & OHm) * p.sy + ph.dy0;
-        a_x[j] = (m & OWm) * p.sx + ph.dx0;
-    }
-    const unsigned row_bytes = (unsigned)p.C * sizeof(T);
-    unsigned va[4], vb[2];
-    auto tap_offsets = [&](int ty, int tx) {
-        const int oy = ty * ph.dys, ox = tx * ph.dxs;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int iy = a_y[j] + oy, ix = a_x[j] + ox;
-            const bool ok = a_pix0[j] >= 0 && iy >= 0 && iy < HU && ix >= 0 && ix < WU;
-            const unsigned pix = (unsigned)(a_pix0[j] + (iy >> p.up) * p.W + (ix >> p.up));
-            va[j] = ok ? pix * row_bytes + (unsigned)srcchunk * 16u : EG_OOB;
-        }
-    };
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + (j * 4 + wave) * 16 + rsub;
-        vb[j] = n < p.N ? (unsigned)n * (unsigned)ph.Kpad * (unsigned)sizeof(T) + (unsigned)srcchunk * 16u : EG_OOB;
-    }
-    const u32x4_t srdA = eg_make_srd(p.src, (unsigned)((size_t)p.B * p.H * p.W * p.C * sizeof(T)));
-    const u32x4_t srdB = eg_make_srd(reinterpret_cast<const T*>(p.wp) + ph.w_off, (unsigned)((size_t)p.N * ph.Kpad * sizeof(T)));
-    const int nk_all = ph.Kpad / BK;
-    const int per = (nk_all + nsplit - 1) / nsplit;
-    const int kt0 = split * per;
-    const int nk = min(per, nk_all - kt0);
-
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)wave * 1024u;
-    const int steps_per_tap = p.C / BK;
-    const int tap0 = kt0 / steps_per_tap;
-    int ty = tap0 / ph.TW, tx = tap0 - ty * ph.TW;
-    unsigned kc_bytes = (unsigned)(kt0 - tap0 * steps_per_tap) * 64u;
-    if (ty < ph.TH) tap_offsets(ty, tx);
-    else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) va[j] = EG_OOB;
-    }
-    auto issue = [&](int kt, int stage) {
-        const unsigned sa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)stage * STAGE);
-        eg_bufdma4(srdA, va[0], va[1], va[2], va[3], kc_bytes, sa);
-        eg_bufdma2(srdB, vb[0], vb[1], (unsigned)(kt0 + kt) * 64u, sa + BM * 64);
-        kc_bytes += 64u;
-        if (kc_bytes >= row_bytes) {               // next tap (uniform branch)
-            kc_bytes = 0;
-            if (++tx == ph.TW) { tx = 0; ++ty; }
-            if (ty < ph.TH) tap_offsets(ty, tx);
-            else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) va[j] = EG_OOB;
-            }
-        }
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int frow = lane & 15, fq = lane >> 4;
-    if (nk > 0) issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    int st_use = 0, st_fill = 2;
-    for (int kt = 0; kt < nk; ++kt) {
-        // stage kt has landed once at most the 6 pieces of stage kt+1 are outstanding
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                 // everyone's stage kt landed; everyone finished reading stage kt-1
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < nk) issue(kt + 2, st_fill);
-        const char* sa = smem + st_use * STAGE;
-        const char* sb = sa + BM * 64;
-        uint4 bfr[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(sb + lds_off64((wn * TN + j) * 16 + frow, fq));
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const uint4 af = *reinterpret_cast<const uint4*>(sa + lds_off64((wm * TM + i) * 16 + frow, fq));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) mfma_step<T>(af, bfr[j], acc[i][j]);
-        }
-        st_use = st_use == NST - 1 ? 0 : st_use + 1;
-        st_fill = st_fill == NST - 1 ? 0 : st_fill + 1;
-    }
-    if (nsplit > 1) {
-        const int nphase = gridDim.z / nsplit;
-        float* part = p.part + ((size_t)(split * nphase + phase) * (gridDim.x * BM) + m0) * p.N + n0;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = (wm * TM + i) * 16 + frow;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                *reinterpret_cast<f32x4*>(part + (size_t)row * p.N + (wn * TN + j) * 16 + fq * 4) = acc[i][j];
-        }
-        return;
-    }
-    // the 256 x 128 fp32 tile does not fit the 72 KiB: two windows of 128 rows (= the two wave rows)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        __syncthreads();
-        nt_epilogue_lds<T, 128, 128, TM, TN, 256>(p, ph, acc, smem, m0 + h * 128, n0, 0, wm == h ? wn * TN * 16 : -1, tid, frow, fq);
     }
 }
 
@@ -1244,194 +711,6 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_pers_kernel(const NtParams p,
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// igemm_nt_big: the buffer-descriptor kernel on 256-row tiles with 8 waves (512 threads, one workgroup per CU).  The 128x128 kernel moves
-// 32 KiB from L2 into LDS per 2.1 MFLOP (64 FLOP/B) and saturates the L2 -> LDS path at ~600-700 TFLOP/s; 256x128 (3-stage ring, wave
-// tile 64x64) needs 85 FLOP/B and 256x256 (2 stages, wave tile 128x64) 128 FLOP/B.  DMA slot j of wave w covers tile rows (j*8+w)*8..+7.
-// ------------------------------------------------------------------------------------------------
-template <int STRIDE>
-__device__ __forceinline__ void eg_bufdma4s(const u32x4_t srd, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned soff, unsigned lds) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %7\n\ts_nop 0\n\t"
-        "buffer_load_dwordx4 %1, %5, %6 offen lds\n\t"
-        "s_add_u32 m0, m0, %8\n\ts_nop 0\n\t"
-        "buffer_load_dwordx4 %2, %5, %6 offen lds\n\t"
-        "s_add_u32 m0, m0, %8\n\ts_nop 0\n\t"
-        "buffer_load_dwordx4 %3, %5, %6 offen lds\n\t"
-        "s_add_u32 m0, m0, %8\n\ts_nop 0\n\t"
-        "buffer_load_dwordx4 %4, %5, %6 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(srd), "s"(soff), "s"(lds), "i"(STRIDE)
-        : "memory", "scc");
-}
-template <int STRIDE>
-__device__ __forceinline__ void eg_bufdma2s(const u32x4_t srd, unsigned v0, unsigned v1, unsigned soff, unsigned lds) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %5\n\ts_nop 0\n\t"
-        "buffer_load_dwordx4 %1, %3, %4 offen lds\n\t"
-        "s_add_u32 m0, m0, %6\n\ts_nop 0\n\t"
-        "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(v0), "v"(v1), "s"(srd), "s"(soff), "s"(lds), "i"(STRIDE)
-        : "memory", "scc");
-}
-
-template <typename T, int BN, int WM, int NST>
-__global__ __launch_bounds__(512) void igemm_nt_big_kernel(const NtParams p) {
-    constexpr int VEC = Elt<T>::VEC;
-    constexpr int BK = 8 * VEC;
-    constexpr int BM = 256, WN = 64;
-    constexpr int STAGE = (BM + BN) * 128;
-    constexpr int TM = WM / 16, TN = WN / 16;
-    constexpr int WGN = BN / WN;                   // waves along N (2 or 4); WGM * WGN == 8
-    constexpr int B_SL = BN / 64;                  // B pieces per wave and stage (A: 4)
-    static_assert((BM / WM) * WGN == 8, "8 waves");
-    static_assert(NST == 2 || NST == 3, "ring depth");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int nsplit = p.nsplit > 1 ? p.nsplit : 1;
-    const int phase = blockIdx.z / nsplit, split = blockIdx.z - phase * nsplit;
-    const NtPhase ph = p.ph[phase];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
-    const int HU = p.H << p.up, WU = p.W << p.up;
-    const int rsub = lane >> 3, pos = lane & 7;
-    const int srcchunk = pos ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
-
-    int a_pix0[4], a_y[4], a_x[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + (j * 8 + wave) * 8 + rsub;
-        const int b = m >> (p.lOW + p.lOH);
-        a_pix0[j] = (m < p.M) ? b * p.H * p.W : -1;
-        a_y[j] = ((m >> p.lOW) & OHm) * p.sy + ph.dy0;
-        a_x[j] = (m & OWm) * p.sx + ph.dx0;
-    }
-    const unsigned row_bytes = (unsigned)p.C * sizeof(T);
-    unsigned va[4], vb[B_SL];
-    auto tap_offsets = [&](int ty, int tx) {
-        const int oy = ty * ph.dys, ox = tx * ph.dxs;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int iy = a_y[j] + oy, ix = a_x[j] + ox;
-            const bool ok = a_pix0[j] >= 0 && iy >= 0 && iy < HU && ix >= 0 && ix < WU;
-            const unsigned pix = (unsigned)(a_pix0[j] + (iy >> p.up) * p.W + (ix >> p.up));
-            va[j] = ok ? pix * row_bytes + (unsigned)srcchunk * 16u : EG_OOB;
-        }
-    };
-#pragma unroll
-    for (int j = 0; j < B_SL; ++j) {
-        const int n = n0 + (j * 8 + wave) * 8 + rsub;
-        vb[j] = n < p.N ? (unsigned)n * (unsigned)ph.Kpad * (unsigned)sizeof(T) + (unsigned)srcchunk * 16u : EG_OOB;
-    }
-    const u32x4_t srdA = eg_make_srd(p.src, (unsigned)((size_t)p.B * p.H * p.W * p.C * sizeof(T)));
-    const u32x4_t srdB = eg_make_srd(reinterpret_cast<const T*>(p.wp) + ph.w_off, (unsigned)((size_t)p.N * ph.Kpad * sizeof(T)));
-    const int nk_all = ph.Kpad / BK;
-    const int per = (nk_all + nsplit - 1) / nsplit;
-    const int kt0 = split * per;
-    const int nk = min(per, nk_all - kt0);
-
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem + (unsigned)wave * 1024u;
-    const int steps_per_tap = p.C / BK;
-    const int tap0 = kt0 / steps_per_tap;
-    int ty = tap0 / ph.TW, tx = tap0 - ty * ph.TW;
-    unsigned kc_bytes = (unsigned)(kt0 - tap0 * steps_per_tap) * 128u;
-    if (ty < ph.TH) tap_offsets(ty, tx);
-    else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) va[j] = EG_OOB;
-    }
-    auto issue = [&](int kt, int stage) {
-        const unsigned sa = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)stage * STAGE);
-        eg_bufdma4s<0x2000>(srdA, va[0], va[1], va[2], va[3], kc_bytes, sa);
-        if constexpr (B_SL == 4) eg_bufdma4s<0x2000>(srdB, vb[0], vb[1], vb[2], vb[3], (unsigned)(kt0 + kt) * 128u, sa + BM * 128);
-        else eg_bufdma2s<0x2000>(srdB, vb[0], vb[1], (unsigned)(kt0 + kt) * 128u, sa + BM * 128);
-        kc_bytes += 128u;
-        if (kc_bytes >= row_bytes) {               // next tap (uniform branch)
-            kc_bytes = 0;
-            if (++tx == ph.TW) { tx = 0; ++ty; }
-            if (ty < ph.TH) tap_offsets(ty, tx);
-            else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) va[j] = EG_OOB;
-            }
-        }
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int frow = lane & 15, fq = lane >> 4;
-    constexpr int AHEAD = NST - 1;
-#pragma unroll
-    for (int q = 0; q < AHEAD; ++q)
-        if (q < nk) issue(q, q);
-    int st_use = 0, st_fill = AHEAD % NST;
-    for (int kt = 0; kt < nk; ++kt) {
-        // stage kt has landed once at most the pieces of the (AHEAD-1) younger stages are outstanding (4 + B_SL pieces per stage)
-        if (NST == 3 && kt + 1 < nk) {
-            if constexpr (B_SL == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                 // everyone's stage kt landed; everyone finished reading stage kt-1
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + AHEAD < nk) issue(kt + AHEAD, st_fill);
-        const char* sa = smem + st_use * STAGE;
-        const char* sb = sa + BM * 128;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 bfr[TN];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const uint4*>(sb + lds_off((wn * TN + j) * 16 + frow, ks * 4 + fq));
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const uint4 af = *reinterpret_cast<const uint4*>(sa + lds_off((wm * TM + i) * 16 + frow, ks * 4 + fq));
-#pragma unroll
-                for (int j = 0; j < TN; ++j) mfma_step<T>(af, bfr[j], acc[i][j]);
-            }
-        }
-        st_use = st_use + 1 == NST ? 0 : st_use + 1;
-        st_fill = st_fill + 1 == NST ? 0 : st_fill + 1;
-    }
-    if (nsplit > 1) {
-        const int nphase = gridDim.z / nsplit;
-        float* part = p.part + ((size_t)(split * nphase + phase) * (gridDim.x * BM) + m0) * p.N + n0;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = (wm * TM + i) * 16 + frow;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                *reinterpret_cast<f32x4*>(part + (size_t)row * p.N + (wn * TN + j) * 16 + fq * 4) = acc[i][j];
-        }
-        return;
-    }
-    __syncthreads();
-    if constexpr (BN == 128) {
-        nt_epilogue_lds<T, BM, 128, TM, TN, 512>(p, ph, acc, smem, m0, n0, wm * TM * 16, wn * TN * 16, tid, frow, fq);
-    } else {
-        // 256 x 256 fp32 does not fit the LDS: two 128-column windows
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int col0 = (wn >> 1) == h ? (wn & 1) * TN * 16 : -1;
-            nt_epilogue_lds<T, BM, 128, TM, TN, 512>(p, ph, acc, smem, m0, n0 + h * 128, wm * TM * 16, col0, tid, frow, fq);
-            __syncthreads();
-        }
-    }
-}
-
 // sum of the split-K partial tiles + the fused epilogue (1/sigma, bias, activation, activation-gradient mask), NHWC store.
 // blockIdx.y = phase; 32-bit index arithmetic (M * N / VEC < 2^31, checked by the planner's size limits), shifts when N / VEC is a power
 // of two (lvpr >= 0), one bias modulo per vector: with 64-bit divisions and a modulo per element this copy was ALU-bound.
@@ -1486,86 +765,92 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(const NtParams 
     }
 }
 
-// 0: register-staged kernels only; 1: 256x128 / 3-stage DMA ring; 2: 128x128 / 2-stage DMA (default: +2 % whole-step, bit-exact);
-// 3: 128x128 / 3-stage DMA (1 block per CU); 4: igemm_nt_buf where eligible, else as 2.  Measured on CelebA B=128 bf16: 0 -> 14.55k img/s, 1 -> 12.8k, 2 -> 14.85k, 3 -> 13.1k.
-static int g_use_dma = 4;
-extern "C" int eg_set_igemm_dma(int on) { const int old = g_use_dma; g_use_dma = on; return old; }
+// ------------------------------------------------------------------------------------------------
+// dispatch.  The planner is a pure function of the problem and of the caller's per-call hints (eg_epilogue.nt_variant / nt_splitk):
+// the library keeps no tuning state, so two trainers (or a test and a trainer) in one process cannot interfere.
+//   EG_NT_REG     register-staged 128 x {16,32,64,128} tiles: everything (N < 128, NCHW image outputs, ragged channel counts); the
+//                 bit-exact reference of the other variants
+//   EG_NT_BUF128  128 x 128, 4 waves, 2-stage buffer-descriptor LDS-DMA ring (+ split-K): launches too small for 256-row tiles
+//   EG_NT_PERS    persistent 128 x 128 pipeline: the 1-2-step image-side layers
+//   EG_NT_P8_128 / EG_NT_P8_256   igemm_nt8.hip: 256 x 128 / 256 x 256 tiles, 8 waves, deep ring, half-phase stagger (+ split-K)
+// ------------------------------------------------------------------------------------------------
+template <typename T> void eg_launch_nt8(const NtParams& p, int nphase, int bn, int ns, hipStream_t st);
 
-// tuning knobs of the buffer-descriptor kernels (units: workgroups per launch).  128x128 kernel: launches with fewer tiles than
-// g_buf_min_tiles go to the register-staged kernels; launches below g_splitk_target tiles are split along K (when the caller lent a
-// workspace) to reach that many workgroups.  256-row kernel: taken when the launch has at least g_big_min_tiles of its tiles (0 = never).
-static int g_buf_min_tiles = 512, g_splitk_target = 512, g_big_min_tiles = 0, g_persistent = 0, g_wide_min_tiles = 0;
-extern "C" int eg_set_igemm_tuning(int buf_min_tiles, int splitk_target, int big_min_tiles, int persistent, int wide_min_tiles) {
-    if (wide_min_tiles >= 0) g_wide_min_tiles = wide_min_tiles;
-    if (buf_min_tiles > 0) g_buf_min_tiles = buf_min_tiles;
-    if (splitk_target >= 0) g_splitk_target = splitk_target;
-    if (big_min_tiles >= 0) g_big_min_tiles = big_min_tiles;
-    if (persistent >= 0) g_persistent = persistent;
-    return 0;
-}
-
-enum { NT_PLAN_NONE = 0, NT_PLAN_BUF128 = 1, NT_PLAN_BIG128 = 2, NT_PLAN_BIG256 = 3, NT_PLAN_PERS = 4, NT_PLAN_WIDE = 5 };
 struct NtPlan { int kind, ns; };
 
-static NtPlan nt_plan(const NtParams& p, int nphase, int vec, size_t esize, size_t ws_bytes) {
-    const NtPlan none = {NT_PLAN_NONE, 1};
-    if (g_use_dma != 4 || p.out_mode != EG_OUT_NHWC || (p.N % 128) != 0 || (p.C % vec) != 0) return none;
-    if ((size_t)p.B * p.H * p.W * p.C * esize >= 0x7fffffffull) return none;
-    int nk_min = 1 << 30, nk_max = 0;
+// geometry facts every DMA variant needs
+struct NtFacts { bool dma_ok, c_tiles; int nk_min, nk_max; long long tiles128; };
+static NtFacts nt_facts(const NtParams& p, int nphase, int vec, size_t esize) {
+    NtFacts f{false, false, 1 << 30, 0, 0};
+    f.tiles128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * nphase;
+    if (p.out_mode != EG_OUT_NHWC || (p.N % 128) != 0 || (p.C % vec) != 0) return f;
+    if ((size_t)p.B * p.H * p.W * p.C * esize >= 0x7fffffffull) return f;
     bool single_tap = true;
     for (int i = 0; i < nphase; ++i) {
-        if ((size_t)p.N * p.ph[i].Kpad * esize >= 0x7fffffffull) return none;
-        nk_min = std::min(nk_min, p.ph[i].Kpad / (8 * vec));
-        nk_max = std::max(nk_max, p.ph[i].Kpad / (8 * vec));
+        if ((size_t)p.N * p.ph[i].Kpad * esize >= 0x7fffffffull) return f;
+        f.nk_min = std::min(f.nk_min, p.ph[i].Kpad / (8 * vec));
+        f.nk_max = std::max(f.nk_max, p.ph[i].Kpad / (8 * vec));
         single_tap = single_tap && p.ph[i].TH * p.ph[i].TW == 1;
     }
-    const bool c_tiles = (p.C % (8 * vec)) == 0;     // every lane of a K step sits in the same filter tap
-    if (!c_tiles && !single_tap) return none;
-    const long long tiles = (long long)cdiv(p.M, 128) * (p.N / 128) * nphase;
+    f.c_tiles = (p.C % (8 * vec)) == 0;              // every lane of a K step sits in the same filter tap
+    f.dma_ok = f.c_tiles || single_tap;
+    return f;
+}
+
+// split count: enough workgroups to reach `target`, at least 8 K steps per split, partial tiles must fit the lent scratch
+static int nt_splits(long long wgs, int target, int nk_min, size_t bytes_per_split, size_t ws_bytes, int forced) {
+    if (ws_bytes == 0 || bytes_per_split == 0) return 1;
+    int ns = 1;
+    if (forced > 0) {
+        while (ns * 2 <= forced && nk_min / (ns * 2) >= 1) ns *= 2;
+    } else {
+        while (wgs * ns < target && ns < 16 && nk_min / (ns * 2) >= 8) ns *= 2;
+    }
+    while (ns > 1 && (size_t)ns * bytes_per_split > ws_bytes) ns /= 2;
+    return ns;
+}
+
+static NtPlan nt_plan_auto(const NtParams& p, int nphase, const NtFacts& f, size_t ws_bytes, int splitk);
+
+// variant > 0: that kernel or an error; variant < 0: that kernel where it can run the problem, else the planner's choice (A/B runs)
+static NtPlan nt_plan(const NtParams& p, int nphase, int vec, size_t esize, size_t ws_bytes, int variant, int splitk) {
+    const NtFacts f = nt_facts(p, nphase, vec, esize);
+    const bool prefer = variant < 0;
+    if (prefer) variant = -variant;
+    const NtPlan bad = prefer ? nt_plan_auto(p, nphase, f, ws_bytes, splitk) : NtPlan{-1, 1};
+    const size_t part128 = (size_t)nphase * cdiv(p.M, 128) * 128 * p.N * 4, part256 = (size_t)nphase * cdiv(p.M, 256) * 256 * p.N * 4;
+    switch (variant) {
+        case EG_NT_REG: return {EG_NT_REG, 1};
+        case EG_NT_BUF128:
+            if (!f.dma_ok || !f.c_tiles || f.nk_max < 2) return bad;
+            return {EG_NT_BUF128, nt_splits(f.tiles128, 512, f.nk_min, part128, ws_bytes, splitk)};
+        case EG_NT_PERS: return f.dma_ok ? NtPlan{EG_NT_PERS, 1} : bad;
+        case EG_NT_P8_128:
+        case EG_NT_P8_256:
+            if (!f.dma_ok || !f.c_tiles || (variant == EG_NT_P8_256 && (p.N % 256) != 0)) return bad;
+            return {variant, nt_splits((long long)cdiv(p.M, 256) * (p.N / (variant == EG_NT_P8_256 ? 256 : 128)) * nphase, 224, f.nk_min, part256, ws_bytes, splitk)};
+        case EG_NT_AUTO: return nt_plan_auto(p, nphase, f, ws_bytes, splitk);
+        default: return {-1, 1};
+    }
+}
+
+static NtPlan nt_plan_auto(const NtParams& p, int nphase, const NtFacts& f, size_t ws_bytes, int splitk) {
+    const size_t part128 = (size_t)nphase * cdiv(p.M, 128) * 128 * p.N * 4, part256 = (size_t)nphase * cdiv(p.M, 256) * 256 * p.N * 4;
+    if (!f.dma_ok) return {EG_NT_REG, 1};
     // shallow launches (1-2 K steps: the image-side layers as 1x1 convolutions over patches) are all prologue and epilogue for a
     // workgroup-per-tile kernel: only the persistent pipeline overlaps them
-    if (nk_max < 3 || !c_tiles) return tiles >= 128 ? NtPlan{NT_PLAN_PERS, 1} : none;
-    if (g_wide_min_tiles > 0 && (long long)cdiv(p.M, 256) * (p.N / 128) * nphase >= g_wide_min_tiles) return {NT_PLAN_WIDE, 1};
-    if (g_big_min_tiles > 0) {
-        const int bn = (p.N % 256) == 0 ? 256 : 128;
-        if ((long long)cdiv(p.M, 256) * (p.N / bn) * nphase >= g_big_min_tiles) return {bn == 256 ? NT_PLAN_BIG256 : NT_PLAN_BIG128, 1};
+    if (f.nk_max < 3 || !f.c_tiles) return f.tiles128 >= 128 ? NtPlan{EG_NT_PERS, 1} : NtPlan{EG_NT_REG, 1};
+    // 256-row tiles, one workgroup per CU: K is split until about 256 workgroups exist
+    const long long wgs256 = (long long)cdiv(p.M, 256) * (p.N / 128) * nphase;
+    if (p.M >= 1024 && wgs256 * (splitk > 0 ? splitk : 16) >= 96 && f.nk_min >= 4) {
+        const int ns = nt_splits(wgs256, 224, f.nk_min, part256, ws_bytes, splitk);
+        if (wgs256 * ns >= 96) return {EG_NT_P8_128, ns};
     }
-    if (tiles < g_splitk_target && ws_bytes > 0) {
-        int ns = 1;
-        while (tiles * ns < g_splitk_target && ns < 16 && nk_min / (ns * 2) >= 8) ns *= 2;
-        while (ns > 1 && (size_t)ns * nphase * cdiv(p.M, 128) * 128 * p.N * 4 > ws_bytes) ns /= 2;
-        if (ns > 1) return {NT_PLAN_BUF128, ns};
+    if (f.tiles128 < 512 && ws_bytes > 0) {
+        const int ns = nt_splits(f.tiles128, 512, f.nk_min, part128, ws_bytes, splitk);
+        if (ns > 1) return {EG_NT_BUF128, ns};
     }
-    return tiles >= g_buf_min_tiles ? NtPlan{g_persistent ? NT_PLAN_PERS : NT_PLAN_BUF128, 1} : none;
-}
-
-static bool dma_eligible(const NtParams& p, int nphase, int vec) {
-    if (!g_use_dma || p.out_mode != EG_OUT_NHWC || (p.N % 128) != 0 || (p.N % vec) != 0) return false;
-    for (int i = 0; i < nphase; ++i)
-        if (p.ph[i].Kpad / (8 * vec) < 3) return false;
-    const int bm = g_use_dma == 1 ? 256 : 128;
-    const long long need = g_use_dma == 1 ? 240 : (g_use_dma == 3 ? 256 : 512);   // mode 4 falls back to the 2-stage variant (512)
-    return (long long)cdiv(p.M, bm) * (p.N / EG_DMA_BN) * nphase >= need;
-}
-
-template <typename T, int BM, int NST>
-static void launch_nt_dma_cfg(const NtParams& p, int nphase, hipStream_t st) {
-    static bool attr_set = false;
-    const size_t stage = (size_t)(BM + EG_DMA_BN) * 128;
-    const size_t lds = NST * stage > (size_t)BM * EG_DMA_BN * 4 ? NST * stage : (size_t)BM * EG_DMA_BN * 4;
-    if (!attr_set && lds > 65536) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_nt_dma_kernel<T, BM, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    dim3 grid(cdiv(p.M, BM), p.N / EG_DMA_BN, nphase);
-    hipLaunchKernelGGL((igemm_nt_dma_kernel<T, BM, NST>), grid, dim3(256), lds, st, p);
-}
-
-template <typename T>
-static void launch_nt_dma(const NtParams& p, int nphase, hipStream_t st) {
-    if (g_use_dma == 1) launch_nt_dma_cfg<T, 256, 3>(p, nphase, st);
-    else if (g_use_dma == 3) launch_nt_dma_cfg<T, 128, 3>(p, nphase, st);
-    else launch_nt_dma_cfg<T, 128, 2>(p, nphase, st);
+    return f.tiles128 >= 512 ? NtPlan{EG_NT_BUF128, 1} : NtPlan{EG_NT_REG, 1};
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN>
@@ -1576,37 +861,30 @@ static void launch_nt_cfg(const NtParams& p, int nphase, hipStream_t st) {
 }
 
 template <typename T>
-static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
-    const NtPlan plan = nt_plan(p, nphase, Elt<T>::VEC, sizeof(T), p.part ? p.part_bytes : 0);
-    if (plan.kind == NT_PLAN_BIG128 || plan.kind == NT_PLAN_BIG256) {
-        static bool attr_set[2] = {false, false};
-        const bool wide = plan.kind == NT_PLAN_BIG256;
-        const size_t lds = wide ? 2 * (256 + 256) * 128 : 3 * (256 + 128) * 128;
-        const void* fn = wide ? reinterpret_cast<const void*>(&igemm_nt_big_kernel<T, 256, 128, 2>) : reinterpret_cast<const void*>(&igemm_nt_big_kernel<T, 128, 64, 3>);
-        if (!attr_set[wide]) {
-            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set[wide] = true;
-        }
+static void launch_splitk_epilogue(const NtParams& q, int nphase, int Mpad, hipStream_t st) {
+    // split launches have at most a few thousand tiles: M * N / VEC is far below 2^31
+    const int vpr = q.N / Elt<T>::VEC;
+    const long long vecs = (long long)q.M * vpr;
+    const int blocks = (int)std::min<long long>((vecs + 255) / 256, std::max(1, 256 * 16 / nphase));
+    int lvpr = -1;
+    if ((vpr & (vpr - 1)) == 0) { lvpr = 0; while ((1 << lvpr) < vpr) ++lvpr; }
+    hipLaunchKernelGGL((nt_splitk_epilogue_kernel<T>), dim3(blocks, nphase), dim3(256), 0, st, q, nphase, Mpad, lvpr);
+}
+
+template <typename T>
+static int launch_nt(const NtParams& p, int nphase, int variant, int splitk, hipStream_t st) {
+    const NtPlan plan = nt_plan(p, nphase, Elt<T>::VEC, sizeof(T), p.part ? p.part_bytes : 0, variant, splitk);
+    EG_REQUIRE(plan.kind > 0, "eg_epilogue.nt_variant %d cannot run this problem (M=%d N=%d C=%d)", variant, p.M, p.N, p.C);
+    static const int xcd = [] { const char* e = getenv("EG_XCD_REMAP"); return e ? atoi(e) : 1; }();   // default on
+    if (plan.kind == EG_NT_P8_128 || plan.kind == EG_NT_P8_256) {
         NtParams q = p;
-        q.nsplit = 1;
-        const dim3 grid(cdiv(p.M, 256), p.N / (wide ? 256 : 128), nphase);
-        if (wide) hipLaunchKernelGGL((igemm_nt_big_kernel<T, 256, 128, 2>), grid, dim3(512), lds, st, q);
-        else hipLaunchKernelGGL((igemm_nt_big_kernel<T, 128, 64, 3>), grid, dim3(512), lds, st, q);
-        return;
+        q.nsplit = plan.ns;
+        q.xcd_remap = xcd;
+        eg_launch_nt8<T>(q, nphase, plan.kind == EG_NT_P8_256 ? 256 : 128, plan.ns, st);
+        if (plan.ns > 1) launch_splitk_epilogue<T>(q, nphase, cdiv(p.M, 256) * 256, st);
+        return 0;
     }
-    if (plan.kind == NT_PLAN_WIDE) {
-        static bool attr_set = false;
-        const size_t lds = 3 * (256 + 128) * 64;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_nt_w_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
-        NtParams q = p;
-        q.nsplit = 1;
-        hipLaunchKernelGGL((igemm_nt_w_kernel<T>), dim3(cdiv(p.M, 256), p.N / 128, nphase), dim3(256), lds, st, q);
-        return;
-    }
-    if (plan.kind == NT_PLAN_PERS) {
+    if (plan.kind == EG_NT_PERS) {
         static bool attr_set = false;
         const size_t lds = 2 * (128 + 128) * 128;
         if (!attr_set) {
@@ -1615,9 +893,9 @@ static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
         }
         const int tm = cdiv(p.M, 128), tn = p.N / 128, ntiles = tm * tn * nphase;
         hipLaunchKernelGGL((igemm_nt_pers_kernel<T>), dim3(std::min(ntiles, 512)), dim3(256), lds, st, p, tm, tn, ntiles);
-        return;
+        return 0;
     }
-    if (plan.kind == NT_PLAN_BUF128) {
+    if (plan.kind == EG_NT_BUF128) {
         const int ns = plan.ns;
         static bool attr_set = false;
         const size_t lds = 2 * (128 + 128) * 128;
@@ -1627,10 +905,9 @@ static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
         }
         NtParams q = p;
         q.nsplit = ns;
-        static const int xcd = [] { const char* e = getenv("EG_XCD_REMAP"); return e ? atoi(e) : 1; }();   // default on: +1.5 % on the dominant kernel
         q.xcd_remap = xcd;
         // diagnostic (EG_NT_PROF=1 in the environment): run the instrumented instantiation synchronously and print the per-wave averages of
-        // its phase timers (wait+barrier / LDS-DMA issue / ds_read+MFMA / epilogue) -- how DESIGN.md section 6's breakdown was measured
+        // its phase timers (wait+barrier / LDS-DMA issue / ds_read+MFMA / epilogue) -- how DESIGN.md section 6's round-1 breakdown was measured
         static const char* prof_env = getenv("EG_NT_PROF");
         if (prof_env && ns == 1) {
             const dim3 grid(cdiv(p.M, 128), p.N / 128, nphase);
@@ -1648,7 +925,7 @@ static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
             const int nk = p.ph[0].Kpad / (8 * Elt<T>::VEC);
             fprintf(stderr, "[nt_prof] grid %ux%ux%u nk %d | per wave (s_memtime ticks): total %.0f  wait+barrier %.0f (%.1f/step)  issue %.0f (%.1f/step)  compute %.0f (%.1f/step)  epilogue %.0f\n",
                     grid.x, grid.y, grid.z, nk, tot / nw, wt / nw, wt / nw / nk, is / nw, is / nw / nk, cp / nw, cp / nw / nk, ep / nw);
-            return;
+            return 0;
         }
         if (ns > 1) {
             static bool attr_split = false;
@@ -1657,52 +934,42 @@ static void launch_nt(const NtParams& p, int nphase, hipStream_t st) {
                 attr_split = true;
             }
             hipLaunchKernelGGL((igemm_nt_buf_kernel<T, false, true>), dim3(cdiv(p.M, 128), p.N / 128, nphase * ns), dim3(256), lds, st, q);
+            launch_splitk_epilogue<T>(q, nphase, cdiv(p.M, 128) * 128, st);
         } else
-            hipLaunchKernelGGL((igemm_nt_buf_kernel<T>), dim3(cdiv(p.M, 128), p.N / 128, nphase * ns), dim3(256), lds, st, q);
-        if (ns > 1) {
-            // split launches have < g_splitk_target (<= a few thousand) tiles of 128 x 128: M * N / VEC is far below 2^31
-            const int vpr = p.N / Elt<T>::VEC;
-            const long long vecs = (long long)p.M * vpr;
-            const int blocks = (int)std::min<long long>((vecs + 255) / 256, std::max(1, 256 * 16 / nphase));
-            int lvpr = -1;
-            if ((vpr & (vpr - 1)) == 0) { lvpr = 0; while ((1 << lvpr) < vpr) ++lvpr; }
-            hipLaunchKernelGGL((nt_splitk_epilogue_kernel<T>), dim3(blocks, nphase), dim3(256), 0, st, q, nphase, cdiv(p.M, 128) * 128, lvpr);
-        }
-        return;
-    }
-    if (dma_eligible(p, nphase, Elt<T>::VEC)) {
-        launch_nt_dma<T>(p, nphase, st);
-        return;
+            hipLaunchKernelGGL((igemm_nt_buf_kernel<T>), dim3(cdiv(p.M, 128), p.N / 128, nphase), dim3(256), lds, st, q);
+        return 0;
     }
     if (p.N <= 16)
         launch_nt_cfg<T, 128, 16, 4, 1>(p, nphase, st);
     else if (p.N <= 32)
         launch_nt_cfg<T, 128, 32, 4, 1>(p, nphase, st);
-    else if (p.N <= 64 || (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * nphase < 512)
+    else if (p.N <= 64 || (variant != EG_NT_REG && (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * nphase < 512))
         launch_nt_cfg<T, 128, 64, 2, 2>(p, nphase, st);
     else
         launch_nt_cfg<T, 128, 128, 2, 2>(p, nphase, st);
+    return 0;
 }
 
-/* which igemm_nt instantiation a problem is dispatched to (profiling labels only; same predicates as launch_nt): BM*1000 + BN, where
- * BN 129 / 130 / 131 stand for the 128-wide LDS-DMA variants (2-stage, 3-stage, buffer-descriptor). */
-extern "C" int eg_igemm_nt_tile(int dtype, int M, int N, int C, int K, int nphase) {
+/* which igemm_nt instantiation a problem is dispatched to (profiling labels and tests; same planner as the launches): BM * 1000 + code,
+ * code = BN of the register-staged kernels, or 131 / 132 buffer-descriptor 128 x 128 (plain / split-K), 135 persistent pipeline,
+ * 141 / 142 igemm_nt8<128> (plain / split-K), 143 / 144 igemm_nt8<256>; -1 if the forced variant cannot run the problem. */
+extern "C" int eg_igemm_nt_tile(int dtype, int M, int N, int C, int K, int nphase, int variant, int splitk) {
     const int vec = vec_of(dtype), bk = bk_of(dtype);
     NtParams p{};
     p.out_mode = EG_OUT_NHWC; p.M = M; p.N = N; p.C = C; p.B = 1; p.H = 1; p.W = 1;
     for (int i = 0; i < nphase && i < 4; ++i) { p.ph[i].Kpad = round_up(K, bk); p.ph[i].TH = 1; p.ph[i].TW = std::max(1, K / std::max(C, 1)); }
-    const NtPlan plan = nt_plan(p, nphase, vec, dtype == EG_F32 ? 4 : 2, (size_t)1 << 40);
-    if (plan.kind == NT_PLAN_BIG128) return 256 * 1000 + 133;
-    if (plan.kind == NT_PLAN_BIG256) return 256 * 1000 + 134;
-    if (plan.kind == NT_PLAN_WIDE) return 256 * 1000 + 136;
-    if (plan.kind == NT_PLAN_PERS) return 128 * 1000 + 135;
-    if (plan.kind == NT_PLAN_BUF128) return 128 * 1000 + (plan.ns > 1 ? 132 : 131);
-    if (dma_eligible(p, nphase, vec)) return g_use_dma == 1 ? 256 * 1000 + 128 : (g_use_dma == 3 ? 128 * 1000 + 130 : 128 * 1000 + 129);
+    const NtPlan plan = nt_plan(p, nphase, vec, dtype == EG_F32 ? 4 : 2, (size_t)1 << 40, variant, splitk);
+    if (plan.kind < 0) return -1;
+    if (plan.kind == EG_NT_P8_128) return 256 * 1000 + (plan.ns > 1 ? 142 : 141);
+    if (plan.kind == EG_NT_P8_256) return 256 * 1000 + (plan.ns > 1 ? 144 : 143);
+    if (plan.kind == EG_NT_PERS) return 128 * 1000 + 135;
+    if (plan.kind == EG_NT_BUF128) return 128 * 1000 + (plan.ns > 1 ? 132 : 131);
     if (N <= 16) return 128 * 1000 + 16;
     if (N <= 32) return 128 * 1000 + 32;
-    if (N <= 64 || (long long)cdiv(M, 128) * cdiv(N, 128) * nphase < 512) return 128 * 1000 + 64;
+    if (N <= 64 || (variant != EG_NT_REG && (long long)cdiv(M, 128) * cdiv(N, 128) * nphase < 512)) return 128 * 1000 + 64;
     return 128 * 1000 + 128;
 }
+
 
 static void fill_epilogue(NtParams& p, const eg_epilogue* ep) {
     p.bias = ep ? ep->bias : nullptr;
@@ -1728,9 +995,12 @@ extern "C" int eg_conv_fwd(const eg_conv* c, int dtype, const void* X, const voi
     geom_fwd(c, dtype, p);
     p.src = X; p.wp = wp_fwd; p.dst = Y;
     fill_epilogue(p, ep);
-    if (dtype == EG_F32) launch_nt<float>(p, 1, (hipStream_t)s);
-    else if (dtype == EG_F16) launch_nt<f16_t>(p, 1, (hipStream_t)s);
-    else launch_nt<bf16_t>(p, 1, (hipStream_t)s);
+    const int variant = ep ? ep->nt_variant : EG_NT_AUTO, splitk = ep ? ep->nt_splitk : 0;
+    int rc;
+    if (dtype == EG_F32) rc = launch_nt<float>(p, 1, variant, splitk, (hipStream_t)s);
+    else if (dtype == EG_F16) rc = launch_nt<f16_t>(p, 1, variant, splitk, (hipStream_t)s);
+    else rc = launch_nt<bf16_t>(p, 1, variant, splitk, (hipStream_t)s);
+    if (rc) return rc;
     EG_LAUNCH_CHECK();
     return 0;
 }
@@ -1745,9 +1015,12 @@ extern "C" int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, con
     if (int e = geom_bwd(c, dtype, p, &nphase)) return e;
     p.src = dY; p.wp = wp_bwd; p.dst = dX;
     fill_epilogue(p, ep);
-    if (dtype == EG_F32) launch_nt<float>(p, nphase, (hipStream_t)s);
-    else if (dtype == EG_F16) launch_nt<f16_t>(p, nphase, (hipStream_t)s);
-    else launch_nt<bf16_t>(p, nphase, (hipStream_t)s);
+    const int variant = ep ? ep->nt_variant : EG_NT_AUTO, splitk = ep ? ep->nt_splitk : 0;
+    int rc;
+    if (dtype == EG_F32) rc = launch_nt<float>(p, nphase, variant, splitk, (hipStream_t)s);
+    else if (dtype == EG_F16) rc = launch_nt<f16_t>(p, nphase, variant, splitk, (hipStream_t)s);
+    else rc = launch_nt<bf16_t>(p, nphase, variant, splitk, (hipStream_t)s);
+    if (rc) return rc;
     EG_LAUNCH_CHECK();
     return 0;
 }
@@ -1760,8 +1033,11 @@ extern "C" size_t eg_conv_splitk_ws_bytes(const eg_conv* c, int dtype, int bwd) 
     if (bwd) { if (geom_bwd(c, dtype, p, &nphase)) return 0; }
     else geom_fwd(c, dtype, p);
     p.out_mode = EG_OUT_NHWC;
-    const NtPlan plan = nt_plan(p, nphase, vec_of(dtype), dtype == EG_F32 ? 4 : 2, (size_t)1 << 40);
-    return plan.ns > 1 ? (size_t)plan.ns * nphase * cdiv(p.M, 128) * 128 * p.N * 4 : 0;
+    // what the planner would split into with unlimited scratch (callers size one shared scratch from the maximum over their layers)
+    const NtPlan plan = nt_plan(p, nphase, vec_of(dtype), dtype == EG_F32 ? 4 : 2, (size_t)1 << 40, EG_NT_AUTO, 0);
+    if (plan.ns <= 1) return 0;
+    const int bm = (plan.kind == EG_NT_P8_128 || plan.kind == EG_NT_P8_256) ? 256 : 128;
+    return (size_t)plan.ns * nphase * cdiv(p.M, bm) * bm * p.N * 4;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -6,11 +6,12 @@ torch is used for device memory and streams only.  No function here has a CPU or
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
-from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, EG_BF16, EG_F16, EG_F32, OUT_NCHW_F32,
-                   OUT_NHWC, EgConv, EgEpilogue, EgSnLayer, lib)
+from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, EG_BF16, EG_F16, EG_F32, NT_AUTO, NT_BUF128,
+                   NT_P8_128, NT_P8_256, NT_PERS, NT_REG, OUT_NCHW_F32, OUT_NHWC, EgConv, EgEpilogue, EgSnLayer, lib)
 
 __all__ = ["EG_F32", "EG_BF16", "EG_F16", "ACT_NONE", "ACT_LRELU", "ACT_RELU", "ACT_TANH", "ACT_SIGMOID", "OUT_NHWC",
            "OUT_NCHW_F32"]
@@ -56,11 +57,20 @@ def conv_splitk_ws_bytes(c, dtype, bwd):
     return lib().query("eg_conv_splitk_ws_bytes", ctypes.byref(c), dtype, int(bwd))
 
 
+# experiment switches (A/B runs of a whole step): default hints of every launch that does not pass its own
+_ENV_VARIANT = int(os.environ.get("EG_NT_VARIANT", "0"))
+_ENV_SPLITK = int(os.environ.get("EG_NT_SPLITK", "0"))
+
+
 def epilogue(bias=None, bias_mod=0, sigma=None, act=ACT_NONE, slope=0.0, mask=None, mask_act=ACT_NONE,
-             mask_slope=0.0, out_mode=OUT_NHWC, sigma_rows=0) -> EgEpilogue:
-    ws = SPLITK_WS.get(torch.cuda.current_device()) if SPLITK_WS else None
+             mask_slope=0.0, out_mode=OUT_NHWC, sigma_rows=0, nt_variant=_ENV_VARIANT, nt_splitk=_ENV_SPLITK, splitk_ws="default") -> EgEpilogue:
+    """``nt_variant`` / ``nt_splitk``: per-call kernel hints (NT_* in _lib.py; 0 = the planner decides).  ``splitk_ws``: scratch
+    tensor lent for K splits (default: the device's registered workspace; None = never split)."""
+    ws = splitk_ws
+    if isinstance(ws, str):
+        ws = SPLITK_WS.get(torch.cuda.current_device()) if SPLITK_WS else None
     return EgEpilogue(_p(bias), bias_mod, _p(sigma), act, slope, _p(mask), mask_act, mask_slope, out_mode, sigma_rows,
-                      _p(ws), ws.numel() * ws.element_size() if ws is not None else 0)
+                      _p(ws), ws.numel() * ws.element_size() if ws is not None else 0, nt_variant, nt_splitk)
 
 
 # ---- implicit-GEMM family ------------------------------------------------------------------------
@@ -102,7 +112,7 @@ def _out_hw(c):
     return ((c.H << c.up) + 2 * c.pad - c.k) // c.stride + 1, ((c.W << c.up) + 2 * c.pad - c.k) // c.stride + 1
 
 
-def _timed(kind, c, dtype, args):
+def _timed(kind, c, dtype, args, ep=None):
     oh, ow = _out_hw(c)
     M = c.B * oh * ow
     flops = 2.0 * M * c.Cout * c.Cin * c.k * c.k
@@ -112,11 +122,13 @@ def _timed(kind, c, dtype, args):
     else:
         N, C, K, nph = (c.Cout, c.Cin, c.k * c.k * c.Cin, 1) if kind == "fwd" else \
             (c.Cin, c.Cout, (c.k // c.stride) ** 2 * c.Cout, c.stride * c.stride)
-        tile = lib().query("eg_igemm_nt_tile", dtype, M, N, C, K, nph)
+        tile = lib().query("eg_igemm_nt_tile", dtype, M, N, C, K, nph, ep.nt_variant if ep is not None else 0,
+                           (ep.nt_splitk if ep.splitk_ws else 1) if ep is not None else 1)
         bm, bn = tile // 1000, tile % 1000
-        label = {129: f"igemm_nt_dma_kernel<{tname},{bm},2>", 130: f"igemm_nt_dma_kernel<{tname},{bm},3>",
-                 131: f"igemm_nt_buf_kernel<{tname}>", 132: f"igemm_nt_buf_kernel<{tname}>+splitk",
-                 135: f"igemm_nt_pers_kernel<{tname}>", 136: f"igemm_nt_w_kernel<{tname}>", 133: f"igemm_nt_big_kernel<{tname},128,64,3>", 134: f"igemm_nt_big_kernel<{tname},256,128,2>"}.get(bn, f"igemm_nt_dma_kernel<{tname},256,3>" if bm == 256 else f"igemm_nt_kernel<{tname},{bm},{bn}>")
+        label = {131: f"igemm_nt_buf_kernel<{tname}>", 132: f"igemm_nt_buf_kernel<{tname}>+splitk",
+                 135: f"igemm_nt_pers_kernel<{tname}>",
+                 141: f"igemm_nt8_kernel<{tname},128>", 142: f"igemm_nt8_kernel<{tname},128>+splitk",
+                 143: f"igemm_nt8_kernel<{tname},256>", 144: f"igemm_nt8_kernel<{tname},256>+splitk"}.get(bn, f"igemm_nt_kernel<{tname},{bm},{bn}>")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     lib().call(*args, _stream())
@@ -129,7 +141,7 @@ def conv_fwd(c, dtype, X, wp, Y, ep=None):
         ep = epilogue()          # carries the split-K scratch
     args = ("eg_conv_fwd", ctypes.byref(c), dtype, _p(X), _p(wp), _p(Y), ctypes.byref(ep) if ep is not None else None)
     if RECORDER is not None:
-        return _timed("fwd", c, dtype, args)
+        return _timed("fwd", c, dtype, args, ep)
     lib().call(*args, _stream())
 
 
@@ -138,7 +150,7 @@ def conv_bwd_data(c, dtype, dY, wp, dX, ep=None):
         ep = epilogue()
     args = ("eg_conv_bwd_data", ctypes.byref(c), dtype, _p(dY), _p(wp), _p(dX), ctypes.byref(ep) if ep is not None else None)
     if RECORDER is not None:
-        return _timed("bwd", c, dtype, args)
+        return _timed("bwd", c, dtype, args, ep)
     lib().call(*args, _stream())
 
 

@@ -61,7 +61,18 @@ typedef struct eg_epilogue {
     int sigma_rows;
     void* splitk_ws;          /* optional caller-owned scratch: lets small-M / deep-K launches split K across workgroups */
     size_t splitk_ws_bytes;   /* (fp32 partial tiles, summed in a fixed order by a second launch); NULL / 0 = never split */
+    int nt_variant;           /* EG_NT_AUTO (0): the planner picks the kernel; otherwise force one (the call fails if it cannot run the problem) */
+    int nt_splitk;            /* 0: the planner picks the K split; n >= 1: at most n splits (1 = never) */
 } eg_epilogue;
+
+/* kernels behind eg_conv_fwd / eg_conv_bwd_data.  The choice is a pure function of the problem and of these two per-call fields:
+ * the library holds no tuning state.  All variants accumulate K in the same order: without a K split they are bit-identical. */
+#define EG_NT_AUTO 0
+#define EG_NT_REG 1      /* register-staged 128 x {16,32,64,128} tiles: every problem; the reference of the others */
+#define EG_NT_BUF128 2   /* 128 x 128, 4 waves, 2-stage buffer-descriptor LDS-DMA ring */
+#define EG_NT_PERS 3     /* persistent 128 x 128 pipeline (1-2-step image-side layers) */
+#define EG_NT_P8_128 4   /* 256 x 128, 8 waves, 3-K-tile ring, half-phase stagger (igemm_nt8.hip) */
+#define EG_NT_P8_256 5   /* 256 x 256, 8 waves, ten-slot ring */
 
 /* --- implicit-GEMM convolution family (MFMA) ---------------------------------------------------
  * replaces torch.nn.functional.conv2d / conv_transpose2d / linear and their autograd backward:
@@ -79,21 +90,11 @@ int eg_conv_fwd(const eg_conv* c, int dtype, const void* X, const void* wp_fwd, 
 /* dX = conv^T(dY, W)  (== ConvTranspose2d forward); dX has spatial dims (H<<up, W<<up) */
 int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, const void* wp_bwd, void* dX,
                      const eg_epilogue* ep, eg_stream_t s);
-/* tile (BM*1000+BN) of the igemm_nt instantiation a problem (M rows, N columns, C gathered channels per tap, K per phase) is
- * dispatched to; BN = 129 / 130 / 131 / 132 name the 128-wide LDS-DMA variants (2-stage, 3-stage, buffer-descriptor, the latter with
- * split-K), 133 / 134 the 256-row buffer-descriptor kernel with 128 / 256 columns, 135 the persistent 128x128 pipeline, 136 igemm_nt_w.  Profiling labels only. */
-int eg_igemm_nt_tile(int dtype, int M, int N, int C, int K, int nphase);
-/* LDS-DMA (global_load_lds) staged variants of the NT kernel for large launches: 0 = off (register staging only),
- * 1 = 256x128 tile / 3-stage ring, 2 = 128x128 tile / 2 stages, 3 = 128x128 / 3 stages, 4 (default) = 128x128 / 2 stages gathered
- * through buffer descriptors (`buffer_load ... lds`, scalar tap bookkeeping) where C is a multiple of the K tile, else as 2.  Returns the previous
- * setting.  All variants are bit-identical to the register-staged kernel; measurements in DESIGN.md section 4. */
-int eg_set_igemm_dma(int on);
-/* dispatch policy of the buffer-descriptor kernels, thresholds in workgroups per launch.  In this order: launches with at least
- * wide_min_tiles tiles of 256 rows run igemm_nt_w (256x128 tile, 64-byte K steps, 3-stage ring; 0 = never); with at least big_min_tiles
- * the 8-wave 256x256 / 256x128 kernels (0 = never, the default: slower); otherwise the 128x128 kernel runs when there are at least
- * buf_min_tiles tiles -- one workgroup per tile, or one persistent pipeline over all tiles (persistent = 1) -- and is split along K
- * (eg_epilogue.splitk_ws lent) below splitk_target tiles.  Arguments <= 0 / < 0 / < 0 / < 0 / < 0 keep the current value. */
-int eg_set_igemm_tuning(int buf_min_tiles, int splitk_target, int big_min_tiles, int persistent, int wide_min_tiles);
+/* which kernel a problem (M rows, N columns, C gathered channels per tap, K per phase) is dispatched to under the given hints:
+ * BM * 1000 + code; code = BN of the register-staged kernels, 131 / 132 = 128 x 128 buffer-descriptor kernel (plain / split-K),
+ * 135 = persistent pipeline, 141 / 142 = igemm_nt8<128> (plain / split-K), 143 / 144 = igemm_nt8<256>; -1 = the forced variant
+ * cannot run the problem.  Profiling labels and tests. */
+int eg_igemm_nt_tile(int dtype, int M, int N, int C, int K, int nphase, int variant, int splitk);
 /* bytes of eg_epilogue.splitk_ws that let eg_conv_fwd (bwd = 0) / eg_conv_bwd_data (bwd = 1) split as far as the policy wants */
 size_t eg_conv_splitk_ws_bytes(const eg_conv* c, int dtype, int bwd);
 /* dW partial slabs: slab[split][Cout][k*k][Cin] fp32.  Returns the split count through *nsplit. */

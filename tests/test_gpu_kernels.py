@@ -447,26 +447,20 @@ def test_spectral_norm_multi_layer_launch_matches_single():
         torch.testing.assert_close(sg, s1, rtol=1e-5, atol=1e-6)
 
 
-# (eg_set_igemm_dma mode, big_min_tiles) -> label of the kernel the forward case below must be dispatched to
-NT_VARIANTS = [((1, 0), 256128), ((2, 0), 128129), ((3, 0), 128130), ((4, 0), 128131), ((4, -1), 128135), ((4, -2), 256136), ((4, 224), 256133),
-               ((0, 0), 128128)]
-
-
-def _set_variant(lib, mode, big):
-    """big == -1: the persistent 128x128 pipeline; big == -2: igemm_nt_w (256x128, 64-byte K steps) from 64 tiles on; otherwise one
-    workgroup per 128x128 tile and big_min_tiles = big"""
-    lib.query("eg_set_igemm_dma", mode)
-    lib.query("eg_set_igemm_tuning", 512, 512, max(big, 0), 1 if big == -1 else 0, 64 if big == -2 else 0)
+# eg_epilogue.nt_variant values (include/eadgan_hip.h EG_NT_*) -> label eg_igemm_nt_tile reports for the 128-column cases below
+NT_REG, NT_BUF128, NT_PERS, NT_P8_128, NT_P8_256 = 1, 2, 3, 4, 5
+NT_VARIANTS = [(NT_BUF128, 128131), (NT_PERS, 128135), (NT_P8_128, 256141), (NT_REG, 128128)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_igemm_dma_variant_matches_register_staged_kernel(dtype):
-    """Every LDS-DMA variant of the NT kernel (global_load_lds 256x128 / 128x128 rings, buffer-descriptor 128x128, 256x128 and
-    256x256 tiles): bit-exact vs the 128x128 register-staged kernel (same K order) and within tolerance of torch, for a padded
-    stride-2 forward conv, a 4-phase backward-data and a 256-column forward."""
+def test_igemm_variants_match_register_staged_kernel(dtype):
+    """Every LDS-DMA variant of the NT kernel, forced per call through eg_epilogue.nt_variant (the library keeps no tuning state):
+    128x128 buffer-descriptor kernel, persistent pipeline, and the 8-wave 256x128 / 256x256 kernels of igemm_nt8.hip -- bit-exact vs
+    the register-staged kernel (same K order) and within tolerance of torch, for a padded stride-2 forward conv, a 4-phase
+    backward-data with per-tape 1/sigma and an activation mask, and a 256-column forward."""
     lib = eg._lib.lib()
     g = torch.Generator().manual_seed(21)
-    # forward: B=64, 64x64x64 -> 32x32x128  (M = 65536 -> 512 tiles of 128)
+    # forward: B=64, 64x64x64 -> 32x32x128  (M = 65536: 512 tiles of 128 rows, 256 of 256)
     B, H, Cin, Cout = 64, 64, 64, 128
     x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
     w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.05
@@ -476,19 +470,19 @@ def test_igemm_dma_variant_matches_register_staged_kernel(dtype):
     ops.pack_fwd(c, dtype, w.to(DEV), wp)
     xd = nhwc(x, dtype)
     outs = []
-    for (mode, big), label in NT_VARIANTS:
-        _set_variant(lib, mode, big)
-        assert lib.query("eg_igemm_nt_tile", dtype, B * 32 * 32, Cout, Cin, 16 * Cin, 1) == label
+    for variant, label in NT_VARIANTS:
+        assert lib.query("eg_igemm_nt_tile", dtype, B * 32 * 32, Cout, Cin, 16 * Cin, 1, variant, 1) == label
         y = torch.zeros(B, 32, 32, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
-        ops.conv_fwd(c, dtype, xd, wp, y, ops.epilogue(bias=b.to(DEV), act=ops.ACT_LRELU, slope=0.2))
+        ops.conv_fwd(c, dtype, xd, wp, y, ops.epilogue(bias=b.to(DEV), act=ops.ACT_LRELU, slope=0.2, nt_variant=variant, nt_splitk=1))
         torch.cuda.synchronize()
         outs.append(y)
-    _set_variant(lib, 4, 0)
     assert all(torch.equal(o, outs[-1]) for o in outs[:-1])
     want = F.leaky_relu(F.conv2d(x, rq(w, dtype), b, 2, 1), 0.2)
     rt, at = tol(dtype, Cin * 16)
     torch.testing.assert_close(nchw(outs[0]), want, rtol=rt, atol=at)
-    # backward-data: dY [16,32,32,64] -> dX [16,64,64,128], 4 phases of M = 16384
+    # the planner on its own picks the 8-wave kernel for this launch
+    assert lib.query("eg_igemm_nt_tile", dtype, B * 32 * 32, Cout, Cin, 16 * Cin, 1, 0, 0) == 256141
+    # backward-data: dY [16,32,32,64] -> dX [16,64,64,128], 4 phases of M = 16384, two tapes
     B, H, Cin, Cout = 16, 64, 128, 64
     dy = rq(torch.randn(B, Cout, 32, 32, generator=g), dtype)
     w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.05
@@ -498,21 +492,20 @@ def test_igemm_dma_variant_matches_register_staged_kernel(dtype):
     ops.pack_bwd(c, dtype, w.to(DEV), wp)
     sig = torch.tensor([1.3, 0.7], device=DEV)
     outs = []
-    for (mode, big), _ in NT_VARIANTS:
-        _set_variant(lib, mode, big)
+    for variant, _ in NT_VARIANTS:
         dx = torch.zeros(B, H, H, Cin, device=DEV, dtype=ops.torch_dtype(dtype))
         ops.conv_bwd_data(c, dtype, nhwc(dy, dtype), wp, dx,
-                          ops.epilogue(sigma=sig, sigma_rows=8 * 32 * 32, mask=nhwc(a, dtype), mask_act=ops.ACT_LRELU, mask_slope=0.1))
+                          ops.epilogue(sigma=sig, sigma_rows=8 * 32 * 32, mask=nhwc(a, dtype), mask_act=ops.ACT_LRELU, mask_slope=0.1,
+                                       nt_variant=variant, nt_splitk=1))
         torch.cuda.synchronize()
         outs.append(dx)
-    _set_variant(lib, 4, 0)
     assert all(torch.equal(o, outs[-1]) for o in outs[:-1])
     want = F.conv_transpose2d(dy, rq(w, dtype), None, 2, 1) * torch.where(a > 0, 1.0, 0.1)
     want[:8] /= 1.3
     want[8:] /= 0.7
     rt, at = tol(dtype, Cout * 4)
     torch.testing.assert_close(nchw(outs[0]), want, rtol=rt, atol=at)
-    # 256 output channels: the 256x256 tile (two epilogue windows) vs the register-staged kernel
+    # 256 output channels: the 256x256 tile (ten-slot ring, two epilogue windows) and the 256x128 tile vs the register-staged kernel
     B, H, Cin, Cout = 64, 32, 64, 256
     x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
     w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.05
@@ -521,25 +514,29 @@ def test_igemm_dma_variant_matches_register_staged_kernel(dtype):
     wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
     ops.pack_fwd(c, dtype, w.to(DEV), wp)
     outs = []
-    for (mode, big), label in (((4, 32), 256134), ((4, -2), 256136), ((0, 0), 128128)):
-        _set_variant(lib, mode, big)
-        assert lib.query("eg_igemm_nt_tile", dtype, B * 16 * 16, Cout, Cin, 16 * Cin, 1) == (label if mode else 128064)
+    for variant, label in ((NT_P8_256, 256143), (NT_P8_128, 256141), (NT_BUF128, 128131), (NT_REG, 128128)):
+        assert lib.query("eg_igemm_nt_tile", dtype, B * 16 * 16, Cout, Cin, 16 * Cin, 1, variant, 1) == label
         y = torch.zeros(B, 16, 16, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
-        ops.conv_fwd(c, dtype, nhwc(x, dtype), wp, y, ops.epilogue(bias=b.to(DEV), act=ops.ACT_RELU))
+        ops.conv_fwd(c, dtype, nhwc(x, dtype), wp, y, ops.epilogue(bias=b.to(DEV), act=ops.ACT_RELU, nt_variant=variant, nt_splitk=1))
         torch.cuda.synchronize()
         outs.append(y)
-    _set_variant(lib, 4, 0)
-    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[2])
+    assert all(torch.equal(o, outs[-1]) for o in outs[:-1])
     rt, at = tol(dtype, Cin * 16)
     torch.testing.assert_close(nchw(outs[0]), F.relu(F.conv2d(x, rq(w, dtype), b, 2, 1)), rtol=rt, atol=at)
+    # a variant that cannot run the problem is an error, not a silent substitution (N = 128 is not a multiple of 256)
+    with pytest.raises(RuntimeError):
+        c = ops.make_conv(4, 8, 8, 64, 128, 3, 1, 1)
+        ops.conv_fwd(c, dtype, torch.zeros(4, 8, 8, 64, device=DEV, dtype=ops.torch_dtype(dtype)),
+                     torch.zeros(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype)),
+                     torch.zeros(4, 8, 8, 128, device=DEV, dtype=ops.torch_dtype(dtype)), ops.epilogue(nt_variant=NT_P8_256))
 
 
-@pytest.mark.parametrize("big,Cout", [(0, 128), (-1, 128), (-1, 256), (-2, 128), (-2, 256), (224, 128), (224, 256)])
+@pytest.mark.parametrize("variant,Cout", [(NT_BUF128, 128), (NT_PERS, 128), (NT_PERS, 256), (NT_P8_128, 128), (NT_P8_128, 256), (NT_P8_256, 256)])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_igemm_buf_variant_ragged_rows_and_k_padding(dtype, big, Cout):
-    """Buffer-descriptor LDS-DMA NT kernels (128x128, 256x128, 256x256) on a launch whose last row tile is almost empty
-    (M = 1025*64) and whose 3x3 filter walks 9 taps with image borders on every side: bit-exact vs the register-staged kernel."""
-    lib = eg._lib.lib()
+def test_igemm_dma_variants_ragged_rows_and_k_padding(dtype, variant, Cout):
+    """Buffer-descriptor LDS-DMA NT kernels (128x128, persistent, 256x128, 256x256) on a launch whose last row tile is almost empty
+    (M = 1025*64) and whose 3x3 filter walks 9 taps with image borders on every side (9 K tiles: odd, so the rings end mid-cycle):
+    bit-exact vs the register-staged kernel."""
     g = torch.Generator().manual_seed(22)
     B, H, Cin = 1025, 8, 64
     x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
@@ -549,73 +546,95 @@ def test_igemm_buf_variant_ragged_rows_and_k_padding(dtype, big, Cout):
     ops.pack_fwd(c, dtype, w.to(DEV), wp)
     xd = nhwc(x, dtype)
     outs = []
-    for mode in (4, 0):
-        _set_variant(lib, mode, big)
-        if mode:
-            assert lib.query("eg_igemm_nt_tile", dtype, B * 64, Cout, Cin, 9 * Cin, 1) == {(0, 128): 128131, (-1, 128): 128135, (-1, 256): 128135, (-2, 128): 256136, (-2, 256): 256136, (224, 128): 256133, (224, 256): 256134}[(big, Cout)]
+    for v in (variant, NT_REG):
         y = torch.zeros(B, H, H, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
-        ops.conv_fwd(c, dtype, xd, wp, y, ops.epilogue())
+        ops.conv_fwd(c, dtype, xd, wp, y, ops.epilogue(nt_variant=v, nt_splitk=1))
         torch.cuda.synchronize()
         outs.append(y)
-    _set_variant(lib, 4, 0)
     assert torch.equal(outs[0], outs[1])
     want = F.conv2d(x[:64], rq(w, dtype), None, 1, 1)
     rt, at = tol(dtype, Cin * 9)
     torch.testing.assert_close(nchw(outs[0][:64]), want, rtol=rt, atol=at)
 
 
+@pytest.mark.parametrize("variant,nk_taps", [(NT_P8_128, 1), (NT_P8_128, 2), (NT_P8_256, 1), (NT_P8_256, 2), (NT_P8_256, 3)])
+def test_igemm_nt8_short_k_loops(variant, nk_taps):
+    """K loops of one, two and three K tiles (1x1 conv over 64 / 128 / 192 channels in bf16): the rings' prologue / tail counts."""
+    dtype = 1
+    g = torch.Generator().manual_seed(26)
+    B, H, Cin, Cout = 16, 8, 64 * nk_taps, 256
+    x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.1
+    c = ops.make_conv(B, H, H, Cin, Cout, 1, 1, 0)
+    wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
+    ops.pack_fwd(c, dtype, w.to(DEV), wp)
+    outs = []
+    for v in (variant, NT_REG):
+        y = torch.zeros(B, H, H, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
+        ops.conv_fwd(c, dtype, nhwc(x, dtype), wp, y, ops.epilogue(nt_variant=v, nt_splitk=1))
+        torch.cuda.synchronize()
+        outs.append(y)
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_igemm_splitk_small_m_deep_k(dtype):
     """Few-row / deep-K launches (the last Discriminator conv: celebA/EAD-GAN_celebA.py:118) split K across workgroups into fp32
     partial tiles that a second launch sums in a fixed order before the fused epilogue: forward (bias + LeakyReLU) and 4-phase
-    backward-data (1/sigma per tape + activation-gradient mask) against torch, and repeatable bit for bit."""
+    backward-data (1/sigma per tape + activation-gradient mask) against torch, and repeatable bit for bit -- planner's choice (128-row
+    tiles at this M), and the 8-wave kernels forced with 4 splits."""
     lib = eg._lib.lib()
-    ops.set_splitk_workspace(torch.empty(16 << 20, device=DEV, dtype=torch.float32))
+    ws = torch.empty(16 << 20, device=DEV, dtype=torch.float32)
     g = torch.Generator().manual_seed(23)
     B, H, Cin, Cout = 24, 8, 256, 256
     c = ops.make_conv(B, H, H, Cin, Cout, 4, 2, 1)
     assert ops.conv_splitk_ws_bytes(c, dtype, 0) > 0 and ops.conv_splitk_ws_bytes(c, dtype, 1) > 0
-    assert lib.query("eg_igemm_nt_tile", dtype, B * 16, Cout, Cin, 16 * Cin, 1) == 128132
+    assert lib.query("eg_igemm_nt_tile", dtype, B * 16, Cout, Cin, 16 * Cin, 1, 0, 0) == 128132
+    assert lib.query("eg_igemm_nt_tile", dtype, B * 16, Cout, Cin, 16 * Cin, 1, NT_P8_128, 4) == 256142
+    assert lib.query("eg_igemm_nt_tile", dtype, B * 16, Cout, Cin, 16 * Cin, 1, NT_P8_256, 4) == 256144
     x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
     w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.03
     b = torch.randn(Cout, generator=g)
     wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
     ops.pack_fwd(c, dtype, w.to(DEV), wp)
-    ys = []
-    for _ in range(2):
-        y = torch.zeros(B, 4, 4, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
-        ops.conv_fwd(c, dtype, nhwc(x, dtype), wp, y, ops.epilogue(bias=b.to(DEV), act=ops.ACT_LRELU, slope=0.2))
-        torch.cuda.synchronize()
-        ys.append(y)
-    assert torch.equal(ys[0], ys[1])
-    want = F.leaky_relu(F.conv2d(x, rq(w, dtype), b, 2, 1), 0.2)
-    rt, at = tol(dtype, Cin * 16)
-    torch.testing.assert_close(nchw(ys[0]), want, rtol=rt, atol=at)
-    # backward-data of the same layer, two tapes of 12 images
     dy = rq(torch.randn(B, Cout, 4, 4, generator=g), dtype)
     a = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
     wpb = torch.empty(ops.pack_bwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
     ops.pack_bwd(c, dtype, w.to(DEV), wpb)
     sig = torch.tensor([1.3, 0.7], device=DEV)
-    dx = torch.zeros(B, H, H, Cin, device=DEV, dtype=ops.torch_dtype(dtype))
-    ops.conv_bwd_data(c, dtype, nhwc(dy, dtype), wpb, dx,
-                      ops.epilogue(sigma=sig, sigma_rows=12 * 16, mask=nhwc(a, dtype), mask_act=ops.ACT_LRELU, mask_slope=0.1))
-    torch.cuda.synchronize()
-    want = F.conv_transpose2d(dy, rq(w, dtype), None, 2, 1) * torch.where(a > 0, 1.0, 0.1)
-    want[:12] /= 1.3
-    want[12:] /= 0.7
-    rt, at = tol(dtype, Cout * 4)
-    torch.testing.assert_close(nchw(dx), want, rtol=rt, atol=at)
-    ops.SPLITK_WS.clear()
+    for variant, splitk in ((0, 0), (NT_P8_128, 4), (NT_P8_256, 4)):
+        ys = []
+        for _ in range(2):
+            y = torch.zeros(B, 4, 4, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
+            ops.conv_fwd(c, dtype, nhwc(x, dtype), wp, y,
+                         ops.epilogue(bias=b.to(DEV), act=ops.ACT_LRELU, slope=0.2, nt_variant=variant, nt_splitk=splitk, splitk_ws=ws))
+            torch.cuda.synchronize()
+            ys.append(y)
+        assert torch.equal(ys[0], ys[1])
+        want = F.leaky_relu(F.conv2d(x, rq(w, dtype), b, 2, 1), 0.2)
+        rt, at = tol(dtype, Cin * 16)
+        torch.testing.assert_close(nchw(ys[0]), want, rtol=rt, atol=at)
+        # backward-data of the same layer, two tapes of 12 images
+        dx = torch.zeros(B, H, H, Cin, device=DEV, dtype=ops.torch_dtype(dtype))
+        ops.conv_bwd_data(c, dtype, nhwc(dy, dtype), wpb, dx,
+                          ops.epilogue(sigma=sig, sigma_rows=12 * 16, mask=nhwc(a, dtype), mask_act=ops.ACT_LRELU, mask_slope=0.1,
+                                       nt_variant=variant, nt_splitk=splitk, splitk_ws=ws))
+        torch.cuda.synchronize()
+        want = F.conv_transpose2d(dy, rq(w, dtype), None, 2, 1) * torch.where(a > 0, 1.0, 0.1)
+        want[:12] /= 1.3
+        want[12:] /= 0.7
+        rt, at = tol(dtype, Cout * 4)
+        torch.testing.assert_close(nchw(dx), want, rtol=rt, atol=at)
 
 
+@pytest.mark.parametrize("variant", [0, NT_BUF128, NT_P8_128, NT_P8_256])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_igemm_splitk_range_starting_inside_a_tap(dtype):
+def test_igemm_splitk_range_starting_inside_a_tap(dtype, variant):
     """3x3 conv whose K split boundaries fall inside filter taps (9 taps x 256 channels, 4 splits of 9 (bf16) / 18 (fp32) K steps
     against 4 / 8 steps per tap): the per-split start state (tap, channel offset) must be reconstructed exactly."""
-    ops.set_splitk_workspace(torch.empty(16 << 20, device=DEV, dtype=torch.float32))
+    ws = torch.empty(16 << 20, device=DEV, dtype=torch.float32)
     g = torch.Generator().manual_seed(24)
-    B, H, Cin, Cout = 8, 8, 256, 128
+    B, H, Cin, Cout = 8, 8, 256, 256
     c = ops.make_conv(B, H, H, Cin, Cout, 3, 1, 1)
     assert ops.conv_splitk_ws_bytes(c, dtype, 0) > 0
     x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
@@ -623,9 +642,8 @@ def test_igemm_splitk_range_starting_inside_a_tap(dtype):
     wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
     ops.pack_fwd(c, dtype, w.to(DEV), wp)
     y = torch.zeros(B, H, H, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
-    ops.conv_fwd(c, dtype, nhwc(x, dtype), wp, y, ops.epilogue())
+    ops.conv_fwd(c, dtype, nhwc(x, dtype), wp, y, ops.epilogue(nt_variant=variant, nt_splitk=4 if variant else 0, splitk_ws=ws))
     torch.cuda.synchronize()
-    ops.SPLITK_WS.clear()
     rt, at = tol(dtype, Cin * 9)
     torch.testing.assert_close(nchw(y), F.conv2d(x, rq(w, dtype), None, 1, 1), rtol=rt, atol=at)
 
@@ -633,7 +651,7 @@ def test_igemm_splitk_range_starting_inside_a_tap(dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_igemm_shallow_single_tap_runs_on_persistent_pipeline(dtype):
     """The image-side layers run as 1x1 convolutions over 48-channel patch rows (K = 48: one K step in bf16, two in fp32, the row
-    is not a whole number of K tiles).  Such launches go to the persistent pipeline whatever the tuning says; bit-exact vs the
+    is not a whole number of K tiles).  Such launches go to the persistent pipeline by the planner's own choice; bit-exact vs the
     register-staged kernel, several tiles per workgroup, ragged last tile."""
     lib = eg._lib.lib()
     g = torch.Generator().manual_seed(25)
@@ -646,15 +664,12 @@ def test_igemm_shallow_single_tap_runs_on_persistent_pipeline(dtype):
     wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
     ops.pack_fwd(c, dtype, w.to(DEV), wp)
     outs = []
-    for mode in (4, 0):
-        _set_variant(lib, mode, 0)
-        if mode:
-            assert lib.query("eg_igemm_nt_tile", dtype, B * H * H, Cout, Cin, Cin, 1) == 128135
+    assert lib.query("eg_igemm_nt_tile", dtype, B * H * H, Cout, Cin, Cin, 1, 0, 0) == 128135
+    for v in (0, NT_REG):
         y = torch.zeros(B, H, H, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
-        ops.conv_fwd(c, dtype, nhwc(x, dtype), wp, y, ops.epilogue(bias=b.to(DEV), sigma=sig, act=ops.ACT_LRELU, slope=0.1))
+        ops.conv_fwd(c, dtype, nhwc(x, dtype), wp, y, ops.epilogue(bias=b.to(DEV), sigma=sig, act=ops.ACT_LRELU, slope=0.1, nt_variant=v))
         torch.cuda.synchronize()
         outs.append(y)
-    _set_variant(lib, 4, 0)
     assert torch.equal(outs[0], outs[1])
     rt, at = tol(dtype, Cin)
     torch.testing.assert_close(nchw(outs[0][:16]), F.leaky_relu(F.conv2d(x[:16], rq(w, dtype) / 0.9, b), 0.1), rtol=rt, atol=at)
