@@ -773,8 +773,11 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(const NtParams 
 //   EG_NT_BUF128  128 x 128, 4 waves, 2-stage buffer-descriptor LDS-DMA ring (+ split-K): launches too small for 256-row tiles
 //   EG_NT_PERS    persistent 128 x 128 pipeline: the 1-2-step image-side layers
 //   EG_NT_P8_128 / EG_NT_P8_256   igemm_nt8.hip: 256 x 128 / 256 x 256 tiles, 8 waves, deep ring, half-phase stagger (+ split-K)
+//   EG_NT_P8P     igemm_nt8.hip: 256 x 128, A held in LDS as an input patch shared by the taps of a class (+ split-K)
 // ------------------------------------------------------------------------------------------------
 template <typename T> void eg_launch_nt8(const NtParams& p, int nphase, int bn, int ns, hipStream_t st);
+template <typename T> void eg_launch_nt8p(const NtParams& p, const Nt8pGeom& g, int nphase, int ns, hipStream_t st);
+bool eg_nt8p_geometry(const NtParams& p, int nphase, Nt8pGeom& g);
 
 struct NtPlan { int kind, ns; };
 
@@ -829,6 +832,11 @@ static NtPlan nt_plan(const NtParams& p, int nphase, int vec, size_t esize, size
         case EG_NT_P8_256:
             if (!f.dma_ok || !f.c_tiles || (variant == EG_NT_P8_256 && (p.N % 256) != 0)) return bad;
             return {variant, nt_splits((long long)cdiv(p.M, 256) * (p.N / (variant == EG_NT_P8_256 ? 256 : 128)) * nphase, 224, f.nk_min, part256, ws_bytes, splitk)};
+        case EG_NT_P8P: {
+            Nt8pGeom g;
+            if (!f.dma_ok || !f.c_tiles || !eg_nt8p_geometry(p, nphase, g)) return bad;
+            return {EG_NT_P8P, nt_splits((long long)cdiv(p.M, 256) * (p.N / 128) * nphase, 224, f.nk_min, part256, ws_bytes, splitk)};
+        }
         case EG_NT_AUTO: return nt_plan_auto(p, nphase, f, ws_bytes, splitk);
         default: return {-1, 1};
     }
@@ -844,7 +852,8 @@ static NtPlan nt_plan_auto(const NtParams& p, int nphase, const NtFacts& f, size
     const long long wgs256 = (long long)cdiv(p.M, 256) * (p.N / 128) * nphase;
     if (p.M >= 1024 && wgs256 * (splitk > 0 ? splitk : 16) >= 96 && f.nk_min >= 4) {
         const int ns = nt_splits(wgs256, 224, f.nk_min, part256, ws_bytes, splitk);
-        if (wgs256 * ns >= 96) return {EG_NT_P8_128, ns};
+        Nt8pGeom g;
+        if (wgs256 * ns >= 96) return {eg_nt8p_geometry(p, nphase, g) ? EG_NT_P8P : EG_NT_P8_128, ns};
     }
     if (f.tiles128 < 512 && ws_bytes > 0) {
         const int ns = nt_splits(f.tiles128, 512, f.nk_min, part128, ws_bytes, splitk);
@@ -876,11 +885,16 @@ static int launch_nt(const NtParams& p, int nphase, int variant, int splitk, hip
     const NtPlan plan = nt_plan(p, nphase, Elt<T>::VEC, sizeof(T), p.part ? p.part_bytes : 0, variant, splitk);
     EG_REQUIRE(plan.kind > 0, "eg_epilogue.nt_variant %d cannot run this problem (M=%d N=%d C=%d)", variant, p.M, p.N, p.C);
     static const int xcd = [] { const char* e = getenv("EG_XCD_REMAP"); return e ? atoi(e) : 1; }();   // default on
-    if (plan.kind == EG_NT_P8_128 || plan.kind == EG_NT_P8_256) {
+    if (plan.kind == EG_NT_P8_128 || plan.kind == EG_NT_P8_256 || plan.kind == EG_NT_P8P) {
         NtParams q = p;
         q.nsplit = plan.ns;
         q.xcd_remap = xcd;
-        eg_launch_nt8<T>(q, nphase, plan.kind == EG_NT_P8_256 ? 256 : 128, plan.ns, st);
+        if (plan.kind == EG_NT_P8P) {
+            Nt8pGeom g;
+            EG_REQUIRE(eg_nt8p_geometry(p, nphase, g), "patch geometry");
+            eg_launch_nt8p<T>(q, g, nphase, plan.ns, st);
+        } else
+            eg_launch_nt8<T>(q, nphase, plan.kind == EG_NT_P8_256 ? 256 : 128, plan.ns, st);
         if (plan.ns > 1) launch_splitk_epilogue<T>(q, nphase, cdiv(p.M, 256) * 256, st);
         return 0;
     }
@@ -950,26 +964,31 @@ static int launch_nt(const NtParams& p, int nphase, int variant, int splitk, hip
     return 0;
 }
 
-/* which igemm_nt instantiation a problem is dispatched to (profiling labels and tests; same planner as the launches): BM * 1000 + code,
- * code = BN of the register-staged kernels, or 131 / 132 buffer-descriptor 128 x 128 (plain / split-K), 135 persistent pipeline,
- * 141 / 142 igemm_nt8<128> (plain / split-K), 143 / 144 igemm_nt8<256>; -1 if the forced variant cannot run the problem. */
-extern "C" int eg_igemm_nt_tile(int dtype, int M, int N, int C, int K, int nphase, int variant, int splitk) {
-    const int vec = vec_of(dtype), bk = bk_of(dtype);
-    NtParams p{};
-    p.out_mode = EG_OUT_NHWC; p.M = M; p.N = N; p.C = C; p.B = 1; p.H = 1; p.W = 1;
-    for (int i = 0; i < nphase && i < 4; ++i) { p.ph[i].Kpad = round_up(K, bk); p.ph[i].TH = 1; p.ph[i].TW = std::max(1, K / std::max(C, 1)); }
-    const NtPlan plan = nt_plan(p, nphase, vec, dtype == EG_F32 ? 4 : 2, (size_t)1 << 40, variant, splitk);
+/* which igemm_nt instantiation eg_conv_fwd (bwd = 0) / eg_conv_bwd_data (bwd = 1) dispatches this problem to under the given hints
+ * (profiling labels and tests; the same planner as the launches, with unlimited split-K scratch): BM * 1000 + code, code = BN of the
+ * register-staged kernels, 131 / 132 = 128 x 128 buffer-descriptor kernel (plain / split-K), 135 = persistent pipeline, 141 / 142 =
+ * igemm_nt8<128>, 143 / 144 = igemm_nt8<256>, 145 / 146 = igemm_nt8p (input patch); -1 = the forced variant cannot run the problem. */
+extern "C" int eg_igemm_nt_tile(const eg_conv* c, int dtype, int bwd, int variant, int splitk) {
+    if (!c || check_conv(c, dtype, bwd ? NEED_COUT : NEED_CIN)) return -1;
+    NtParams p;
+    memset(&p, 0, sizeof(p));
+    int nphase = 1;
+    if (bwd) { if (geom_bwd(c, dtype, p, &nphase)) return -1; }
+    else geom_fwd(c, dtype, p);
+    p.out_mode = EG_OUT_NHWC;
+    const NtPlan plan = nt_plan(p, nphase, vec_of(dtype), dtype == EG_F32 ? 4 : 2, (size_t)1 << 40, variant, splitk);
     if (plan.kind < 0) return -1;
+    if (plan.kind == EG_NT_P8P) return 256 * 1000 + (plan.ns > 1 ? 146 : 145);
     if (plan.kind == EG_NT_P8_128) return 256 * 1000 + (plan.ns > 1 ? 142 : 141);
     if (plan.kind == EG_NT_P8_256) return 256 * 1000 + (plan.ns > 1 ? 144 : 143);
     if (plan.kind == EG_NT_PERS) return 128 * 1000 + 135;
     if (plan.kind == EG_NT_BUF128) return 128 * 1000 + (plan.ns > 1 ? 132 : 131);
+    const int M = p.M, N = p.N;
     if (N <= 16) return 128 * 1000 + 16;
     if (N <= 32) return 128 * 1000 + 32;
     if (N <= 64 || (variant != EG_NT_REG && (long long)cdiv(M, 128) * cdiv(N, 128) * nphase < 512)) return 128 * 1000 + 64;
     return 128 * 1000 + 128;
 }
-
 
 static void fill_epilogue(NtParams& p, const eg_epilogue* ep) {
     p.bias = ep ? ep->bias : nullptr;
@@ -1036,7 +1055,7 @@ extern "C" size_t eg_conv_splitk_ws_bytes(const eg_conv* c, int dtype, int bwd) 
     // what the planner would split into with unlimited scratch (callers size one shared scratch from the maximum over their layers)
     const NtPlan plan = nt_plan(p, nphase, vec_of(dtype), dtype == EG_F32 ? 4 : 2, (size_t)1 << 40, EG_NT_AUTO, 0);
     if (plan.ns <= 1) return 0;
-    const int bm = (plan.kind == EG_NT_P8_128 || plan.kind == EG_NT_P8_256) ? 256 : 128;
+    const int bm = (plan.kind == EG_NT_P8_128 || plan.kind == EG_NT_P8_256 || plan.kind == EG_NT_P8P) ? 256 : 128;
     return (size_t)plan.ns * nphase * cdiv(p.M, bm) * bm * p.N * 4;
 }
 

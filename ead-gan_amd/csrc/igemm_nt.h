@@ -43,6 +43,17 @@ struct NtParams {
     NtPhase ph[4];
 };
 
+// patch geometry of igemm_nt8p_kernel (igemm_nt8.hip): filter taps grouped into classes that walk one pixel lattice
+struct NtClass { int oy0, ox0, AH, AW, ty0, tys, tx0, txs; };       // source = stride * lattice + o0; tap(ay, ax) = (ty0 + ay*tys, tx0 + ax*txs)
+struct Nt8pPhase { int ncls; NtClass cls[4]; };
+struct Nt8pGeom {
+    int nimg, OHt;                  // images per 256-row tile; output rows of one image per tile
+    int PH, PW, npix, npp;          // patch lattice per image, pixels per patch, DMA pieces per wave
+    unsigned inv_pw, inv_plane;     // x / PW == (x * inv_pw) >> 20, x / (PH*PW) == (x * inv_plane) >> 20  for x < 512
+    Nt8pPhase ph[4];
+};
+#define EG_P8P_SLOTS 448
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline int bk_of(int dtype) { return dtype == EG_F32 ? 32 : 64; }
 static inline int vec_of(int dtype) { return dtype == EG_F32 ? 4 : 8; }
@@ -260,6 +271,21 @@ __device__ __forceinline__ u32x4_t eg_make_srd(const void* base, unsigned bytes)
 }
 
 #define EG_OOB 0x80000000u
+
+// one 1-KiB LDS-DMA piece (64 lanes x 16 B from per-lane offsets into `srd`, + the SGPR offset) to LDS [lds, lds + 1 KiB).  Issued
+// through inline asm so that hipcc does not count it: the caller owns the waits (counted s_waitcnt vmcnt + s_barrier before any wave
+// reads the bytes).  M0 is saved and restored inside the statement.
+__device__ __forceinline__ void eg_bufdma1s(const u32x4_t srd, unsigned v0, unsigned soff, unsigned lds) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(v0), "s"(srd), "s"(soff), "s"(lds)
+        : "memory");
+}
 
 template <int STRIDE>
 __device__ __forceinline__ void eg_bufdma4s(const u32x4_t srd, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned soff, unsigned lds) {

@@ -11,7 +11,7 @@ import os
 import torch
 
 from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, EG_BF16, EG_F16, EG_F32, NT_AUTO, NT_BUF128,
-                   NT_P8_128, NT_P8_256, NT_PERS, NT_REG, OUT_NCHW_F32, OUT_NHWC, EgConv, EgEpilogue, EgSnLayer, lib)
+                   NT_P8_128, NT_P8_256, NT_P8P, NT_PERS, NT_REG, OUT_NCHW_F32, OUT_NHWC, EgConv, EgEpilogue, EgSnLayer, lib)
 
 __all__ = ["EG_F32", "EG_BF16", "EG_F16", "ACT_NONE", "ACT_LRELU", "ACT_RELU", "ACT_TANH", "ACT_SIGMOID", "OUT_NHWC",
            "OUT_NCHW_F32"]
@@ -120,15 +120,14 @@ def _timed(kind, c, dtype, args, ep=None):
     if kind == "tn":
         label = f"igemm_tn_kernel<{tname}>"
     else:
-        N, C, K, nph = (c.Cout, c.Cin, c.k * c.k * c.Cin, 1) if kind == "fwd" else \
-            (c.Cin, c.Cout, (c.k // c.stride) ** 2 * c.Cout, c.stride * c.stride)
-        tile = lib().query("eg_igemm_nt_tile", dtype, M, N, C, K, nph, ep.nt_variant if ep is not None else 0,
+        tile = lib().query("eg_igemm_nt_tile", ctypes.byref(c), dtype, int(kind == "bwd"), ep.nt_variant if ep is not None else 0,
                            (ep.nt_splitk if ep.splitk_ws else 1) if ep is not None else 1)
         bm, bn = tile // 1000, tile % 1000
         label = {131: f"igemm_nt_buf_kernel<{tname}>", 132: f"igemm_nt_buf_kernel<{tname}>+splitk",
                  135: f"igemm_nt_pers_kernel<{tname}>",
                  141: f"igemm_nt8_kernel<{tname},128>", 142: f"igemm_nt8_kernel<{tname},128>+splitk",
-                 143: f"igemm_nt8_kernel<{tname},256>", 144: f"igemm_nt8_kernel<{tname},256>+splitk"}.get(bn, f"igemm_nt_kernel<{tname},{bm},{bn}>")
+                 143: f"igemm_nt8_kernel<{tname},256>", 144: f"igemm_nt8_kernel<{tname},256>+splitk",
+                 145: f"igemm_nt8p_kernel<{tname}>", 146: f"igemm_nt8p_kernel<{tname}>+splitk"}.get(bn, f"igemm_nt_kernel<{tname},{bm},{bn}>")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     lib().call(*args, _stream())

@@ -73,6 +73,9 @@ typedef struct eg_epilogue {
 #define EG_NT_PERS 3     /* persistent 128 x 128 pipeline (1-2-step image-side layers) */
 #define EG_NT_P8_128 4   /* 256 x 128, 8 waves, 3-K-tile ring, half-phase stagger (igemm_nt8.hip) */
 #define EG_NT_P8_256 5   /* 256 x 256, 8 waves, ten-slot ring */
+#define EG_NT_P8P 6      /* 256 x 128, 8 waves, A operand held in LDS as an input patch shared by the filter taps of a class: 2.6-3.5x
+                          * fewer A bytes through the LDS-DMA path; K is accumulated class by class (deterministic, not bit-identical
+                          * to the tap-major variants) */
 
 /* --- implicit-GEMM convolution family (MFMA) ---------------------------------------------------
  * replaces torch.nn.functional.conv2d / conv_transpose2d / linear and their autograd backward:
@@ -90,11 +93,11 @@ int eg_conv_fwd(const eg_conv* c, int dtype, const void* X, const void* wp_fwd, 
 /* dX = conv^T(dY, W)  (== ConvTranspose2d forward); dX has spatial dims (H<<up, W<<up) */
 int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, const void* wp_bwd, void* dX,
                      const eg_epilogue* ep, eg_stream_t s);
-/* which kernel a problem (M rows, N columns, C gathered channels per tap, K per phase) is dispatched to under the given hints:
- * BM * 1000 + code; code = BN of the register-staged kernels, 131 / 132 = 128 x 128 buffer-descriptor kernel (plain / split-K),
- * 135 = persistent pipeline, 141 / 142 = igemm_nt8<128> (plain / split-K), 143 / 144 = igemm_nt8<256>; -1 = the forced variant
- * cannot run the problem.  Profiling labels and tests. */
-int eg_igemm_nt_tile(int dtype, int M, int N, int C, int K, int nphase, int variant, int splitk);
+/* which kernel eg_conv_fwd (bwd = 0) / eg_conv_bwd_data (bwd = 1) runs this problem on under the given hints (same planner as the
+ * launches, unlimited split-K scratch): BM * 1000 + code; code = BN of the register-staged kernels, 131 / 132 = 128 x 128
+ * buffer-descriptor kernel (plain / split-K), 135 = persistent pipeline, 141 / 142 = igemm_nt8<128>, 143 / 144 = igemm_nt8<256>,
+ * 145 / 146 = igemm_nt8p (input patch); -1 = the forced variant cannot run the problem.  Profiling labels and tests. */
+int eg_igemm_nt_tile(const eg_conv* c, int dtype, int bwd, int variant, int splitk);
 /* bytes of eg_epilogue.splitk_ws that let eg_conv_fwd (bwd = 0) / eg_conv_bwd_data (bwd = 1) split as far as the policy wants */
 size_t eg_conv_splitk_ws_bytes(const eg_conv* c, int dtype, int bwd);
 /* dW partial slabs: slab[split][Cout][k*k][Cin] fp32.  Returns the split count through *nsplit. */

@@ -9,9 +9,10 @@ random, each timing is HIP events around `inner` back-to-back launches.  Prints 
 unsplit variants bit for bit against the register-staged kernel.
 
 usage: python profiles/scripts/nt_layers.py [--shapes ABCDEF] [--T 1,2,3] [--configs v:s,v:s,...] [--rounds 5] [--dtype 1]
-       config v:s = nt_variant : nt_splitk   (0:0 = planner; 2 = 128x128 4 waves; 4 = 256x128 8 waves; 5 = 256x256 8 waves)
+       config v:s = nt_variant : nt_splitk   (0:0 = planner; 2 = 128x128 4 waves; 4 = 256x128 8 waves; 5 = 256x256 8 waves; 6 = 256x128 input patch)
 """
 import argparse
+import ctypes
 import importlib
 import os
 import statistics
@@ -33,7 +34,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--shapes", default="ABCDEF")
     ap.add_argument("--T", default="1,2,3")
-    ap.add_argument("--configs", default="2:0,4:0,4:1,5:0,5:1,0:0")
+    ap.add_argument("--configs", default="2:1,4:1,6:1,2:0,6:0")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--inner", type=int, default=10)
     ap.add_argument("--dtype", type=int, default=1)
@@ -79,26 +80,29 @@ def main():
                     ops.conv_bwd_data(c, dt, x, wp, out, ops.epilogue(sigma=sig, sigma_rows=rows, mask=mask, mask_act=ops.ACT_LRELU,
                                                                       mask_slope=0.1, nt_variant=v, nt_splitk=s, splitk_ws=ws))
             flops = 2.0 * M * N * K * nph
-            labels = [lib.query("eg_igemm_nt_tile", dt, M, N, C, K, nph, v, s) for v, s in cfgs]
+            labels = [lib.query("eg_igemm_nt_tile", ctypes.byref(c), dt, int(kind == "bwd"), v, s) for v, s in cfgs]
             if a.check:
                 ref = torch.empty_like(y)
                 run(1, 1, ref)
                 for (v, s), lab in zip(cfgs, labels):
+                    if lab < 0:
+                        continue
                     out = torch.full_like(y, 7.0)
                     run(v, s, out)
                     torch.cuda.synchronize()
-                    split = lab % 1000 in (132, 142, 144)
+                    split = lab % 1000 in (132, 142, 144, 145, 146)       # 145: other K order
                     if split:
                         err = (out.float() - ref.float()).abs().max().item()
                         assert err < 0.05 * ref.float().abs().max().item() + 1e-3, (name, T, v, s, err)
                     else:
                         assert torch.equal(out, ref), (name, T, v, s, (out.float() - ref.float()).abs().max().item())
             times = {cfg: [] for cfg in cfgs}
-            for cfg in cfgs:                                   # warm-up
+            cfgs_ok = [cfg for cfg, lab in zip(cfgs, labels) if lab >= 0]
+            for cfg in cfgs_ok:                                # warm-up
                 run(*cfg)
             torch.cuda.synchronize()
             for _ in range(a.rounds):
-                for cfg in cfgs:
+                for cfg in cfgs_ok:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     for _ in range(a.inner):
@@ -108,6 +112,9 @@ def main():
                     times[cfg].append(e0.elapsed_time(e1) * 1e-3 / a.inner)
             cells = []
             for cfg, lab in zip(cfgs, labels):
+                if lab < 0:
+                    cells.append("n/a")
+                    continue
                 med, best = statistics.median(times[cfg]), min(times[cfg])
                 cells.append(f"{lab % 1000:3d} {flops / med / 1e12:6.0f}/{flops / best / 1e12:4.0f} {med * 1e6:6.1f}us")
             print(f"{name} T={T:<3d} " + " ".join(f"{c_:>22s}" for c_ in cells), flush=True)
