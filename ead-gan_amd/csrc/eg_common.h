@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
 
 #include "../../include/eadgan_hip.h"
 
@@ -81,6 +82,31 @@ __device__ __forceinline__ float eg_act_grad_from_out(float a, int act, float sl
         case EG_ACT_SIGMOID: return a * (1.f - a);
         default: return 1.f;
     }
+}
+
+// The same two functions for code that applies them to many elements of one launch: `act` is uniform, so the switch above costs a
+// chain of scalar branches PER ELEMENT (the 256 x 128 epilogue spent 12-25k cycles in them).  NONE / LRELU / RELU become two selects
+// on loop-invariant operands with bit-identical results (x * 1 == x; RELU keeps its +0); tanh / sigmoid keep the switch -- callers
+// test `special` once, outside their loops.
+struct EgActFast { float neg; bool relu, special; };
+__device__ __forceinline__ EgActFast eg_act_fast(int act, float slope) {
+    return {act == EG_ACT_LRELU ? slope : 1.f, act == EG_ACT_RELU, act >= EG_ACT_TANH};
+}
+__device__ __forceinline__ float eg_act_apply(float v, const EgActFast& a) {
+    float alt = v * a.neg;
+    alt = a.relu ? 0.f : alt;
+    return v > 0.f ? v : alt;
+}
+struct EgGradFast { float neg; bool special; };
+__device__ __forceinline__ EgGradFast eg_grad_fast(int act, float slope) {
+    return {act == EG_ACT_LRELU ? slope : (act == EG_ACT_RELU ? 0.f : 1.f), act >= EG_ACT_TANH};
+}
+__device__ __forceinline__ float eg_grad_apply(float a, const EgGradFast& g) { return a > 0.f ? 1.f : g.neg; }
+// f(std::true_type) on the fast path, f(std::false_type) when the launch uses tanh / sigmoid
+template <typename F>
+__device__ __forceinline__ void eg_if_fast(bool special, F&& f) {
+    if (special) f(std::false_type{});
+    else f(std::true_type{});
 }
 
 // wave (64 lanes) and block reductions

@@ -207,70 +207,14 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
     // ---- epilogue ----
     // acc[i][j][r] = C[m = m0 + (wm*TM+i)*16 + frow][n = n0 + (wn*TN+j)*16 + fq*4 + r]
     if (p.out_mode == EG_OUT_NHWC && (p.N % VEC) == 0) {
-        // stage the fp32 tile through LDS (16-byte chunks XOR-swizzled by row), then store whole 16-byte vectors:
-        // every wave-store covers full 128..256-byte row segments instead of 2-byte scatters.
-        constexpr int CH = BN / 4;                       // fp32 16-byte chunks per tile row
-        constexpr int SW = CH < 32 ? CH - 1 : 31;
-        float* ct = reinterpret_cast<float*>(smem);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = (wm * TM + i) * 16 + frow;
-            const int mrow = min(m0 + row, p.M - 1);
-            const float inv_sigma = p.sigma ? 1.f / p.sigma[p.sigma_rows ? mrow / p.sigma_rows : 0] : 1.f;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nl = (wn * TN + j) * 16 + fq * 4;
-                float4 v;
-                float* ve = reinterpret_cast<float*>(&v);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = __fmul_rn(acc[i][j][r], inv_sigma);
-                    const int n = n0 + nl + r;
-                    if (p.bias && n < p.N) x = __fadd_rn(x, p.bias[p.bias_mod ? n % p.bias_mod : n]);
-                    ve[r] = eg_act(x, p.act, p.slope);
-                }
-                *reinterpret_cast<float4*>(ct + row * BN + (((nl >> 2) ^ (row & SW)) << 2)) = v;
-            }
-        }
-        __syncthreads();
-        constexpr int VPR = BN / VEC;                    // output vectors per tile row
-        constexpr int RPP = 256 / VPR;                   // rows per pass
-        const int vc = tid % VPR, vr = tid / VPR;
-        const T* __restrict__ mask = reinterpret_cast<const T*>(p.mask);
-        const int n = n0 + vc * VEC;
-        if (n < p.N) {
-#pragma unroll 4
-            for (int row = vr; row < BM; row += RPP) {
-                const int m = m0 + row;
-                if (m >= p.M) break;
-                const int b = m >> (p.lOW + p.lOH);
-                const int y = ((m >> p.lOW) & OHm) * p.osy + ph.ooy;
-                const int x = (m & OWm) * p.osx + ph.oox;
-                const size_t o = (((size_t)b * p.DH + y) * p.DW + x) * p.N + n;
-                float f[VEC];
-#pragma unroll
-                for (int q = 0; q < VEC / 4; ++q) {
-                    const int chunk = (vc * (VEC / 4) + q) ^ (row & SW);
-                    const float4 v = *reinterpret_cast<const float4*>(ct + row * BN + (chunk << 2));
-                    f[q * 4 + 0] = v.x; f[q * 4 + 1] = v.y; f[q * 4 + 2] = v.z; f[q * 4 + 3] = v.w;
-                }
-                if (mask) {
-                    const uint4 mv = *reinterpret_cast<const uint4*>(mask + o);
-                    const T* me = reinterpret_cast<const T*>(&mv);
-#pragma unroll
-                    for (int q = 0; q < VEC; ++q) f[q] *= eg_act_grad_from_out(Elt<T>::ld(me + q), p.mask_act, p.mask_slope);
-                }
-                uint4 ov;
-                T* oe = reinterpret_cast<T*>(&ov);
-#pragma unroll
-                for (int q = 0; q < VEC; ++q) Elt<T>::st(oe + q, f[q]);
-                *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.dst) + o) = ov;
-            }
-        }
+        // the shared epilogue: fp32 tile through LDS (16-byte chunks XOR-swizzled by row), then whole 16-byte vector stores
+        nt_epilogue_lds<T, BM, BN, TM, TN, 256>(p, ph, acc, smem, m0, n0, wm * TM * 16, wn * TN * 16, tid, frow, fq);
         return;
     }
     // scalar path: NCHW fp32 image outputs (N = 1..4) and channel counts that are not a multiple of the vector width
     const T* __restrict__ mask = reinterpret_cast<const T*>(p.mask);
+    const EgActFast af = eg_act_fast(p.act, p.slope);
+    const EgGradFast gf = eg_grad_fast(p.mask_act, p.mask_slope);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + (wm * TM + i) * 16 + frow;
@@ -288,14 +232,17 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
                 if (n >= p.N) continue;
                 float v = __fmul_rn(acc[i][j][r], inv_sigma);
                 if (p.bias) v = __fadd_rn(v, p.bias[p.bias_mod ? n % p.bias_mod : n]);
-                v = eg_act(v, p.act, p.slope);
+                v = af.special ? eg_act(v, p.act, p.slope) : eg_act_apply(v, af);
                 if (p.out_mode == EG_OUT_NHWC) {
                     const size_t o = pix * p.N + n;
-                    if (mask) v *= eg_act_grad_from_out(Elt<T>::ld(mask + o), p.mask_act, p.mask_slope);
+                    if (mask) v *= gf.special ? eg_act_grad_from_out(Elt<T>::ld(mask + o), p.mask_act, p.mask_slope) : eg_grad_apply(Elt<T>::ld(mask + o), gf);
                     Elt<T>::st(reinterpret_cast<T*>(p.dst) + o, v);
                 } else {
                     const size_t o = (((size_t)b * p.N + n) * p.DH + y) * p.DW + x;
-                    if (p.mask) v *= eg_act_grad_from_out(reinterpret_cast<const float*>(p.mask)[o], p.mask_act, p.mask_slope);
+                    if (p.mask) {
+                        const float a = reinterpret_cast<const float*>(p.mask)[o];
+                        v *= gf.special ? eg_act_grad_from_out(a, p.mask_act, p.mask_slope) : eg_grad_apply(a, gf);
+                    }
                     reinterpret_cast<float*>(p.dst)[o] = v;
                 }
             }
@@ -680,6 +627,8 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_pers_kernel(const NtParams p,
         ++g;
         if (!last) { ++ckt; continue; }
         // ---- epilogue straight from the accumulators: acc[i][j][r] = C[c_m0 + (wm*TM+i)*16 + frow][c_n0 + (wn*TN+j)*16 + fq*4 + r]
+        const EgActFast eaf = eg_act_fast(p.act, p.slope);
+        const EgGradFast egf = eg_grad_fast(p.mask_act, p.mask_slope);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const float inv_sigma = p.sigma ? 1.f / e_sigma[i] : 1.f;
@@ -690,12 +639,13 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_pers_kernel(const NtParams p,
                 for (int r = 0; r < 4; ++r) {
                     float x = __fmul_rn(acc[i][j][r], inv_sigma);
                     if (p.bias) x = __fadd_rn(x, e_bias[j][r]);
-                    f[r] = eg_act(x, p.act, p.slope);
+                    f[r] = eaf.special ? eg_act(x, p.act, p.slope) : eg_act_apply(x, eaf);
                 }
                 if (maskp) {
                     const T* me = reinterpret_cast<const T*>(&e_mask[i][j]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) f[r] *= eg_act_grad_from_out(Elt<T>::ld(me + r), p.mask_act, p.mask_slope);
+                    for (int r = 0; r < 4; ++r)
+                        f[r] *= egf.special ? eg_act_grad_from_out(Elt<T>::ld(me + r), p.mask_act, p.mask_slope) : eg_grad_apply(Elt<T>::ld(me + r), egf);
                 }
                 OutVec ov;
                 T* oe = reinterpret_cast<T*>(&ov);
@@ -717,6 +667,8 @@ __global__ __launch_bounds__(256, 2) void igemm_nt_pers_kernel(const NtParams p,
 template <typename T>
 __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(const NtParams p, int nphase, int Mpad, int lvpr) {
     constexpr int VEC = Elt<T>::VEC;
+    const EgActFast saf = eg_act_fast(p.act, p.slope);
+    const EgGradFast sgf = eg_grad_fast(p.mask_act, p.mask_slope);
     const unsigned vpr = p.N / VEC;
     const unsigned total = (unsigned)p.M * vpr;
     const int phase = blockIdx.y;
@@ -749,13 +701,14 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(const NtParams 
         for (int q = 0; q < VEC; ++q) {
             float v = __fmul_rn(f[q], inv_sigma);
             if (p.bias) v = __fadd_rn(v, p.bias[bias_vec ? nb + q : (n + q) % p.bias_mod]);
-            f[q] = eg_act(v, p.act, p.slope);
+            f[q] = saf.special ? eg_act(v, p.act, p.slope) : eg_act_apply(v, saf);
         }
         if (mask) {
             const uint4 mv = *reinterpret_cast<const uint4*>(mask + o);
             const T* me = reinterpret_cast<const T*>(&mv);
 #pragma unroll
-            for (int q = 0; q < VEC; ++q) f[q] *= eg_act_grad_from_out(Elt<T>::ld(me + q), p.mask_act, p.mask_slope);
+            for (int q = 0; q < VEC; ++q)
+                f[q] *= sgf.special ? eg_act_grad_from_out(Elt<T>::ld(me + q), p.mask_act, p.mask_slope) : eg_grad_apply(Elt<T>::ld(me + q), sgf);
         }
         uint4 ov;
         T* oe = reinterpret_cast<T*>(&ov);
@@ -778,6 +731,7 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(const NtParams 
 template <typename T> void eg_launch_nt8(const NtParams& p, int nphase, int bn, int ns, hipStream_t st);
 template <typename T> void eg_launch_nt8p(const NtParams& p, const Nt8pGeom& g, int nphase, int ns, hipStream_t st);
 bool eg_nt8p_geometry(const NtParams& p, int nphase, Nt8pGeom& g);
+template <typename T> void eg_launch_nt8s(const NtParams& p, const Nt8pGeom& g, bool patch, int nphase, int ns, hipStream_t st);
 
 struct NtPlan { int kind, ns; };
 
@@ -832,11 +786,15 @@ static NtPlan nt_plan(const NtParams& p, int nphase, int vec, size_t esize, size
         case EG_NT_P8_256:
             if (!f.dma_ok || !f.c_tiles || (variant == EG_NT_P8_256 && (p.N % 256) != 0)) return bad;
             return {variant, nt_splits((long long)cdiv(p.M, 256) * (p.N / (variant == EG_NT_P8_256 ? 256 : 128)) * nphase, 224, f.nk_min, part256, ws_bytes, splitk)};
-        case EG_NT_P8P: {
+        case EG_NT_P8P:
+        case EG_NT_S8P: {
             Nt8pGeom g;
             if (!f.dma_ok || !f.c_tiles || !eg_nt8p_geometry(p, nphase, g)) return bad;
-            return {EG_NT_P8P, nt_splits((long long)cdiv(p.M, 256) * (p.N / 128) * nphase, 224, f.nk_min, part256, ws_bytes, splitk)};
+            return {variant, nt_splits((long long)cdiv(p.M, 256) * (p.N / 128) * nphase, 224, f.nk_min, part256, ws_bytes, splitk)};
         }
+        case EG_NT_S8:
+            if (!f.dma_ok || !f.c_tiles) return bad;
+            return {variant, nt_splits((long long)cdiv(p.M, 256) * (p.N / 128) * nphase, 224, f.nk_min, part256, ws_bytes, splitk)};
         case EG_NT_AUTO: return nt_plan_auto(p, nphase, f, ws_bytes, splitk);
         default: return {-1, 1};
     }
@@ -853,7 +811,7 @@ static NtPlan nt_plan_auto(const NtParams& p, int nphase, const NtFacts& f, size
     if (p.M >= 1024 && wgs256 * (splitk > 0 ? splitk : 16) >= 96 && f.nk_min >= 4) {
         const int ns = nt_splits(wgs256, 224, f.nk_min, part256, ws_bytes, splitk);
         Nt8pGeom g;
-        if (wgs256 * ns >= 96) return {eg_nt8p_geometry(p, nphase, g) ? EG_NT_P8P : EG_NT_P8_128, ns};
+        if (wgs256 * ns >= 96) return {eg_nt8p_geometry(p, nphase, g) ? EG_NT_S8P : EG_NT_S8, ns};
     }
     if (f.tiles128 < 512 && ws_bytes > 0) {
         const int ns = nt_splits(f.tiles128, 512, f.nk_min, part128, ws_bytes, splitk);
@@ -885,11 +843,16 @@ static int launch_nt(const NtParams& p, int nphase, int variant, int splitk, hip
     const NtPlan plan = nt_plan(p, nphase, Elt<T>::VEC, sizeof(T), p.part ? p.part_bytes : 0, variant, splitk);
     EG_REQUIRE(plan.kind > 0, "eg_epilogue.nt_variant %d cannot run this problem (M=%d N=%d C=%d)", variant, p.M, p.N, p.C);
     static const int xcd = [] { const char* e = getenv("EG_XCD_REMAP"); return e ? atoi(e) : 1; }();   // default on
-    if (plan.kind == EG_NT_P8_128 || plan.kind == EG_NT_P8_256 || plan.kind == EG_NT_P8P) {
+    if (plan.kind == EG_NT_P8_128 || plan.kind == EG_NT_P8_256 || plan.kind == EG_NT_P8P || plan.kind == EG_NT_S8 || plan.kind == EG_NT_S8P) {
         NtParams q = p;
         q.nsplit = plan.ns;
         q.xcd_remap = xcd;
-        if (plan.kind == EG_NT_P8P) {
+        if (plan.kind == EG_NT_S8 || plan.kind == EG_NT_S8P) {
+            Nt8pGeom g;
+            memset(&g, 0, sizeof(g));
+            if (plan.kind == EG_NT_S8P) EG_REQUIRE(eg_nt8p_geometry(p, nphase, g), "patch geometry");
+            eg_launch_nt8s<T>(q, g, plan.kind == EG_NT_S8P, nphase, plan.ns, st);
+        } else if (plan.kind == EG_NT_P8P) {
             Nt8pGeom g;
             EG_REQUIRE(eg_nt8p_geometry(p, nphase, g), "patch geometry");
             eg_launch_nt8p<T>(q, g, nphase, plan.ns, st);
@@ -979,6 +942,8 @@ extern "C" int eg_igemm_nt_tile(const eg_conv* c, int dtype, int bwd, int varian
     const NtPlan plan = nt_plan(p, nphase, vec_of(dtype), dtype == EG_F32 ? 4 : 2, (size_t)1 << 40, variant, splitk);
     if (plan.kind < 0) return -1;
     if (plan.kind == EG_NT_P8P) return 256 * 1000 + (plan.ns > 1 ? 146 : 145);
+    if (plan.kind == EG_NT_S8) return 256 * 1000 + (plan.ns > 1 ? 148 : 147);
+    if (plan.kind == EG_NT_S8P) return 256 * 1000 + (plan.ns > 1 ? 150 : 149);
     if (plan.kind == EG_NT_P8_128) return 256 * 1000 + (plan.ns > 1 ? 142 : 141);
     if (plan.kind == EG_NT_P8_256) return 256 * 1000 + (plan.ns > 1 ? 144 : 143);
     if (plan.kind == EG_NT_PERS) return 128 * 1000 + 135;
@@ -1055,7 +1020,7 @@ extern "C" size_t eg_conv_splitk_ws_bytes(const eg_conv* c, int dtype, int bwd) 
     // what the planner would split into with unlimited scratch (callers size one shared scratch from the maximum over their layers)
     const NtPlan plan = nt_plan(p, nphase, vec_of(dtype), dtype == EG_F32 ? 4 : 2, (size_t)1 << 40, EG_NT_AUTO, 0);
     if (plan.ns <= 1) return 0;
-    const int bm = (plan.kind == EG_NT_P8_128 || plan.kind == EG_NT_P8_256 || plan.kind == EG_NT_P8P) ? 256 : 128;
+    const int bm = plan.kind >= EG_NT_P8_128 ? 256 : 128;
     return (size_t)plan.ns * nphase * cdiv(p.M, bm) * bm * p.N * 4;
 }
 

@@ -88,29 +88,41 @@ __device__ __forceinline__ void nt_epilogue_lds(const NtParams& p, const NtPhase
                                                 int col0, int tid, int frow, int fq) {
     constexpr int VEC = Elt<T>::VEC;
     const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
-    constexpr int SW = 31;
+    constexpr int SW = BNW / 4 < 32 ? BNW / 4 - 1 : 31;     // 16-byte fp32 chunks per tile row - 1
     float* ct = reinterpret_cast<float*>(smem);
+    const EgActFast af = eg_act_fast(p.act, p.slope);
+    const EgGradFast gf = eg_grad_fast(p.mask_act, p.mask_slope);
     if (col0 >= 0) {
+        float bias[TN][4];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = row0 + i * 16 + frow;
-            const int mrow = min(m0 + row, p.M - 1);
-            const float inv_sigma = p.sigma ? 1.f / p.sigma[p.sigma_rows ? mrow / p.sigma_rows : 0] : 1.f;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int nl = col0 + j * 16 + fq * 4;
-                float4 v;
-                float* ve = reinterpret_cast<float*>(&v);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float x = __fmul_rn(acc[i][j][r], inv_sigma);
-                    const int n = nw0 + nl + r;
-                    if (p.bias && n < p.N) x = __fadd_rn(x, p.bias[p.bias_mod ? n % p.bias_mod : n]);
-                    ve[r] = eg_act(x, p.act, p.slope);
-                }
-                *reinterpret_cast<float4*>(ct + row * BNW + (((nl >> 2) ^ (row & SW)) << 2)) = v;
+            for (int r = 0; r < 4; ++r) {
+                const int n = nw0 + col0 + j * 16 + fq * 4 + r;
+                bias[j][r] = (p.bias && n < p.N) ? p.bias[p.bias_mod ? n % p.bias_mod : n] : 0.f;
             }
-        }
+        eg_if_fast(af.special, [&](auto fast) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = row0 + i * 16 + frow;
+                const int mrow = min(m0 + row, p.M - 1);
+                const float inv_sigma = p.sigma ? 1.f / p.sigma[p.sigma_rows ? mrow / p.sigma_rows : 0] : 1.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int nl = col0 + j * 16 + fq * 4;
+                    float4 v;
+                    float* ve = reinterpret_cast<float*>(&v);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float x = __fmul_rn(acc[i][j][r], inv_sigma);
+                        if (p.bias && nw0 + nl + r < p.N) x = __fadd_rn(x, bias[j][r]);
+                        if constexpr (decltype(fast)::value) ve[r] = eg_act_apply(x, af);
+                        else ve[r] = eg_act(x, p.act, p.slope);
+                    }
+                    *reinterpret_cast<float4*>(ct + row * BNW + (((nl >> 2) ^ (row & SW)) << 2)) = v;
+                }
+            }
+        });
     }
     __syncthreads();
     constexpr int VPR = BNW / VEC;
@@ -137,8 +149,13 @@ __device__ __forceinline__ void nt_epilogue_lds(const NtParams& p, const NtPhase
             if (mask) {
                 const uint4 mv = *reinterpret_cast<const uint4*>(mask + o);
                 const T* me = reinterpret_cast<const T*>(&mv);
+                if (!gf.special) {
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) f[q] *= eg_act_grad_from_out(Elt<T>::ld(me + q), p.mask_act, p.mask_slope);
+                    for (int q = 0; q < VEC; ++q) f[q] *= eg_grad_apply(Elt<T>::ld(me + q), gf);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) f[q] *= eg_act_grad_from_out(Elt<T>::ld(me + q), p.mask_act, p.mask_slope);
+                }
             }
             uint4 ov;
             T* oe = reinterpret_cast<T*>(&ov);
@@ -199,26 +216,31 @@ __device__ __forceinline__ void nt_epilogue_lds_pre(const NtEpiPre<T, TM, TN, PF
                                                     char* smem, int m0, int nw0, int row0, int col0, int tid, int frow, int fq) {
     constexpr int VEC = Elt<T>::VEC;
     const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
-    constexpr int SW = 31;
+    constexpr int SW = BNW / 4 < 32 ? BNW / 4 - 1 : 31;     // 16-byte fp32 chunks per tile row - 1
     float* ct = reinterpret_cast<float*>(smem);
+    const EgActFast af = eg_act_fast(p.act, p.slope);
+    const EgGradFast gf = eg_grad_fast(p.mask_act, p.mask_slope);
+    eg_if_fast(af.special, [&](auto fast) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = row0 + i * 16 + frow;
-        const float inv_sigma = p.sigma ? 1.f / e.inv_sigma[i] : 1.f;
+        for (int i = 0; i < TM; ++i) {
+            const int row = row0 + i * 16 + frow;
+            const float inv_sigma = p.sigma ? 1.f / e.inv_sigma[i] : 1.f;
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nl = col0 + j * 16 + fq * 4;
-            float4 v;
-            float* ve = reinterpret_cast<float*>(&v);
+            for (int j = 0; j < TN; ++j) {
+                const int nl = col0 + j * 16 + fq * 4;
+                float4 v;
+                float* ve = reinterpret_cast<float*>(&v);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = __fmul_rn(acc[i][j][r], inv_sigma);
-                if (p.bias && nw0 + nl + r < p.N) x = __fadd_rn(x, e.bias[j][r]);
-                ve[r] = eg_act(x, p.act, p.slope);
+                for (int r = 0; r < 4; ++r) {
+                    float x = __fmul_rn(acc[i][j][r], inv_sigma);
+                    if (p.bias && nw0 + nl + r < p.N) x = __fadd_rn(x, e.bias[j][r]);
+                    if constexpr (decltype(fast)::value) ve[r] = eg_act_apply(x, af);
+                    else ve[r] = eg_act(x, p.act, p.slope);
+                }
+                *reinterpret_cast<float4*>(ct + row * BNW + (((nl >> 2) ^ (row & SW)) << 2)) = v;
             }
-            *reinterpret_cast<float4*>(ct + row * BNW + (((nl >> 2) ^ (row & SW)) << 2)) = v;
         }
-    }
+    });
     __syncthreads();
     constexpr int VPR = BNW / VEC;
     constexpr int RPP = NT / VPR;
@@ -246,8 +268,13 @@ __device__ __forceinline__ void nt_epilogue_lds_pre(const NtEpiPre<T, TM, TN, PF
             if (mask) {
                 const uint4 mv = it < PF ? e.mask[it < PF ? it : 0] : *reinterpret_cast<const uint4*>(mask + o);
                 const T* me = reinterpret_cast<const T*>(&mv);
+                if (!gf.special) {
 #pragma unroll
-                for (int q = 0; q < VEC; ++q) f[q] *= eg_act_grad_from_out(Elt<T>::ld(me + q), p.mask_act, p.mask_slope);
+                    for (int q = 0; q < VEC; ++q) f[q] *= eg_grad_apply(Elt<T>::ld(me + q), gf);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) f[q] *= eg_act_grad_from_out(Elt<T>::ld(me + q), p.mask_act, p.mask_slope);
+                }
             }
             uint4 ov;
             T* oe = reinterpret_cast<T*>(&ov);

@@ -448,8 +448,9 @@ def test_spectral_norm_multi_layer_launch_matches_single():
 
 
 # eg_epilogue.nt_variant values (include/eadgan_hip.h EG_NT_*) -> label eg_igemm_nt_tile reports for the 128-column cases below
-NT_REG, NT_BUF128, NT_PERS, NT_P8_128, NT_P8_256, NT_P8P = 1, 2, 3, 4, 5, 6
-NT_VARIANTS = [(NT_BUF128, 128131), (NT_PERS, 128135), (NT_P8_128, 256141), (NT_P8P, 256145), (NT_REG, 128128)]
+NT_REG, NT_BUF128, NT_PERS, NT_P8_128, NT_P8_256, NT_P8P, NT_S8, NT_S8P = 1, 2, 3, 4, 5, 6, 7, 8
+NT_PATCHED = (NT_P8P, NT_S8P)
+NT_VARIANTS = [(NT_BUF128, 128131), (NT_PERS, 128135), (NT_P8_128, 256141), (NT_P8P, 256145), (NT_S8, 256147), (NT_S8P, 256149), (NT_REG, 128128)]
 
 
 def nt_tile(c, dtype, bwd, variant, splitk):
@@ -460,7 +461,7 @@ def nt_tile(c, dtype, bwd, variant, splitk):
 def same(got, ref, variant, dtype, K):
     """Variants that accumulate K in the reference order must match bit for bit; the input-patch variant accumulates class by class
     (fp32 sums in another order, then one rounding to the output type): a few output ulps."""
-    if variant != NT_P8P:
+    if variant not in NT_PATCHED:
         return torch.equal(got, ref)
     g, r = got.float(), ref.float()
     scale = r.abs().max().item() + 1e-6
@@ -495,10 +496,10 @@ def test_igemm_variants_match_register_staged_kernel(dtype):
     assert all(same(o, outs[-1], v, dtype, Cin * 16) for o, (v, _) in zip(outs[:-1], NT_VARIANTS))
     want = F.leaky_relu(F.conv2d(x, rq(w, dtype), b, 2, 1), 0.2)
     rt, at = tol(dtype, Cin * 16)
-    for o in (outs[0], outs[3]):
+    for o in (outs[0], outs[3], outs[5]):
         torch.testing.assert_close(nchw(o), want, rtol=rt, atol=at)
     # the planner on its own picks the 8-wave input-patch kernel for this launch
-    assert nt_tile(c, dtype, 0, 0, 0) == 256145
+    assert nt_tile(c, dtype, 0, 0, 0) == 256149
     # backward-data: dY [16,32,32,64] -> dX [16,64,64,128], 4 phases of M = 16384, two tapes
     B, H, Cin, Cout = 16, 64, 128, 64
     dy = rq(torch.randn(B, Cout, 32, 32, generator=g), dtype)
@@ -521,7 +522,7 @@ def test_igemm_variants_match_register_staged_kernel(dtype):
     want[:8] /= 1.3
     want[8:] /= 0.7
     rt, at = tol(dtype, Cout * 4)
-    for o in (outs[0], outs[3]):
+    for o in (outs[0], outs[3], outs[5]):
         torch.testing.assert_close(nchw(o), want, rtol=rt, atol=at)
     # 256 output channels: the 256x256 tile (ten-slot ring, two epilogue windows) and the 256x128 tile vs the register-staged kernel
     B, H, Cin, Cout = 64, 32, 64, 256
@@ -532,7 +533,7 @@ def test_igemm_variants_match_register_staged_kernel(dtype):
     wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
     ops.pack_fwd(c, dtype, w.to(DEV), wp)
     outs = []
-    v256 = ((NT_P8_256, 256143), (NT_P8_128, 256141), (NT_P8P, 256145), (NT_BUF128, 128131), (NT_REG, 128128))
+    v256 = ((NT_P8_256, 256143), (NT_P8_128, 256141), (NT_P8P, 256145), (NT_S8, 256147), (NT_S8P, 256149), (NT_BUF128, 128131), (NT_REG, 128128))
     for variant, label in v256:
         assert nt_tile(c, dtype, 0, variant, 1) == label
         y = torch.zeros(B, 16, 16, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
@@ -541,7 +542,7 @@ def test_igemm_variants_match_register_staged_kernel(dtype):
         outs.append(y)
     assert all(same(o, outs[-1], v, dtype, Cin * 16) for o, (v, _) in zip(outs[:-1], v256))
     rt, at = tol(dtype, Cin * 16)
-    for o in (outs[0], outs[2]):
+    for o in (outs[0], outs[2], outs[4]):
         torch.testing.assert_close(nchw(o), F.relu(F.conv2d(x, rq(w, dtype), b, 2, 1)), rtol=rt, atol=at)
     # a variant that cannot run the problem is an error, not a silent substitution (N = 128 is not a multiple of 256)
     with pytest.raises(RuntimeError):
@@ -552,7 +553,7 @@ def test_igemm_variants_match_register_staged_kernel(dtype):
 
 
 @pytest.mark.parametrize("variant,Cout", [(NT_BUF128, 128), (NT_PERS, 128), (NT_PERS, 256), (NT_P8_128, 128), (NT_P8_128, 256), (NT_P8_256, 256),
-                                          (NT_P8P, 128), (NT_P8P, 256)])
+                                          (NT_P8P, 128), (NT_P8P, 256), (NT_S8, 128), (NT_S8, 256), (NT_S8P, 128), (NT_S8P, 256)])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_igemm_dma_variants_ragged_rows_and_k_padding(dtype, variant, Cout):
     """Buffer-descriptor LDS-DMA NT kernels (128x128, persistent, 256x128, 256x256) on a launch whose last row tile is almost empty
@@ -580,7 +581,8 @@ def test_igemm_dma_variants_ragged_rows_and_k_padding(dtype, variant, Cout):
 
 
 @pytest.mark.parametrize("variant,nk_taps", [(NT_P8_128, 1), (NT_P8_128, 2), (NT_P8_256, 1), (NT_P8_256, 2), (NT_P8_256, 3), (NT_P8P, 1), (NT_P8P, 2),
-                                             (NT_P8P, 3)])
+                                             (NT_P8P, 3), (NT_S8, 1), (NT_S8, 2), (NT_S8, 3), (NT_S8, 4), (NT_S8, 5), (NT_S8P, 1), (NT_S8P, 2), (NT_S8P, 3),
+                                             (NT_S8P, 4), (NT_S8P, 5)])
 def test_igemm_nt8_short_k_loops(variant, nk_taps):
     """K loops of one, two and three K tiles (1x1 conv over 64 / 128 / 192 channels in bf16): the rings' prologue / tail counts."""
     dtype = 1
@@ -616,6 +618,7 @@ def test_igemm_splitk_small_m_deep_k(dtype):
     assert nt_tile(c, dtype, 0, NT_P8_128, 4) == 256142
     assert nt_tile(c, dtype, 0, NT_P8_256, 4) == 256144
     assert nt_tile(c, dtype, 0, NT_P8P, 4) == 256146 and nt_tile(c, dtype, 1, NT_P8P, 4) == 256146
+    assert nt_tile(c, dtype, 0, NT_S8, 4) == 256148 and nt_tile(c, dtype, 1, NT_S8P, 4) == 256150
     x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
     w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.03
     b = torch.randn(Cout, generator=g)
@@ -626,7 +629,7 @@ def test_igemm_splitk_small_m_deep_k(dtype):
     wpb = torch.empty(ops.pack_bwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
     ops.pack_bwd(c, dtype, w.to(DEV), wpb)
     sig = torch.tensor([1.3, 0.7], device=DEV)
-    for variant, splitk in ((0, 0), (NT_P8_128, 4), (NT_P8_256, 4), (NT_P8P, 4), (NT_P8P, 8)):
+    for variant, splitk in ((0, 0), (NT_P8_128, 4), (NT_P8_256, 4), (NT_P8P, 4), (NT_P8P, 8), (NT_S8, 4), (NT_S8P, 4), (NT_S8P, 8), (NT_S8P, 16)):
         ys = []
         for _ in range(2):
             y = torch.zeros(B, 4, 4, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
@@ -651,7 +654,7 @@ def test_igemm_splitk_small_m_deep_k(dtype):
         torch.testing.assert_close(nchw(dx), want, rtol=rt, atol=at)
 
 
-@pytest.mark.parametrize("variant", [0, NT_BUF128, NT_P8_128, NT_P8_256, NT_P8P])
+@pytest.mark.parametrize("variant", [0, NT_BUF128, NT_P8_128, NT_P8_256, NT_P8P, NT_S8, NT_S8P])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_igemm_splitk_range_starting_inside_a_tap(dtype, variant):
     """3x3 conv whose K split boundaries fall inside filter taps (9 taps x 256 channels, 4 splits of 9 (bf16) / 18 (fp32) K steps
