@@ -19,7 +19,7 @@ EG_F32, EG_BF16, EG_F16 = 0, 1, 2
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = range(5)
 OUT_NHWC, OUT_NCHW_F32 = 0, 1
 # eg_epilogue.nt_variant (include/eadgan_hip.h: EG_NT_*)
-NT_AUTO, NT_REG, NT_BUF128, NT_PERS, NT_P8_128, NT_P8_256, NT_P8P, NT_S8, NT_S8P = range(9)
+NT_AUTO, NT_REG, NT_BUF128, NT_PERS, NT_S8, NT_S8P = range(6)
 
 
 class EgConv(ctypes.Structure):

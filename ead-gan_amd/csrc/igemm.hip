@@ -725,11 +725,9 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(const NtParams 
 //                 bit-exact reference of the other variants
 //   EG_NT_BUF128  128 x 128, 4 waves, 2-stage buffer-descriptor LDS-DMA ring (+ split-K): launches too small for 256-row tiles
 //   EG_NT_PERS    persistent 128 x 128 pipeline: the 1-2-step image-side layers
-//   EG_NT_P8_128 / EG_NT_P8_256   igemm_nt8.hip: 256 x 128 / 256 x 256 tiles, 8 waves, deep ring, half-phase stagger (+ split-K)
-//   EG_NT_P8P     igemm_nt8.hip: 256 x 128, A held in LDS as an input patch shared by the taps of a class (+ split-K)
+//   EG_NT_S8      igemm_nt8s.hip: 256 x 128 tiles, 8 waves, 3-K-tile ring, one barrier per K tile, register double buffering (+ split-K)
+//   EG_NT_S8P     the same with A held in LDS as an input patch shared by the taps of a class
 // ------------------------------------------------------------------------------------------------
-template <typename T> void eg_launch_nt8(const NtParams& p, int nphase, int bn, int ns, hipStream_t st);
-template <typename T> void eg_launch_nt8p(const NtParams& p, const Nt8pGeom& g, int nphase, int ns, hipStream_t st);
 bool eg_nt8p_geometry(const NtParams& p, int nphase, Nt8pGeom& g);
 template <typename T> void eg_launch_nt8s(const NtParams& p, const Nt8pGeom& g, bool patch, int nphase, int ns, hipStream_t st);
 
@@ -782,11 +780,6 @@ static NtPlan nt_plan(const NtParams& p, int nphase, int vec, size_t esize, size
             if (!f.dma_ok || !f.c_tiles || f.nk_max < 2) return bad;
             return {EG_NT_BUF128, nt_splits(f.tiles128, 512, f.nk_min, part128, ws_bytes, splitk)};
         case EG_NT_PERS: return f.dma_ok ? NtPlan{EG_NT_PERS, 1} : bad;
-        case EG_NT_P8_128:
-        case EG_NT_P8_256:
-            if (!f.dma_ok || !f.c_tiles || (variant == EG_NT_P8_256 && (p.N % 256) != 0)) return bad;
-            return {variant, nt_splits((long long)cdiv(p.M, 256) * (p.N / (variant == EG_NT_P8_256 ? 256 : 128)) * nphase, 224, f.nk_min, part256, ws_bytes, splitk)};
-        case EG_NT_P8P:
         case EG_NT_S8P: {
             Nt8pGeom g;
             if (!f.dma_ok || !f.c_tiles || !eg_nt8p_geometry(p, nphase, g)) return bad;
@@ -806,13 +799,12 @@ static NtPlan nt_plan_auto(const NtParams& p, int nphase, const NtFacts& f, size
     // shallow launches (1-2 K steps: the image-side layers as 1x1 convolutions over patches) are all prologue and epilogue for a
     // workgroup-per-tile kernel: only the persistent pipeline overlaps them
     if (f.nk_max < 3 || !f.c_tiles) return f.tiles128 >= 128 ? NtPlan{EG_NT_PERS, 1} : NtPlan{EG_NT_REG, 1};
-    // 256-row tiles, one workgroup per CU: K is split until about 256 workgroups exist
+    // 256 x 128 tiles, one 8-wave workgroup per CU (igemm_nt8s): where the launch fills the chip in whole rounds and the K loop is long
+    // enough to pay for a prologue and an epilogue that nothing overlaps (measured per shape: profiles/r02_d_layers_nt8s.txt); shorter
+    // or fewer tiles run better as 128 x 128 tiles with two workgroups per CU (one's epilogue beside the other's K loop)
     const long long wgs256 = (long long)cdiv(p.M, 256) * (p.N / 128) * nphase;
-    if (p.M >= 1024 && wgs256 * (splitk > 0 ? splitk : 16) >= 96 && f.nk_min >= 4) {
-        const int ns = nt_splits(wgs256, 224, f.nk_min, part256, ws_bytes, splitk);
-        Nt8pGeom g;
-        if (wgs256 * ns >= 96) return {eg_nt8p_geometry(p, nphase, g) ? EG_NT_S8P : EG_NT_S8, ns};
-    }
+    const long long rounds = (wgs256 + 255) / 256;
+    if (splitk <= 1 && f.nk_min >= 32 && wgs256 >= 200 && wgs256 * 100 >= rounds * 256 * 85) return {EG_NT_S8, 1};
     if (f.tiles128 < 512 && ws_bytes > 0) {
         const int ns = nt_splits(f.tiles128, 512, f.nk_min, part128, ws_bytes, splitk);
         if (ns > 1) return {EG_NT_BUF128, ns};
@@ -842,22 +834,15 @@ template <typename T>
 static int launch_nt(const NtParams& p, int nphase, int variant, int splitk, hipStream_t st) {
     const NtPlan plan = nt_plan(p, nphase, Elt<T>::VEC, sizeof(T), p.part ? p.part_bytes : 0, variant, splitk);
     EG_REQUIRE(plan.kind > 0, "eg_epilogue.nt_variant %d cannot run this problem (M=%d N=%d C=%d)", variant, p.M, p.N, p.C);
-    static const int xcd = [] { const char* e = getenv("EG_XCD_REMAP"); return e ? atoi(e) : 1; }();   // default on
-    if (plan.kind == EG_NT_P8_128 || plan.kind == EG_NT_P8_256 || plan.kind == EG_NT_P8P || plan.kind == EG_NT_S8 || plan.kind == EG_NT_S8P) {
+    static const int xcd = [] { const char* e = getenv("EG_XCD_REMAP"); return e ? atoi(e) : 1; }();   // default on (7: + diagnostic piece skipping in PROF builds)
+    if (plan.kind == EG_NT_S8 || plan.kind == EG_NT_S8P) {
         NtParams q = p;
         q.nsplit = plan.ns;
         q.xcd_remap = xcd;
-        if (plan.kind == EG_NT_S8 || plan.kind == EG_NT_S8P) {
-            Nt8pGeom g;
-            memset(&g, 0, sizeof(g));
-            if (plan.kind == EG_NT_S8P) EG_REQUIRE(eg_nt8p_geometry(p, nphase, g), "patch geometry");
-            eg_launch_nt8s<T>(q, g, plan.kind == EG_NT_S8P, nphase, plan.ns, st);
-        } else if (plan.kind == EG_NT_P8P) {
-            Nt8pGeom g;
-            EG_REQUIRE(eg_nt8p_geometry(p, nphase, g), "patch geometry");
-            eg_launch_nt8p<T>(q, g, nphase, plan.ns, st);
-        } else
-            eg_launch_nt8<T>(q, nphase, plan.kind == EG_NT_P8_256 ? 256 : 128, plan.ns, st);
+        Nt8pGeom g;
+        memset(&g, 0, sizeof(g));
+        if (plan.kind == EG_NT_S8P) EG_REQUIRE(eg_nt8p_geometry(p, nphase, g), "patch geometry");
+        eg_launch_nt8s<T>(q, g, plan.kind == EG_NT_S8P, nphase, plan.ns, st);
         if (plan.ns > 1) launch_splitk_epilogue<T>(q, nphase, cdiv(p.M, 256) * 256, st);
         return 0;
     }
@@ -929,8 +914,8 @@ static int launch_nt(const NtParams& p, int nphase, int variant, int splitk, hip
 
 /* which igemm_nt instantiation eg_conv_fwd (bwd = 0) / eg_conv_bwd_data (bwd = 1) dispatches this problem to under the given hints
  * (profiling labels and tests; the same planner as the launches, with unlimited split-K scratch): BM * 1000 + code, code = BN of the
- * register-staged kernels, 131 / 132 = 128 x 128 buffer-descriptor kernel (plain / split-K), 135 = persistent pipeline, 141 / 142 =
- * igemm_nt8<128>, 143 / 144 = igemm_nt8<256>, 145 / 146 = igemm_nt8p (input patch); -1 = the forced variant cannot run the problem. */
+ * register-staged kernels, 131 / 132 = 128 x 128 buffer-descriptor kernel (plain / split-K), 135 = persistent pipeline, 147 / 148 =
+ * igemm_nt8s, 149 / 150 = igemm_nt8s with the input patch; -1 = the forced variant cannot run the problem. */
 extern "C" int eg_igemm_nt_tile(const eg_conv* c, int dtype, int bwd, int variant, int splitk) {
     if (!c || check_conv(c, dtype, bwd ? NEED_COUT : NEED_CIN)) return -1;
     NtParams p;
@@ -941,11 +926,8 @@ extern "C" int eg_igemm_nt_tile(const eg_conv* c, int dtype, int bwd, int varian
     p.out_mode = EG_OUT_NHWC;
     const NtPlan plan = nt_plan(p, nphase, vec_of(dtype), dtype == EG_F32 ? 4 : 2, (size_t)1 << 40, variant, splitk);
     if (plan.kind < 0) return -1;
-    if (plan.kind == EG_NT_P8P) return 256 * 1000 + (plan.ns > 1 ? 146 : 145);
     if (plan.kind == EG_NT_S8) return 256 * 1000 + (plan.ns > 1 ? 148 : 147);
     if (plan.kind == EG_NT_S8P) return 256 * 1000 + (plan.ns > 1 ? 150 : 149);
-    if (plan.kind == EG_NT_P8_128) return 256 * 1000 + (plan.ns > 1 ? 142 : 141);
-    if (plan.kind == EG_NT_P8_256) return 256 * 1000 + (plan.ns > 1 ? 144 : 143);
     if (plan.kind == EG_NT_PERS) return 128 * 1000 + 135;
     if (plan.kind == EG_NT_BUF128) return 128 * 1000 + (plan.ns > 1 ? 132 : 131);
     const int M = p.M, N = p.N;
@@ -1020,7 +1002,7 @@ extern "C" size_t eg_conv_splitk_ws_bytes(const eg_conv* c, int dtype, int bwd) 
     // what the planner would split into with unlimited scratch (callers size one shared scratch from the maximum over their layers)
     const NtPlan plan = nt_plan(p, nphase, vec_of(dtype), dtype == EG_F32 ? 4 : 2, (size_t)1 << 40, EG_NT_AUTO, 0);
     if (plan.ns <= 1) return 0;
-    const int bm = plan.kind >= EG_NT_P8_128 ? 256 : 128;
+    const int bm = plan.kind >= EG_NT_S8 ? 256 : 128;
     return (size_t)plan.ns * nphase * cdiv(p.M, bm) * bm * p.N * 4;
 }
 

@@ -314,6 +314,18 @@ __device__ __forceinline__ void eg_bufdma1s(const u32x4_t srd, unsigned v0, unsi
         : "memory");
 }
 
+// the same without saving M0 (three instructions): for kernels in which nothing else reads M0 -- gfx9 LDS instructions do not, and the
+// kernels that use this form contain no GWS, s_movrel or s_sendmsg code.  LDS address = base + OFF.
+template <int OFF>
+__device__ __forceinline__ void eg_bufdma1f(const u32x4_t srd, unsigned v0, unsigned soff, unsigned lds_base) {
+    asm volatile(
+        "s_add_u32 m0, %3, %4\n\ts_nop 0\n\t"
+        "buffer_load_dwordx4 %0, %1, %2 offen lds"
+        :
+        : "v"(v0), "s"(srd), "s"(soff), "s"(lds_base), "i"(OFF)
+        : "memory", "scc");
+}
+
 template <int STRIDE>
 __device__ __forceinline__ void eg_bufdma4s(const u32x4_t srd, unsigned v0, unsigned v1, unsigned v2, unsigned v3, unsigned soff, unsigned lds) {
     unsigned keep;

@@ -19,6 +19,7 @@
 // every wave before the barrier that ends iteration t, its first read is in iteration t+1.  WAR: stage t % 3 was last read in iteration
 // t-1 (fragments of K tile t), retired by that iteration's lgkmcnt(0) in front of its barrier.
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include <vector>
 
@@ -56,6 +57,7 @@ __device__ __forceinline__ void eg_wait_vm_dyn_lgkm0(int n) {      // wave-unifo
 template <typename T, bool PATCH, bool SPLITK, bool PROF = false>
 __global__ __launch_bounds__(512) void igemm_nt8s_kernel(const NtParams p, const Nt8pGeom g, int tiles_m, int tiles_n, unsigned long long* prof = nullptr) {
     unsigned long long pt[4] = {0, 0, 0, 0}, pr[4] = {0, 0, 0, 0}, pe[2] = {0, 0};
+    unsigned long long lp[3] = {0, 0, 0};              // PROF: K loop split into groups (reads + DMA issue + MFMA) | counted wait | barrier
     if (PROF) { pt[0] = __builtin_amdgcn_s_memtime(); pr[0] = __builtin_amdgcn_s_memrealtime(); }
     constexpr int VEC = Elt<T>::VEC;
     constexpr int BK = 8 * VEC;
@@ -121,10 +123,8 @@ __global__ __launch_bounds__(512) void igemm_nt8s_kernel(const NtParams p, const
     };
     auto mma4 = [&](uint4 (&ca)[2][4], uint4 (&cb)[2][4], int gidx) {     // group gidx: k half gidx >> 2, row tile gidx & 3, all four column tiles
         const int ks = gidx >> 2, i = gidx & 3;
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < TN; ++j) mfma_step<T>(ca[ks][i], cb[ks][j], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
     };
     auto read_b4 = [&](uint4 (&nb)[2][4], const char* sb, int ks) {
 #pragma unroll
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(512) void igemm_nt8s_kernel(const NtParams p, const
         const int tap0 = kt0 / ncb;
         int ty = tap0 / ph.TW, tx = tap0 - ty * ph.TW;
         unsigned kc_bytes = (unsigned)(kt0 - tap0 * ncb) * 128u;
-        int kb = kt0;                                  // K tile the next B piece belongs to (absolute)
+        unsigned kb_bytes = (unsigned)kt0 * 128u;      // byte offset of the next B K tile in a panel row
         if (ty < ph.TH) tap_offsets(ty, tx);
         else {
 #pragma unroll
@@ -176,14 +176,14 @@ __global__ __launch_bounds__(512) void igemm_nt8s_kernel(const NtParams p, const
             }
         };
         // piece q = 0..5 of the K tile being issued into ring stage `st`: four A pieces (rows 8w + 64q), two B pieces
-        auto issue_piece = [&](int st, int q) {
-            const unsigned base = lds0 + (unsigned)st * STAGE;
-            if (q < 4) {
-                eg_bufdma1s(srdA, va[q], kc_bytes, __builtin_amdgcn_readfirstlane(base + (unsigned)q * 0x2000u));
+        auto issue_piece = [&](unsigned base, auto qc) {       // base: this wave's first piece address in the stage (SGPR)
+            constexpr int q = decltype(qc)::value;
+            if constexpr (q < 4) {
+                eg_bufdma1f<q * 0x2000>(srdA, va[q], kc_bytes, base);
                 if (q == 3) advance_a();
             } else {
-                eg_bufdma1s(srdB, vb[q - 4], (unsigned)kb * 128u, __builtin_amdgcn_readfirstlane(base + 2u * SLOT + (unsigned)(q - 4) * 0x2000u));
-                if (q == 5) ++kb;
+                eg_bufdma1f<2 * SLOT + (q - 4) * 0x2000>(srdB, vb[q - 4], kb_bytes, base);
+                if (q == 5) kb_bytes += 128u;
             }
         };
         auto read_a4 = [&](uint4 (&na)[2][4], const char* sa, int ks) {
@@ -195,47 +195,68 @@ __global__ __launch_bounds__(512) void igemm_nt8s_kernel(const NtParams p, const
             const char* sb = smem + st * STAGE + BOFF + wn * (64 * 128);
             read_b4(nb, sb, 0); read_b4(nb, sb, 1); read_a4(na, sa, 0); read_a4(na, sa, 1);
         };
-        // one iteration: MFMAs of the current set | reads of K tile t+1 into the other set | DMA of K tile t+3
-        auto iter = [&](uint4 (&ca)[2][4], uint4 (&cb)[2][4], uint4 (&na)[2][4], uint4 (&nb)[2][4], int t, int st) {
-            const bool dm = t + 3 < nk;
+        // one iteration: MFMAs of the current set | reads of K tile t+1 into the other set | DMA of K tile t+3 (DM: the main loop;
+        // the last three iterations have nothing left to issue)
+        auto iter = [&](uint4 (&ca)[2][4], uint4 (&cb)[2][4], uint4 (&na)[2][4], uint4 (&nb)[2][4], int st, auto dmc, bool dm_rt) {
+            constexpr bool DM = decltype(dmc)::value;      // true: main loop, every piece issued; false: tail, pieces guarded by dm_rt
             const int st_r = st == 2 ? 0 : st + 1;     // stage of K tile t+1; K tile t+3 goes into stage st (K tile t's)
             const char* sa = smem + st_r * STAGE + wm * (64 * 128);
             const char* sb = smem + st_r * STAGE + BOFF + wn * (64 * 128);
-#pragma unroll
-            for (int gi = 0; gi < 8; ++gi) {
-                // (unconditional: behind a branch hipcc's wait-count pass makes every MFMA group wait for this iteration's fresh reads;
-                // past the last K tile the reads fetch stale bytes of a valid stage that nobody uses)
-                if (gi == 0) read_b4(nb, sb, 0);
-                if (gi == 1) read_b4(nb, sb, 1);
-                if (gi == 2) read_a4(na, sa, 0);
-                if (gi == 3) read_a4(na, sa, 1);
-                if (dm && gi >= 2) issue_piece(st, gi - 2);
-                mma4(ca, cb, gi);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (dm) eg_wait_vm_lgkm0<6>();
+            const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)st * STAGE);
+            unsigned long long q0 = 0, q1 = 0, q2 = 0;
+            if (PROF) q0 = __builtin_amdgcn_s_memtime();
+            // (reads are unconditional: behind a branch hipcc's wait-count pass makes every MFMA group wait for this iteration's fresh
+            // reads; past the last K tile they fetch stale bytes of a valid stage that nobody uses)
+            read_b4(nb, sb, 0);
+            mma4(ca, cb, 0); __builtin_amdgcn_sched_barrier(0);
+            read_b4(nb, sb, 1);
+            mma4(ca, cb, 1); __builtin_amdgcn_sched_barrier(0);
+            read_a4(na, sa, 0);
+            if (DM || dm_rt) issue_piece(base, std::integral_constant<int, 0>{});
+            mma4(ca, cb, 2); __builtin_amdgcn_sched_barrier(0);
+            read_a4(na, sa, 1);
+            if (DM || dm_rt) issue_piece(base, std::integral_constant<int, 1>{});
+            mma4(ca, cb, 3); __builtin_amdgcn_sched_barrier(0);
+            if (DM || dm_rt) issue_piece(base, std::integral_constant<int, 2>{});
+            mma4(ca, cb, 4); __builtin_amdgcn_sched_barrier(0);
+            if (DM || dm_rt) issue_piece(base, std::integral_constant<int, 3>{});
+            mma4(ca, cb, 5); __builtin_amdgcn_sched_barrier(0);
+            if (DM || dm_rt) issue_piece(base, std::integral_constant<int, 4>{});
+            mma4(ca, cb, 6); __builtin_amdgcn_sched_barrier(0);
+            if (DM || dm_rt) issue_piece(base, std::integral_constant<int, 5>{});
+            mma4(ca, cb, 7); __builtin_amdgcn_sched_barrier(0);
+            if (PROF) q1 = __builtin_amdgcn_s_memtime();
+            if (DM || dm_rt) eg_wait_vm_lgkm0<6>();
             else eg_wait_vm_lgkm0<0>();
+            if (PROF) q2 = __builtin_amdgcn_s_memtime();
             barrier();
+            if (PROF) { const unsigned long long q3 = __builtin_amdgcn_s_memtime(); lp[0] += q1 - q0; lp[1] += q2 - q1; lp[2] += q3 - q2; }
         };
         // prologue: K tiles 0, 1, 2 in flight; fragments of K tile 0 in registers; K tile 1 visible
         const int npro = min(nk, 3);
-        for (int s = 0; s < npro; ++s)
-#pragma unroll
-            for (int q = 0; q < 6; ++q) issue_piece(s, q);
+        for (int s = 0; s < npro; ++s) {
+            const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)s * STAGE);
+            issue_piece(base, std::integral_constant<int, 0>{}); issue_piece(base, std::integral_constant<int, 1>{});
+            issue_piece(base, std::integral_constant<int, 2>{}); issue_piece(base, std::integral_constant<int, 3>{});
+            issue_piece(base, std::integral_constant<int, 4>{}); issue_piece(base, std::integral_constant<int, 5>{});
+        }
         eg_wait_vm_dyn_lgkm0(6 * max(npro - 1, 0));
         barrier();
         if (nk > 0) read_all(fa0, fb0, 0);
         eg_wait_vm_dyn_lgkm0(6 * max(npro - 2, 0));
         barrier();
         if (PROF) { pt[1] = __builtin_amdgcn_s_memtime(); pr[1] = __builtin_amdgcn_s_memrealtime(); }
-        int st = 0;
-        for (int t = 0; t < nk; t += 2) {
-            iter(fa0, fb0, fa1, fb1, t, st);
-            st = st == 2 ? 0 : st + 1;
-            if (t + 1 < nk) {
-                iter(fa1, fb1, fa0, fb0, t + 1, st);
-                st = st == 2 ? 0 : st + 1;
-            }
+        // main loop in pairs (the two fragment sets swap roles); K tiles t+3 exist for t < nk - 3
+        int st = 0, t = 0;
+        auto next = [&]() { st = st == 2 ? 0 : st + 1; ++t; };
+        for (; t + 4 < nk;) {
+            iter(fa0, fb0, fa1, fb1, st, std::true_type{}, true); next();
+            iter(fa1, fb1, fa0, fb0, st, std::true_type{}, true); next();
+        }
+        // tail (t is even): the last iterations, DMA only while K tiles t+3 exist
+        for (; t < nk;) {
+            iter(fa0, fb0, fa1, fb1, st, std::false_type{}, t + 3 < nk); next();
+            if (t < nk) { iter(fa1, fb1, fa0, fb0, st, std::false_type{}, t + 3 < nk); next(); }
         }
     } else {
         // ---------------------------------------------------------------- input patch ----------------------------------------------
@@ -318,9 +339,10 @@ __global__ __launch_bounds__(512) void igemm_nt8s_kernel(const NtParams p, const
             }
         };
         auto issue_patch_piece = [&](int buf, unsigned soff, int q) {
-#pragma unroll
-            for (int qq = 0; qq < 7; ++qq)
-                if (qq == q) eg_bufdma1s(srdA, vp[qq], soff, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf * PCAP + (unsigned)qq * 0x2000u));
+            // q is wave-uniform: the register array is indexed through the scalar index register (s_set_gpr_idx / v_movrel), not by a
+            // chain of seven compares per call
+            const int qu = __builtin_amdgcn_readfirstlane(q);
+            eg_bufdma1s(srdA, vp[qu], soff, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf * PCAP + (unsigned)qu * 0x2000u));
         };
         auto read_a4 = [&](uint4 (&na)[2][4], const char* pbuf, int tapoff, int ks) {
 #pragma unroll
@@ -339,6 +361,8 @@ __global__ __launch_bounds__(512) void igemm_nt8s_kernel(const NtParams p, const
             int n_p = 0;
             if (rd && have_next) n_p = left == 1 ? g.npp - pp_done : min(4, g.npp - pp_done);
             const unsigned soff = (unsigned)ncb_n * 128u;
+            unsigned long long q0 = 0, q1 = 0, q2 = 0;
+            if (PROF) q0 = __builtin_amdgcn_s_memtime();
 #pragma unroll
             for (int gi = 0; gi < 8; ++gi) {
                 if (gi == 0) read_b4(nb, sb, 0);
@@ -355,8 +379,11 @@ __global__ __launch_bounds__(512) void igemm_nt8s_kernel(const NtParams p, const
             }
             pp_done += n_p;
             // everything older than this iteration's own issues has to land (B of K tile t+2); at the end of a step the next patch too
+            if (PROF) q1 = __builtin_amdgcn_s_memtime();
             eg_wait_vm_dyn_lgkm0((dm ? 2 : 0) + (left == 1 ? 0 : n_p));
+            if (PROF) q2 = __builtin_amdgcn_s_memtime();
             barrier();
+            if (PROF) { const unsigned long long q3 = __builtin_amdgcn_s_memtime(); lp[0] += q1 - q0; lp[1] += q2 - q1; lp[2] += q3 - q2; }
             if (rd) {
                 advance(itr);
                 if (--left == 0) { par ^= 1; enter_step(t + 2); }
@@ -423,19 +450,65 @@ __global__ __launch_bounds__(512) void igemm_nt8s_kernel(const NtParams p, const
     if (PROF) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pe[0] = __builtin_amdgcn_s_memtime(); }
     nt_epilogue_lds_pre<T, BM, 128, TM, TN, 512, PF>(epi, p, ph, acc, smem, m0, n0, wm * TM * 16, wn * 64, tid, frow, fq);
     if (PROF) pe[1] = __builtin_amdgcn_s_memtime();
-    if (PROF && tid == 0) {
+    if (PROF && (tid == 0 || tid == 448)) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         pt[3] = __builtin_amdgcn_s_memtime(); pr[3] = __builtin_amdgcn_s_memrealtime();
-        unsigned long long* o = prof + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 10;
+        unsigned long long* o = prof + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2 + (tid ? 1 : 0)) * 13;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { o[i] = pt[i]; o[4 + i] = pr[i]; }
-        o[8] = pe[0]; o[9] = pe[1];
+        o[8] = pe[0]; o[9] = pe[1]; o[10] = lp[0]; o[11] = lp[1]; o[12] = lp[2];
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// patch geometry of a launch; false if the problem does not fit the patch buffers (the caller then uses the im2col mode)
+bool eg_nt8p_geometry(const NtParams& p, int nphase, Nt8pGeom& g) {
+    memset(&g, 0, sizeof(g));
+    const int OH = 1 << p.lOH, OW = 1 << p.lOW;
+    if (OW > 256 || p.sy > 2 || p.sx > 2 || p.sy < 1 || p.sx < 1) return false;
+    if (OH * OW >= 256) { g.nimg = 1; g.OHt = 256 / OW; }
+    else { g.nimg = 256 / (OH * OW); g.OHt = OH; }
+    int amax_h = 1, amax_w = 1;
+    for (int f = 0; f < nphase; ++f) {
+        const NtPhase& ph = p.ph[f];
+        struct Ax { int t0, ts, A, o0; } ys[2], xs[2];
+        int ny = 0, nx = 0;
+        auto axis = [](int T, int d0, int ds, int s, Ax* out, int& n) -> bool {
+            n = 0;
+            if (ds > 0) {                              // forward: taps r, r + s, ... walk the lattice of residue r
+                if (ds != 1) return false;
+                for (int r = 0; r < s && r < T; ++r) out[n++] = {r, s, (T - r + s - 1) / s, d0 + r};
+            } else {                                   // backward-data phase: consecutive source pixels, taps in reverse
+                if (ds != -1 || s != 1) return false;
+                out[n++] = {T - 1, -1, T, d0 - (T - 1)};
+            }
+            return true;
+        };
+        if (!axis(ph.TH, ph.dy0, ph.dys, p.sy, ys, ny) || !axis(ph.TW, ph.dx0, ph.dxs, p.sx, xs, nx)) return false;
+        Nt8pPhase& gp = g.ph[f];
+        gp.ncls = 0;
+        for (int a = 0; a < ny; ++a)
+            for (int b = 0; b < nx; ++b) {
+                NtClass& c = gp.cls[gp.ncls++];
+                c.oy0 = ys[a].o0; c.ox0 = xs[b].o0; c.AH = ys[a].A; c.AW = xs[b].A;
+                c.ty0 = ys[a].t0; c.tys = ys[a].ts; c.tx0 = xs[b].t0; c.txs = xs[b].ts;
+                amax_h = std::max(amax_h, c.AH); amax_w = std::max(amax_w, c.AW);
+            }
+    }
+    g.PH = g.OHt + amax_h - 1;
+    g.PW = OW + amax_w - 1;
+    g.npix = g.nimg * g.PH * g.PW;
+    if (g.npix > EG_P8P_SLOTS) return false;
+    g.npp = ((g.npix + 7) / 8 + 7) / 8;
+    g.inv_pw = (1u << 20) / (unsigned)g.PW + 1;
+    g.inv_plane = (1u << 20) / (unsigned)(g.PH * g.PW) + 1;
+    for (unsigned x = 0; x < 512; ++x)                 // the two magic divisions are exact over the slot range
+        if (((x * g.inv_pw) >> 20) != x / (unsigned)g.PW || ((x * g.inv_plane) >> 20) != x / (unsigned)(g.PH * g.PW)) return false;
+    return true;
+}
+
 template <typename T, bool PATCH, bool SPLITK>
 static void launch_s(const NtParams& p, const Nt8pGeom& g, int nphase, int ns, hipStream_t st) {
     constexpr size_t lds = PATCH ? 2 * EG_P8P_SLOTS * 128 + 3 * 16384 : 9 * 16384;
@@ -451,29 +524,32 @@ static void launch_s(const NtParams& p, const Nt8pGeom& g, int nphase, int ns, h
             // diagnostic: synchronous instrumented launch, prints medians over workgroups (ticks of the shader clock; 100 MHz real time)
             const size_t nwg = (size_t)tm * tn * nphase;
             unsigned long long* dbuf = nullptr;
-            (void)hipMalloc(&dbuf, nwg * 80);
+            (void)hipMalloc(&dbuf, nwg * 208);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_nt8s_kernel<T, PATCH, SPLITK, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL((igemm_nt8s_kernel<T, PATCH, SPLITK, true>), dim3(tm * tn, 1, nphase), dim3(512), lds, st, p, g, tm, tn, dbuf);
             (void)hipStreamSynchronize(st);
-            std::vector<unsigned long long> h(nwg * 10);
-            (void)hipMemcpy(h.data(), dbuf, nwg * 80, hipMemcpyDeviceToHost);
+            std::vector<unsigned long long> h(nwg * 26);
+            (void)hipMemcpy(h.data(), dbuf, nwg * 208, hipMemcpyDeviceToHost);
             (void)hipFree(dbuf);
-            std::vector<double> pro, loop, epi, clk, start, endt, e_pf, e_st, e_dr;
+            std::vector<double> pro, loop, epi, clk, start, endt, e_pf, e_st, e_dr, l_g, l_w, l_b, l7_g, l7_w, l7_b;
             unsigned long long r0 = ~0ull, r1 = 0;
             for (size_t w = 0; w < nwg; ++w) {
-                const unsigned long long* o = &h[w * 10];
+                const unsigned long long* o = &h[w * 26];
+                const unsigned long long* o7 = &h[w * 26 + 13];
+                l7_g.push_back((double)o7[10]); l7_w.push_back((double)o7[11]); l7_b.push_back((double)o7[12]);
+                l_g.push_back((double)o[10]); l_w.push_back((double)o[11]); l_b.push_back((double)o[12]);
                 e_pf.push_back((double)(o[8] - o[2])); e_st.push_back((double)(o[9] - o[8])); e_dr.push_back((double)(o[3] - o[9]));
                 pro.push_back((double)(o[1] - o[0])); loop.push_back((double)(o[2] - o[1])); epi.push_back((double)(o[3] - o[2]));
                 clk.push_back((double)(o[3] - o[0]) / (double)(o[7] - o[4]) * 100.0);
                 r0 = std::min(r0, o[4]); r1 = std::max(r1, o[7]);
             }
-            for (size_t w = 0; w < nwg; ++w) { start.push_back((double)(h[w * 10 + 4] - r0) / 100.0); endt.push_back((double)(h[w * 10 + 7] - r0) / 100.0); }
+            for (size_t w = 0; w < nwg; ++w) { start.push_back((double)(h[w * 26 + 4] - r0) / 100.0); endt.push_back((double)(h[w * 26 + 7] - r0) / 100.0); }
             auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
             auto mx = [](std::vector<double>& v) { return *std::max_element(v.begin(), v.end()); };
             const int nk = p.ph[0].Kpad / (8 * Elt<T>::VEC);
-            fprintf(stderr, "[nt8s_prof] patch %d wgs %zu nk %d | median ticks: prologue %.0f  K loop %.0f (%.0f per K tile)  epilogue %.0f (operand fetch %.0f, staging + store issue %.0f, store drain %.0f) | clock %.0f MHz | "
+            fprintf(stderr, "[nt8s_prof] patch %d wgs %zu nk %d | median ticks: prologue %.0f  K loop %.0f (%.0f per K tile: wave 0 groups %.0f, counted wait %.0f, barrier %.0f; wave 7 %.0f / %.0f / %.0f)  epilogue %.0f (operand fetch %.0f, staging + store issue %.0f, store drain %.0f) | clock %.0f MHz | "
                     "first->last wave-0 stamp %.1f us, median WG start %.1f us, median end %.1f us, last end %.1f us\n",
-                    (int)PATCH, nwg, nk, med(pro), med(loop), med(loop) / nk, med(epi), med(e_pf), med(e_st), med(e_dr), med(clk), (double)(r1 - r0) / 100.0, med(start), med(endt), mx(endt));
+                    (int)PATCH, nwg, nk, med(pro), med(loop), med(loop) / nk, med(l_g) / nk, med(l_w) / nk, med(l_b) / nk, med(l7_g) / nk, med(l7_w) / nk, med(l7_b) / nk, med(epi), med(e_pf), med(e_st), med(e_dr), med(clk), (double)(r1 - r0) / 100.0, med(start), med(endt), mx(endt));
             return;
         }
     }

@@ -11,7 +11,7 @@ import os
 import torch
 
 from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, EG_BF16, EG_F16, EG_F32, NT_AUTO, NT_BUF128,
-                   NT_P8_128, NT_P8_256, NT_P8P, NT_PERS, NT_REG, NT_S8, NT_S8P, OUT_NCHW_F32, OUT_NHWC, EgConv, EgEpilogue, EgSnLayer, lib)
+                   NT_PERS, NT_REG, NT_S8, NT_S8P, OUT_NCHW_F32, OUT_NHWC, EgConv, EgEpilogue, EgSnLayer, lib)
 
 __all__ = ["EG_F32", "EG_BF16", "EG_F16", "ACT_NONE", "ACT_LRELU", "ACT_RELU", "ACT_TANH", "ACT_SIGMOID", "OUT_NHWC",
            "OUT_NCHW_F32"]
@@ -125,9 +125,6 @@ def _timed(kind, c, dtype, args, ep=None):
         bm, bn = tile // 1000, tile % 1000
         label = {131: f"igemm_nt_buf_kernel<{tname}>", 132: f"igemm_nt_buf_kernel<{tname}>+splitk",
                  135: f"igemm_nt_pers_kernel<{tname}>",
-                 141: f"igemm_nt8_kernel<{tname},128>", 142: f"igemm_nt8_kernel<{tname},128>+splitk",
-                 143: f"igemm_nt8_kernel<{tname},256>", 144: f"igemm_nt8_kernel<{tname},256>+splitk",
-                 145: f"igemm_nt8p_kernel<{tname}>", 146: f"igemm_nt8p_kernel<{tname}>+splitk",
                  147: f"igemm_nt8s_kernel<{tname},im2col>", 148: f"igemm_nt8s_kernel<{tname},im2col>+splitk",
                  149: f"igemm_nt8s_kernel<{tname},patch>", 150: f"igemm_nt8s_kernel<{tname},patch>+splitk"}.get(bn, f"igemm_nt_kernel<{tname},{bm},{bn}>")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -69,15 +69,12 @@ typedef struct eg_epilogue {
  * the library holds no tuning state.  All variants accumulate K in the same order: without a K split they are bit-identical. */
 #define EG_NT_AUTO 0
 #define EG_NT_REG 1      /* register-staged 128 x {16,32,64,128} tiles: every problem; the reference of the others */
-#define EG_NT_BUF128 2   /* 128 x 128, 4 waves, 2-stage buffer-descriptor LDS-DMA ring */
+#define EG_NT_BUF128 2   /* 128 x 128, 4 waves (two workgroups per CU), 2-stage buffer-descriptor LDS-DMA ring */
 #define EG_NT_PERS 3     /* persistent 128 x 128 pipeline (1-2-step image-side layers) */
-#define EG_NT_P8_128 4   /* 256 x 128, 8 waves, 3-K-tile ring, half-phase stagger (igemm_nt8.hip) */
-#define EG_NT_P8_256 5   /* 256 x 256, 8 waves, ten-slot ring */
-#define EG_NT_P8P 6      /* 256 x 128, 8 waves, A operand held in LDS as an input patch shared by the filter taps of a class: 2.6-3.5x
+#define EG_NT_S8 4       /* 256 x 128, 8 waves, 3-K-tile LDS-DMA ring, one barrier per K tile, fragments double-buffered in registers */
+#define EG_NT_S8P 5      /* the same with the A operand held in LDS as an input patch shared by the filter taps of a class: 2.6-3.5x
                           * fewer A bytes through the LDS-DMA path; K is accumulated class by class (deterministic, not bit-identical
                           * to the tap-major variants) */
-#define EG_NT_S8 7       /* 256 x 128, 8 waves, one barrier per K tile, fragments double-buffered in registers (igemm_nt8s.hip) */
-#define EG_NT_S8P 8      /* the same with the input patch of EG_NT_P8P */
 
 /* --- implicit-GEMM convolution family (MFMA) ---------------------------------------------------
  * replaces torch.nn.functional.conv2d / conv_transpose2d / linear and their autograd backward:
@@ -97,9 +94,8 @@ int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, const void* wp
                      const eg_epilogue* ep, eg_stream_t s);
 /* which kernel eg_conv_fwd (bwd = 0) / eg_conv_bwd_data (bwd = 1) runs this problem on under the given hints (same planner as the
  * launches, unlimited split-K scratch): BM * 1000 + code; code = BN of the register-staged kernels, 131 / 132 = 128 x 128
- * buffer-descriptor kernel (plain / split-K), 135 = persistent pipeline, 141 / 142 = igemm_nt8<128>, 143 / 144 = igemm_nt8<256>,
- * 145 / 146 = igemm_nt8p (input patch), 147 / 148 = igemm_nt8s, 149 / 150 = igemm_nt8s with the input patch; -1 = the forced variant
- * cannot run the problem.  Profiling labels and tests. */
+ * buffer-descriptor kernel (plain / split-K), 135 = persistent pipeline, 147 / 148 = igemm_nt8s (plain / split-K), 149 / 150 =
+ * igemm_nt8s with the input patch; -1 = the forced variant cannot run the problem.  Profiling labels and tests. */
 int eg_igemm_nt_tile(const eg_conv* c, int dtype, int bwd, int variant, int splitk);
 /* bytes of eg_epilogue.splitk_ws that let eg_conv_fwd (bwd = 0) / eg_conv_bwd_data (bwd = 1) split as far as the policy wants */
 size_t eg_conv_splitk_ws_bytes(const eg_conv* c, int dtype, int bwd);

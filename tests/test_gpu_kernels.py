@@ -448,9 +448,9 @@ def test_spectral_norm_multi_layer_launch_matches_single():
 
 
 # eg_epilogue.nt_variant values (include/eadgan_hip.h EG_NT_*) -> label eg_igemm_nt_tile reports for the 128-column cases below
-NT_REG, NT_BUF128, NT_PERS, NT_P8_128, NT_P8_256, NT_P8P, NT_S8, NT_S8P = 1, 2, 3, 4, 5, 6, 7, 8
-NT_PATCHED = (NT_P8P, NT_S8P)
-NT_VARIANTS = [(NT_BUF128, 128131), (NT_PERS, 128135), (NT_P8_128, 256141), (NT_P8P, 256145), (NT_S8, 256147), (NT_S8P, 256149), (NT_REG, 128128)]
+NT_REG, NT_BUF128, NT_PERS, NT_S8, NT_S8P = 1, 2, 3, 4, 5
+NT_PATCHED = (NT_S8P,)
+NT_VARIANTS = [(NT_BUF128, 128131), (NT_PERS, 128135), (NT_S8, 256147), (NT_S8P, 256149), (NT_REG, 128128)]
 
 
 def nt_tile(c, dtype, bwd, variant, splitk):
@@ -472,9 +472,10 @@ def same(got, ref, variant, dtype, K):
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_igemm_variants_match_register_staged_kernel(dtype):
     """Every LDS-DMA variant of the NT kernel, forced per call through eg_epilogue.nt_variant (the library keeps no tuning state):
-    128x128 buffer-descriptor kernel, persistent pipeline, and the 8-wave 256x128 / 256x256 kernels of igemm_nt8.hip -- bit-exact vs
-    the register-staged kernel (same K order) and within tolerance of torch, for a padded stride-2 forward conv, a 4-phase
-    backward-data with per-tape 1/sigma and an activation mask, and a 256-column forward."""
+    128x128 buffer-descriptor kernel, persistent pipeline, and the 8-wave 256x128 kernel of igemm_nt8s.hip in both modes -- bit-exact vs
+    the register-staged kernel where the K order is the same (a few output ulps for the input-patch mode) and within tolerance of
+    torch, for a padded stride-2 forward conv, a 4-phase backward-data with per-tape 1/sigma and an activation mask, and a
+    256-column forward."""
     lib = eg._lib.lib()
     g = torch.Generator().manual_seed(21)
     # forward: B=64, 64x64x64 -> 32x32x128  (M = 65536: 512 tiles of 128 rows, 256 of 256)
@@ -496,10 +497,10 @@ def test_igemm_variants_match_register_staged_kernel(dtype):
     assert all(same(o, outs[-1], v, dtype, Cin * 16) for o, (v, _) in zip(outs[:-1], NT_VARIANTS))
     want = F.leaky_relu(F.conv2d(x, rq(w, dtype), b, 2, 1), 0.2)
     rt, at = tol(dtype, Cin * 16)
-    for o in (outs[0], outs[3], outs[5]):
+    for o in (outs[0], outs[2], outs[3]):
         torch.testing.assert_close(nchw(o), want, rtol=rt, atol=at)
-    # the planner on its own picks the 8-wave input-patch kernel for this launch
-    assert nt_tile(c, dtype, 0, 0, 0) == 256149
+    # the planner on its own: one 256-row tile per CU needs a K loop of at least 32 K tiles (here: fp32, 32 elements per K tile)
+    assert nt_tile(c, dtype, 0, 0, 0) == (256147 if dtype == 0 else 128131)
     # backward-data: dY [16,32,32,64] -> dX [16,64,64,128], 4 phases of M = 16384, two tapes
     B, H, Cin, Cout = 16, 64, 128, 64
     dy = rq(torch.randn(B, Cout, 32, 32, generator=g), dtype)
@@ -522,9 +523,9 @@ def test_igemm_variants_match_register_staged_kernel(dtype):
     want[:8] /= 1.3
     want[8:] /= 0.7
     rt, at = tol(dtype, Cout * 4)
-    for o in (outs[0], outs[3], outs[5]):
+    for o in (outs[0], outs[2], outs[3]):
         torch.testing.assert_close(nchw(o), want, rtol=rt, atol=at)
-    # 256 output channels: the 256x256 tile (ten-slot ring, two epilogue windows) and the 256x128 tile vs the register-staged kernel
+    # 256 output channels: two N tiles per M tile (adjacent workgroups of one XCD share the gathered rows)
     B, H, Cin, Cout = 64, 32, 64, 256
     x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
     w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.05
@@ -533,7 +534,7 @@ def test_igemm_variants_match_register_staged_kernel(dtype):
     wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
     ops.pack_fwd(c, dtype, w.to(DEV), wp)
     outs = []
-    v256 = ((NT_P8_256, 256143), (NT_P8_128, 256141), (NT_P8P, 256145), (NT_S8, 256147), (NT_S8P, 256149), (NT_BUF128, 128131), (NT_REG, 128128))
+    v256 = ((NT_S8, 256147), (NT_S8P, 256149), (NT_BUF128, 128131), (NT_REG, 128128))
     for variant, label in v256:
         assert nt_tile(c, dtype, 0, variant, 1) == label
         y = torch.zeros(B, 16, 16, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
@@ -542,21 +543,20 @@ def test_igemm_variants_match_register_staged_kernel(dtype):
         outs.append(y)
     assert all(same(o, outs[-1], v, dtype, Cin * 16) for o, (v, _) in zip(outs[:-1], v256))
     rt, at = tol(dtype, Cin * 16)
-    for o in (outs[0], outs[2], outs[4]):
+    for o in (outs[0], outs[1]):
         torch.testing.assert_close(nchw(o), F.relu(F.conv2d(x, rq(w, dtype), b, 2, 1)), rtol=rt, atol=at)
-    # a variant that cannot run the problem is an error, not a silent substitution (N = 128 is not a multiple of 256)
+    # a variant that cannot run the problem is an error, not a silent substitution (64 output channels: no 128-column tile)
     with pytest.raises(RuntimeError):
-        c = ops.make_conv(4, 8, 8, 64, 128, 3, 1, 1)
+        c = ops.make_conv(4, 8, 8, 64, 64, 3, 1, 1)
         ops.conv_fwd(c, dtype, torch.zeros(4, 8, 8, 64, device=DEV, dtype=ops.torch_dtype(dtype)),
                      torch.zeros(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype)),
-                     torch.zeros(4, 8, 8, 128, device=DEV, dtype=ops.torch_dtype(dtype)), ops.epilogue(nt_variant=NT_P8_256))
+                     torch.zeros(4, 8, 8, 64, device=DEV, dtype=ops.torch_dtype(dtype)), ops.epilogue(nt_variant=NT_S8))
 
 
-@pytest.mark.parametrize("variant,Cout", [(NT_BUF128, 128), (NT_PERS, 128), (NT_PERS, 256), (NT_P8_128, 128), (NT_P8_128, 256), (NT_P8_256, 256),
-                                          (NT_P8P, 128), (NT_P8P, 256), (NT_S8, 128), (NT_S8, 256), (NT_S8P, 128), (NT_S8P, 256)])
+@pytest.mark.parametrize("variant,Cout", [(NT_BUF128, 128), (NT_PERS, 128), (NT_PERS, 256), (NT_S8, 128), (NT_S8, 256), (NT_S8P, 128), (NT_S8P, 256)])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_igemm_dma_variants_ragged_rows_and_k_padding(dtype, variant, Cout):
-    """Buffer-descriptor LDS-DMA NT kernels (128x128, persistent, 256x128, 256x256) on a launch whose last row tile is almost empty
+    """Buffer-descriptor LDS-DMA NT kernels (128x128, persistent, 256x128 in both modes) on a launch whose last row tile is almost empty
     (M = 1025*64) and whose 3x3 filter walks 9 taps with image borders on every side (9 K tiles: odd, so the rings end mid-cycle):
     bit-exact vs the register-staged kernel."""
     g = torch.Generator().manual_seed(22)
@@ -580,11 +580,10 @@ def test_igemm_dma_variants_ragged_rows_and_k_padding(dtype, variant, Cout):
     torch.testing.assert_close(nchw(outs[0][-64:]), F.conv2d(x[-64:], rq(w, dtype), None, 1, 1), rtol=rt, atol=at)
 
 
-@pytest.mark.parametrize("variant,nk_taps", [(NT_P8_128, 1), (NT_P8_128, 2), (NT_P8_256, 1), (NT_P8_256, 2), (NT_P8_256, 3), (NT_P8P, 1), (NT_P8P, 2),
-                                             (NT_P8P, 3), (NT_S8, 1), (NT_S8, 2), (NT_S8, 3), (NT_S8, 4), (NT_S8, 5), (NT_S8P, 1), (NT_S8P, 2), (NT_S8P, 3),
-                                             (NT_S8P, 4), (NT_S8P, 5)])
-def test_igemm_nt8_short_k_loops(variant, nk_taps):
-    """K loops of one, two and three K tiles (1x1 conv over 64 / 128 / 192 channels in bf16): the rings' prologue / tail counts."""
+@pytest.mark.parametrize("variant,nk_taps", [(NT_S8, 1), (NT_S8, 2), (NT_S8, 3), (NT_S8, 4), (NT_S8, 5), (NT_S8, 6), (NT_S8, 7), (NT_S8P, 1), (NT_S8P, 2),
+                                             (NT_S8P, 3), (NT_S8P, 4), (NT_S8P, 5)])
+def test_igemm_nt8s_short_k_loops(variant, nk_taps):
+    """K loops of one to seven K tiles (1x1 conv over 64 .. 448 channels in bf16): the ring's prologue, main-loop and tail counts."""
     dtype = 1
     g = torch.Generator().manual_seed(26)
     B, H, Cin, Cout = 16, 8, 64 * nk_taps, 256
@@ -607,7 +606,7 @@ def test_igemm_splitk_small_m_deep_k(dtype):
     """Few-row / deep-K launches (the last Discriminator conv: celebA/EAD-GAN_celebA.py:118) split K across workgroups into fp32
     partial tiles that a second launch sums in a fixed order before the fused epilogue: forward (bias + LeakyReLU) and 4-phase
     backward-data (1/sigma per tape + activation-gradient mask) against torch, and repeatable bit for bit -- planner's choice (128-row
-    tiles at this M), and the 8-wave kernels forced with 4 splits."""
+    tiles at this M), and the 8-wave kernel forced with 4 to 16 splits in both modes."""
     lib = eg._lib.lib()
     ws = torch.empty(16 << 20, device=DEV, dtype=torch.float32)
     g = torch.Generator().manual_seed(23)
@@ -615,9 +614,6 @@ def test_igemm_splitk_small_m_deep_k(dtype):
     c = ops.make_conv(B, H, H, Cin, Cout, 4, 2, 1)
     assert ops.conv_splitk_ws_bytes(c, dtype, 0) > 0 and ops.conv_splitk_ws_bytes(c, dtype, 1) > 0
     assert nt_tile(c, dtype, 0, 0, 0) == 128132
-    assert nt_tile(c, dtype, 0, NT_P8_128, 4) == 256142
-    assert nt_tile(c, dtype, 0, NT_P8_256, 4) == 256144
-    assert nt_tile(c, dtype, 0, NT_P8P, 4) == 256146 and nt_tile(c, dtype, 1, NT_P8P, 4) == 256146
     assert nt_tile(c, dtype, 0, NT_S8, 4) == 256148 and nt_tile(c, dtype, 1, NT_S8P, 4) == 256150
     x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
     w = torch.randn(Cout, Cin, 4, 4, generator=g) * 0.03
@@ -629,7 +625,7 @@ def test_igemm_splitk_small_m_deep_k(dtype):
     wpb = torch.empty(ops.pack_bwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
     ops.pack_bwd(c, dtype, w.to(DEV), wpb)
     sig = torch.tensor([1.3, 0.7], device=DEV)
-    for variant, splitk in ((0, 0), (NT_P8_128, 4), (NT_P8_256, 4), (NT_P8P, 4), (NT_P8P, 8), (NT_S8, 4), (NT_S8P, 4), (NT_S8P, 8), (NT_S8P, 16)):
+    for variant, splitk in ((0, 0), (NT_S8, 4), (NT_S8, 8), (NT_S8P, 4), (NT_S8P, 8), (NT_S8P, 16)):
         ys = []
         for _ in range(2):
             y = torch.zeros(B, 4, 4, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
@@ -654,7 +650,7 @@ def test_igemm_splitk_small_m_deep_k(dtype):
         torch.testing.assert_close(nchw(dx), want, rtol=rt, atol=at)
 
 
-@pytest.mark.parametrize("variant", [0, NT_BUF128, NT_P8_128, NT_P8_256, NT_P8P, NT_S8, NT_S8P])
+@pytest.mark.parametrize("variant", [0, NT_BUF128, NT_S8, NT_S8P])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_igemm_splitk_range_starting_inside_a_tap(dtype, variant):
     """3x3 conv whose K split boundaries fall inside filter taps (9 taps x 256 channels, 4 splits of 9 (bf16) / 18 (fp32) K steps
