@@ -232,6 +232,16 @@ class _HipModule(nn.Module):
         for e in self._engines.values():
             e.repack()
 
+    def fresh_engine(self, B):
+        """The engine for batch size B with panels re-packed from the masters: the drop-in forward path.  The kernels read packed
+        copies of the convolution weights, and the masters can change behind the module's back in ways nothing reports --
+        ``optimizer.step()`` bumps a version counter, ``module.apply(weights_init_normal)`` writes through ``.data`` and does not -- so
+        every drop-in forward re-packs first (2 small launches per layer, asynchronous).  The fused trainers keep masters and panels in
+        step themselves and never come through here."""
+        eng = self.engine(B)
+        eng.repack()
+        return eng
+
     def load_state_dict(self, *a, **k):
         out = super().load_state_dict(*a, **k)
         self.repack()
@@ -268,7 +278,7 @@ class Generator(_HipModule):
 
     def forward(self, noise, labels, code):
         _require_cuda(noise)
-        eng = self.engine(noise.shape[0])
+        eng = self.fresh_engine(noise.shape[0])
         if not self.training:
             # inference (generate_image.py:146-154, gen_imgs.py:106-120): running-stat BatchNorm, no autograd graph
             with torch.no_grad():
@@ -516,7 +526,7 @@ class Discriminator(_HipModule):
     def raw_forward(self, img):
         """head output [B,19] with autograd support (eager path)."""
         _require_cuda(img)
-        eng = self.engine(img.shape[0])
+        eng = self.fresh_engine(img.shape[0])
         t = self._next_tape
         self._next_tape = (t + 1) % _DiscEngine.NT
         return _DiscFn.apply(eng, t, self.training, img.float().contiguous(), *list(self.parameters()))

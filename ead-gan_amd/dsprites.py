@@ -98,7 +98,7 @@ class Encoder_pxy(_HipModule):
 
     def forward(self, img):
         _require_cuda(img)
-        return self.engine(img.shape[0]).forward(img.float().contiguous()).clone()
+        return self.fresh_engine(img.shape[0]).forward(img.float().contiguous()).clone()
 
 
 # ================================================================================================
@@ -144,7 +144,7 @@ class Discriminator(_TrunkModule):
     def forward(self, img):
         from .mnist import _TrunkFn
         _require_cuda(img)
-        eng = self.engine(img.shape[0])
+        eng = self.fresh_engine(img.shape[0])
         t = self._next_tape
         self._next_tape = (t + 1) % self.NT
         (logit,) = _TrunkFn.apply(eng, t, self.training, ("fc2",), img.float().contiguous(), *list(self.parameters()))
@@ -176,7 +176,7 @@ class Encoder(_TrunkModule):
     def forward(self, img):
         from .mnist import _TrunkFn
         _require_cuda(img)
-        eng = self.engine(img.shape[0])
+        eng = self.fresh_engine(img.shape[0])
         t = self._next_tape
         self._next_tape = (t + 1) % self.NT
         cat, cont = _TrunkFn.apply(eng, t, self.training, ("cat_layer.0", "cont_layer.0"), img.float().contiguous(), *list(self.parameters()))
@@ -332,7 +332,7 @@ class Generator(_HipModule):
     def forward(self, z_c):
         _require_cuda(z_c)
         z_c = z_c.float().contiguous()
-        eng = self.engine(z_c.shape[0])
+        eng = self.fresh_engine(z_c.shape[0])
         if not self.training:       # inference (dSprites/gen_imgs.py): running-stat BatchNorm, no autograd graph
             with torch.no_grad():
                 return eng.forward(z_c[:, :self.n_classes].contiguous(), z_c[:, self.n_classes:].contiguous(), training=False).clone()

@@ -221,7 +221,7 @@ class Generator(_HipModule):
 
     def forward(self, noise, labels, code):
         _require_cuda(noise)
-        eng = self.engine(noise.shape[0])
+        eng = self.fresh_engine(noise.shape[0])
         if not self.training:       # inference (MNIST/generate_image.py): running-stat BatchNorm, no autograd graph
             with torch.no_grad():
                 return eng.forward(noise.float().contiguous(), labels.float().contiguous(), code.float().contiguous(), training=False).clone()
@@ -298,7 +298,7 @@ class Discriminator(_TrunkModule):
 
     def forward(self, img):
         _require_cuda(img)
-        eng = self.engine(img.shape[0])
+        eng = self.fresh_engine(img.shape[0])
         t = self._next_tape
         self._next_tape = (t + 1) % self.NT
         (out,) = _TrunkFn.apply(eng, t, self.training, ("adv_layer.0",), img.float().contiguous(), *list(self.parameters()))
@@ -329,7 +329,7 @@ class Encoder(_TrunkModule):
 
     def forward(self, img):
         _require_cuda(img)
-        eng = self.engine(img.shape[0])
+        eng = self.fresh_engine(img.shape[0])
         t = self._next_tape
         self._next_tape = (t + 1) % self.NT
         logits, latent = _TrunkFn.apply(eng, t, self.training, ("aux_layer.0", "latent_layer.0"), img.float().contiguous(), *list(self.parameters()))
