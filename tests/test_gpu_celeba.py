@@ -239,6 +239,40 @@ def test_teacher_forced_second_step_fp32():
         assert abs(got[k] - want[k]) < t, (k, got[k], want[k])
 
 
+def teacher_forced_curve(steps, B=4, seed=11, progress=None):
+    """The form in which BASELINE.json's "loss curves within 1e-3 of reference for 1k steps" is claimed: the
+    oracle free-runs the reference loop; before EVERY iteration the HIP side is reset to the oracle's state -- parameters, BatchNorm
+    running statistics, spectral-norm u / v, and the moments and step counts of all three Adams -- then both run that iteration on
+    the same inputs.  Returns the per-iteration |loss difference| for g / d / info, [steps, 3].  (Free-running, two fp32
+    implementations of this GAN separate chaotically after a few Adam updates: reference vs oracle on one machine does.)"""
+    orc, G, D = build_pair(seed, "f32")
+    tr = eg.celeba.CelebATrainer(G, D, B, dtype="f32")
+    rng = np.random.RandomState(seed)
+    g = torch.Generator().manual_seed(seed)
+    dev = np.zeros((steps, 3))
+    for i in range(steps):
+        if i:
+            G.load_state_dict({k: v.detach() for k, v in orc.G.items()})
+            D.load_state_dict({k: v.detach() for k, v in orc.D.items()})
+            tr.import_adam_state(orc.opt_G, orc.opt_D, orc.opt_info)
+        real = torch.rand((B, 3, 64, 64), generator=g) * 2 - 1
+        z, code, labels = co.draw_step_inputs(rng, B)
+        got = tr.train_step(real.to(DEV), z.to(DEV), code.to(DEV), labels.to(DEV))
+        want = orc.train_step(real, z, code, labels)
+        dev[i] = [abs(got[k] - want[k]) for k in ("g_loss", "d_loss", "info_loss")]
+        if progress is not None:
+            progress(i, dev)
+    return dev
+
+
+def test_teacher_forced_loss_curve_200_steps_fp32():
+    """200 consecutive iterations, each from the oracle's state: every g / d / info loss within 1e-3 of the oracle's
+    (profiles/scripts/teacher_forced_curve.py runs the same function for 1000 iterations; its table is committed under profiles/)."""
+    dev = teacher_forced_curve(200)
+    assert dev.max() < 1e-3, (dev.max(axis=0), np.argmax(dev, axis=0))
+    assert np.median(dev[:, :2]) < 5e-5          # g / d losses are functions of the synchronised state alone
+
+
 def test_train_step_bf16_tracks_oracle():
     """bf16 MFMA inputs, fp32 accumulate/master weights: losses within 3e-2 of the fp32 oracle over 3 steps."""
     orc, G, D, tr, got, want = run_steps("bf16", 8, 3)
