@@ -3,14 +3,16 @@
 step, three Adams; celebA/EAD-GAN_celebA.py:299-401) at 64x64, batch 128 per GPU, bf16 MFMA compute with fp32 master
 weights, synthetic data, on N MI355X of one node (weak scaling, RCCL all-reduce of the gradient arenas).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline     : dominant kernel (by time) of the step, algorithmic FLOPs per launch / measured launch duration
-                 (HIP events on the launch stream, in this process) against the dense bf16 MFMA peak;
+                 (HIP events on the launch stream, in this process) against the dense bf16 MFMA peak; `algorithmic_bytes` per
+                 launch (inputs + weights + outputs once); `traffic` = HBM bytes per launch from the committed PMC passes
+                 (`traffic_source` names the file: a profile of this code, not a measurement of this run);
   cpu_baseline : the CPU oracle (oracle/celeba_oracle.py, a port pinned to the reference) timed on the host cores
-                 on a bounded sample of the same workload (rank 0, N=1 only).
+                 on a bounded sample of the same workload (rank 0, N=1 only): median of 5 iterations after 2 warm-ups.
 """
 import argparse
 import importlib
@@ -34,18 +36,19 @@ PEAK_F32_TFLOPS = 157.3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=128, help="images per GPU per step (BASELINE config: 128)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--force-dist", action="store_true", help="initialise a process group and run the all-reduce hooks even with one rank "
                                                               "(rehearses the N>1 code path, incl. RCCL capture into the hipGraph, on one GPU)")
-    ap.add_argument("--device-inputs", action="store_true", help="draw every batch on the device inside the captured step (uint8 dataset in HBM + "
-                    "counter-based z / code / labels): the timed iteration then includes the whole input pipeline")
+    ap.add_argument("--resident-inputs", action="store_true", help="CelebA: replay ONE pre-loaded batch instead of drawing every batch on the device "
+                    "inside the captured step (default: uint8 dataset in HBM + counter-based z / code / labels, i.e. the timed iteration includes "
+                    "the whole input pipeline and every step sees new inputs)")
     ap.add_argument("--sync-bn", action="store_true", help="data parallel: BatchNorm statistics over the global batch (dp.SyncBN); default per-rank")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no side lanes for weight-gradient chains / re-packing")
     ap.add_argument("--workload", default="celeba", choices=["celeba", "mnist", "dsprites", "colored", "pxy"],
@@ -63,29 +66,36 @@ def roofline_pass(eg, trainer, dtype, iters=3):
     # timed while another GEMM shares the GPU measures the sharing, not the kernel, so the side streams are folded into the main
     # stream here (same kernels, same arguments, same order inside every chain).  `--no-overlap` runs the whole bench that way:
     # profiles/ holds the rocprofv3 summaries of both commands; the per-kernel averages of the --no-overlap one agree with this table.
-    side, trainer.side = getattr(trainer, "side", None), None
-    # rank 0 runs this pass alone: no collectives inside it (the other ranks are not calling them)
-    allreduce, trainer.allreduce = getattr(trainer, "allreduce", None), None
+    # Rank 0 runs this pass alone: no collectives inside it (the other ranks are not calling them) -- gradient all-reduce AND
+    # synchronised BatchNorm are switched off for its duration.
+    saved = {k: getattr(trainer, k, None) for k in ("side", "allreduce", "sync_bn")}
+    for k in saved:
+        if hasattr(trainer, k):
+            setattr(trainer, k, None)
     ops.RECORDER = []
-    for _ in range(iters):
-        trainer._step_body()
-    torch.cuda.synchronize()
-    rec, ops.RECORDER = ops.RECORDER, None
-    trainer.side, trainer.allreduce = side, allreduce
+    try:
+        for _ in range(iters):
+            trainer._step_body()
+        torch.cuda.synchronize()
+    finally:
+        rec, ops.RECORDER = ops.RECORDER, None
+        for k, v in saved.items():
+            if hasattr(trainer, k):
+                setattr(trainer, k, v)
     table, detail = {}, {}
-    for label, flops, e0, e1, shape in rec:
+    for label, flops, e0, e1, shape, nbytes in rec:
         ms = e0.elapsed_time(e1)
-        t = table.setdefault(label, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        t = table.setdefault(label, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
         t["launches"] += 1
         t["ms"] += ms
         t["flops"] += flops
+        t["bytes"] += nbytes
         d = detail.setdefault((label, shape), [0, 0.0, flops])
         d[0] += 1
         d[1] += ms
     for t in table.values():
-        t["launches"] /= iters
-        t["ms"] /= iters
-        t["flops"] /= iters
+        for k in ("launches", "ms", "flops", "bytes"):
+            t[k] /= iters
     if os.environ.get("EG_BENCH_DETAIL"):
         for (label, shape), (n, ms, fl) in sorted(detail.items(), key=lambda kv: -kv[1][1]):
             print(f"# {label:34s} {shape:44s} x{n / iters:4.1f}  {ms / n * 1e3:8.1f} us/launch  {fl / (ms / n * 1e-3) / 1e12:7.1f} TF/s  total {ms / iters:6.3f} ms/iter", file=sys.stderr)
@@ -95,33 +105,55 @@ def roofline_pass(eg, trainer, dtype, iters=3):
     d = table[dom]
     peak = PEAK_F32_TFLOPS if dtype == "f32" else PEAK_BF16_TFLOPS        # f16 and bf16 MFMA run at the same rate
     achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-    traffic = None          # HBM bytes per launch from the committed PMC passes (profiles/r01_pmc_traffic.json), if this kernel is in them
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
-    except OSError:
-        pass
+    # HBM bytes per launch: NOT measured in this run -- read from the committed PMC passes of this code (rocprofv3 --pmc, FETCH_SIZE and
+    # WRITE_SIZE in separate passes, gfx950 corrections per the microarchitecture guide), if this kernel is in them
+    traffic = source = None
+    for name in ("r02_pmc_traffic.json",):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except OSError:
+            continue
+        if dom in pmc:
+            traffic, source = pmc[dom].get("hbm_bytes_per_launch"), "profiles/" + name
     roof = {"bound": "mfma", "kernel": dom, "mode": "single-stream eager pass", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(achieved / peak, 4), "traffic": traffic, "launches_per_step": round(d["launches"], 1),
+            "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": source,
+            "algorithmic_bytes": round(d["bytes"] / d["launches"]), "launches_per_step": round(d["launches"], 1),
             "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2), "gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3)}
     return roof, table
 
 
-def cpu_baseline(B, steps):
+def kernel_table(table):
+    return {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in table.items()}
+
+
+def capture_or_eager(tr, rank, **kw):
+    """hipGraph capture of the resident step (RCCL collectives included when world > 1); a capture that fails -- e.g. a collective that
+    refuses it -- leaves the trainer on eager launches, and the bench line says so in config.workload."""
+    try:
+        tr.capture(**kw)
+        return True
+    except Exception as exc:
+        print(f"[bench] hipGraph capture failed on rank {rank} ({type(exc).__name__}: {exc}); falling back to eager launches", file=sys.stderr)
+        tr.graph = None
+        torch.cuda.synchronize()
+        return False
+
+
+def cpu_baseline(B, steps, warm=2):
     from oracle import celeba_oracle as co          # the checker, timed as the reported CPU baseline
     torch.set_num_threads(min(16, os.cpu_count() or 1))   # the GPU box's CPU share for one GPU is 16 cores
     orc = co.CelebAOracle(seed=0)
     rng = np.random.RandomState(0)
     real = co.synthetic_real(B, seed=1)
     times = []
-    for i in range(steps + 1):
+    for i in range(steps + warm):
         z, code, labels = co.draw_step_inputs(rng, B)
         t0 = time.perf_counter()
         orc.train_step(real, z, code, labels)
         times.append(time.perf_counter() - t0)
-    t = float(np.median(times[1:]))
+    t = float(np.median(times[warm:]))
     return {"value": round(B / t, 2), "unit": "imgs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} timed iterations of the same workload (B={B}, fp32, torch-CPU oracle) after 1 warm-up; median"}
+            "sample": f"median of {steps} timed iterations of the same workload (B={B}, fp32, torch-CPU oracle) after {warm} warm-ups"}
 
 
 def main_mnist(a, eg, rank, world, local, dev):
@@ -138,9 +170,7 @@ def main_mnist(a, eg, rank, world, local, dev):
     tr.load_inputs(torch.rand((B, 1, 32, 32), device=dev, generator=g) * 2 - 1, torch.randn((B, 62), device=dev, generator=g),
                    torch.rand((B, 7), device=dev, generator=g) * 2 - 1, torch.randint(0, 10, (B,), device=dev, generator=g))
     tr.step_resident()
-    use_graph = (not a.no_graph) and world == 1
-    if use_graph:
-        tr.capture()
+    use_graph = (not a.no_graph) and capture_or_eager(tr, rank)
     for _ in range(max(a.warmup - 1, 0)):
         tr.step_resident()
     eg.dp.barrier()
@@ -151,6 +181,9 @@ def main_mnist(a, eg, rank, world, local, dev):
     torch.cuda.synchronize()
     eg.dp.barrier()
     dt = eg.dp.max_over_ranks(time.perf_counter() - t0, dev)
+    roof = table = None
+    if not a.no_roofline and rank == 0:
+        roof, table = roofline_pass(eg, tr, a.dtype)
     if rank == 0:
         ips = B * world * a.steps / dt
         peak = PEAK_F32_TFLOPS if a.dtype == "f32" else PEAK_BF16_TFLOPS
@@ -159,8 +192,9 @@ def main_mnist(a, eg, rank, world, local, dev):
                           "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                           "config": {"workload": f"EAD-GAN MNIST 32x32x1 full train iteration (G + D + info/affine over G+E), batch {B}/GPU, "
                                                  f"{'hipGraph replay' if use_graph else 'eager launches'}", "per_gpu_batch": B, "parallelism": f"dp{world}"},
-                          "whole_step_mfma_frac": round(ips / world * 1.403 / 1e3 / peak, 5), "roofline": None, "cpu_baseline": None,
-                          "final_losses": [round(x, 4) for x in tr.losses.tolist()[:3]]}), flush=True)
+                          "whole_step_mfma_frac": round(ips / world * 1.403 / 1e3 / peak, 5), "roofline": roof, "cpu_baseline": None,
+                          "final_losses": [round(x, 4) for x in tr.losses.tolist()[:3]],
+                          "kernel_table": kernel_table(table) if table else None}), flush=True)
 
 
 def main_sprites(a, eg, rank, world, local, dev):
@@ -184,9 +218,7 @@ def main_sprites(a, eg, rank, world, local, dev):
     else:
         tr.load_inputs(sprites, c1, l1, c2, l2)
     tr.step_resident()
-    use_graph = not a.no_graph
-    if use_graph:
-        tr.capture()
+    use_graph = (not a.no_graph) and capture_or_eager(tr, rank)
     for _ in range(max(a.warmup - 1, 0)):
         tr.step_resident()
     eg.dp.barrier()
@@ -197,6 +229,9 @@ def main_sprites(a, eg, rank, world, local, dev):
     torch.cuda.synchronize()
     eg.dp.barrier()
     dt = eg.dp.max_over_ranks(time.perf_counter() - t0, dev)
+    roof = table = None
+    if not a.no_roofline and rank == 0:
+        roof, table = roofline_pass(eg, tr, a.dtype)
     if rank == 0:
         ips = B * world * a.steps / dt
         peak = PEAK_F32_TFLOPS if a.dtype == "f32" else PEAK_BF16_TFLOPS
@@ -206,8 +241,9 @@ def main_sprites(a, eg, rank, world, local, dev):
                           "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                           "config": {"workload": f"EAD-GAN {'colored ' if color else ''}dSprites full train iteration (D step + joint info/affine/G step), batch {B}/GPU, "
                                                  f"{'hipGraph replay' if use_graph else 'eager launches'}", "per_gpu_batch": B, "parallelism": f"dp{world}"},
-                          "whole_step_mfma_frac": round(ips / world * gf / 1e3 / peak, 5), "roofline": None, "cpu_baseline": None,
-                          "final_losses": [round(x, 4) for x in tr.losses.tolist()[:5]]}), flush=True)
+                          "whole_step_mfma_frac": round(ips / world * gf / 1e3 / peak, 5), "roofline": roof, "cpu_baseline": None,
+                          "final_losses": [round(x, 4) for x in tr.losses.tolist()[:5]],
+                          "kernel_table": kernel_table(table) if table else None}), flush=True)
 
 
 def main_pxy(a, eg, rank, world, local, dev):
@@ -220,9 +256,7 @@ def main_pxy(a, eg, rank, world, local, dev):
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     tr.load_inputs(do.synthetic_sprites(B, seed=7 + rank).to(dev), torch.rand((B, 3), device=dev, generator=g) * 2 - 1)
     tr.step_resident()
-    use_graph = (not a.no_graph) and world == 1
-    if use_graph:
-        tr.capture()
+    use_graph = (not a.no_graph) and capture_or_eager(tr, rank)
     for _ in range(max(a.warmup - 1, 0)):
         tr.step_resident()
     eg.dp.barrier()
@@ -279,19 +313,11 @@ def main():
     tr.load_inputs(real, z, code, labels)
 
     inputs = None
-    if a.device_inputs:                                  # synthetic uint8 "dataset" resident in HBM (16k images = 197 MB)
+    if not a.resident_inputs:                            # synthetic uint8 "dataset" resident in HBM (16k images = 197 MB)
         inputs = eg.celeba.DeviceInputs(torch.randint(0, 256, (16384, 3, 64, 64), device=dev, dtype=torch.uint8, generator=g), seed=1000 + rank)
         tr.inputs = inputs
-    use_graph = not a.no_graph                           # RCCL collectives are captured into the same hipGraph
     tr.step_resident()                                   # first eager iteration: loads kernels, sizes workspaces (and RCCL channels)
-    if use_graph:
-        try:
-            tr.capture(inputs=inputs)
-        except Exception as exc:                         # e.g. a collective that refuses capture: keep going with eager launches
-            print(f"[bench] hipGraph capture failed on rank {rank} ({type(exc).__name__}: {exc}); falling back to eager launches", file=sys.stderr)
-            tr.graph = None
-            use_graph = False
-            torch.cuda.synchronize()
+    use_graph = (not a.no_graph) and capture_or_eager(tr, rank, inputs=inputs)     # RCCL collectives are captured into the same hipGraph
     for _ in range(max(a.warmup - 1, 0)):
         tr.step_resident()
     eg.dp.barrier()
@@ -319,7 +345,7 @@ def main():
             "metric": "imgs/sec per G+D+E train step, CelebA 64x64 bs=128",
             "value": round(ips, 1), "unit": "imgs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": a.dtype, "data": "synthetic" + (" (drawn on the device inside the timed step)" if a.device_inputs else ""),
+            "dtype": a.dtype, "data": "synthetic" + ("" if a.resident_inputs else " (every batch drawn on the device inside the timed step: uint8 gather + flip + normalise, Philox z / code / labels)"),
             "config": {"workload": f"EAD-GAN CelebA 64x64x3 full train iteration (G adv + D + info/affine, 3 Adams), batch {B}/GPU, "
                                    f"{'hipGraph replay' if use_graph else 'eager launches'}, data-parallel x{world}",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
@@ -328,8 +354,7 @@ def main():
             "final_losses": {"g": round(losses[0], 4), "d": round(losses[1], 4), "info": round(losses[2], 4)},
         }
         if table:
-            out["kernel_table"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                                       "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} for k, v in table.items()}
+            out["kernel_table"] = kernel_table(table)
         print(json.dumps(out), flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()

@@ -57,6 +57,7 @@ class Workspace:
 
     def __init__(self, device, splitk=True):
         self.device = device
+        self._retired = []
         self.slab = torch.empty(0, device=device, dtype=torch.float32)
         self.gtmp = torch.empty(0, device=device, dtype=torch.float32)
         self.small = torch.empty(0, device=device, dtype=torch.float32)
@@ -75,8 +76,12 @@ class Workspace:
         return cls._per_device[key]
 
     def _grow(self, name, floats):
+        """Workspaces only ever grow, and an outgrown buffer is kept alive: a hipGraph captured earlier (another trainer, another batch
+        size) has its address baked in, and memory handed back to the caching allocator would be given to somebody else."""
         t = getattr(self, name)
         if t.numel() < floats:
+            if t.numel():
+                self._retired.append(t)
             setattr(self, name, torch.empty(int(floats), device=self.device, dtype=torch.float32))
 
     def need_slab(self, nbytes):
@@ -93,11 +98,19 @@ class Workspace:
 
 
 class _Lane:
+    NAMES = ("slab", "gtmp", "small", "sums", "partials")
+
     def __init__(self, device, like: "Workspace"):
         self.stream = torch.cuda.Stream(device)
         self.ws = Workspace(device, splitk=False)
-        for name in ("slab", "gtmp", "small", "sums", "partials"):
-            setattr(self.ws, name, torch.empty_like(getattr(like, name)))
+        self.like = like
+        self.ensure()
+
+    def ensure(self):
+        """Lane scratch follows the device workspace: an engine built after the lanes (a second trainer, a larger batch) may have grown
+        it, and work forked onto this lane is sized by the device workspace's reservations."""
+        for name in self.NAMES:
+            self.ws._grow(name, getattr(self.like, name).numel())
 
     def __enter__(self):
         self._ctx = torch.cuda.stream(self.stream)
@@ -138,6 +151,7 @@ class SideStream:
 
     def fork(self, i: int = 0) -> _Lane:
         ln = self.lane(i)
+        ln.ensure()
         ev = torch.cuda.Event()
         ev.record()
         ln.stream.wait_event(ev)
@@ -176,6 +190,7 @@ class SideStream:
         try:
             while self._pending:
                 kind, ln, ev, fn = self._pending.pop(0)
+                ln.ensure()
                 ln.stream.wait_event(ev)
                 if kind == "opt":
                     for other in self.lanes:
@@ -188,6 +203,7 @@ class SideStream:
             self._flushing = False
 
     def fork_prep(self) -> _Lane:
+        self.prep.ensure()
         ev = torch.cuda.Event()
         ev.record()
         self.prep.stream.wait_event(ev)
@@ -195,6 +211,7 @@ class SideStream:
 
     def fork_opt(self) -> _Lane:
         """the optimizer lane waits for the current stream AND for everything the weight-gradient lanes hold so far"""
+        self.opt.ensure()
         ev = torch.cuda.Event()
         ev.record()
         self.opt.stream.wait_event(ev)

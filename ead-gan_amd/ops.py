@@ -113,12 +113,18 @@ def _out_hw(c):
 
 
 def _timed(kind, c, dtype, args, ep=None):
+    """RECORDER entry: (kernel label, algorithmic FLOPs, start event, end event, shape string, algorithmic bytes).  Algorithmic bytes =
+    every input element, weight and output element of the launch once, in its storage type (plus the activation-gradient mask the
+    epilogue reads): what the launch would move with perfect reuse."""
     oh, ow = _out_hw(c)
     M = c.B * oh * ow
     flops = 2.0 * M * c.Cout * c.Cin * c.k * c.k
+    es = 4 if dtype == EG_F32 else 2
+    x_elems, y_elems, w_elems = c.B * c.H * c.W * c.Cin, M * c.Cout, c.Cout * c.Cin * c.k * c.k
     tname = {EG_F32: "float", EG_BF16: "bf16", EG_F16: "f16"}[dtype]
     if kind == "tn":
         label = f"igemm_tn_kernel<{tname}>"
+        nbytes = (x_elems + y_elems) * es + w_elems * 4                     # activations + output gradients in, fp32 weight gradient out
     else:
         tile = lib().query("eg_igemm_nt_tile", ctypes.byref(c), dtype, int(kind == "bwd"), ep.nt_variant if ep is not None else 0,
                            (ep.nt_splitk if ep.splitk_ws else 1) if ep is not None else 1)
@@ -127,11 +133,14 @@ def _timed(kind, c, dtype, args, ep=None):
                  135: f"igemm_nt_pers_kernel<{tname}>",
                  147: f"igemm_nt8s_kernel<{tname},im2col>", 148: f"igemm_nt8s_kernel<{tname},im2col>+splitk",
                  149: f"igemm_nt8s_kernel<{tname},patch>", 150: f"igemm_nt8s_kernel<{tname},patch>+splitk"}.get(bn, f"igemm_nt_kernel<{tname},{bm},{bn}>")
+        nbytes = (x_elems + y_elems + w_elems) * es
+        if ep is not None and ep.mask:
+            nbytes += (x_elems if kind == "bwd" else y_elems) * es
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     lib().call(*args, _stream())
     e1.record()
-    RECORDER.append((label, flops, e0, e1, f"{kind} B{c.B} H{c.H} Cin{c.Cin} Cout{c.Cout} k{c.k} s{c.stride}"))
+    RECORDER.append((label, flops, e0, e1, f"{kind} B{c.B} H{c.H} Cin{c.Cin} Cout{c.Cout} k{c.k} s{c.stride}", float(nbytes)))
 
 
 def conv_fwd(c, dtype, X, wp, Y, ep=None):

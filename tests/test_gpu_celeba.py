@@ -312,6 +312,34 @@ def test_graph_replay_equals_eager():
     assert torch.equal(losses[0], losses[1]), (losses[0], losses[1])
 
 
+def test_workspace_growth_keeps_captured_graphs_valid():
+    """Workspaces are shared per device and grow when a larger engine is built.  A hipGraph captured before has the old addresses
+    baked in: the outgrown buffers must stay alive, and the side lanes of the new trainer must get scratch of the new size.
+    Trainer A (B=4) is captured, trainer B (B=16) is built and stepped (eager, with side lanes), then A's graph is replayed:
+    bit-identical to a second A that never saw B."""
+    def run_a(with_b):
+        orc, G, D = build_pair(9, "bf16")
+        tr = eg.celeba.CelebATrainer(G, D, 4, dtype="bf16")
+        rng = np.random.RandomState(2)
+        real = co.synthetic_real(4, seed=6).to(DEV)
+        z, code, labels = co.draw_step_inputs(rng, 4)
+        tr.load_inputs(real, z.to(DEV), code.to(DEV), labels.to(DEV))
+        tr.step_resident()
+        tr.capture()
+        out = [tr.step_resident().clone()]
+        if with_b:
+            orc2, G2, D2 = build_pair(10, "bf16")
+            trb = eg.celeba.CelebATrainer(G2, D2, 16, dtype="bf16")
+            zb, cb, lb = co.draw_step_inputs(rng, 16)
+            lossb = trb.train_step(co.synthetic_real(16, seed=8).to(DEV), zb.to(DEV), cb.to(DEV), lb.to(DEV))
+            assert all(np.isfinite(v) for v in lossb.values())
+        out.append(tr.step_resident().clone())
+        out.append(tr.step_resident().clone())
+        torch.cuda.synchronize()
+        return torch.stack(out).cpu()
+    assert torch.equal(run_a(False), run_a(True))
+
+
 def test_side_stream_overlap_is_bit_identical():
     """Weight-gradient chains and re-packing on the second stream (eager and captured) vs everything on one stream: the same
     kernels on the same operands in the same per-chain order -> identical losses and identical parameters after 3 steps."""
