@@ -1465,9 +1465,22 @@ static void tn_plan(const eg_conv* c, int* nsplit, int* rps) {
     *nsplit = cdiv(M, r);
 }
 
+bool eg_tn8_plan(const eg_conv* c, int dtype, Tn8Params& p, int* nsplit);
+template <typename T> void eg_launch_tn8(const Tn8Params& p, int nsplit, hipStream_t st);
+
+/* 2: the parity-class kernel igemm_tn8 runs this weight gradient, 1: the per-tap kernel igemm_tn (profiling labels and tests) */
+extern "C" int eg_conv_wgrad_variant(const eg_conv* c, int dtype) {
+    int ns;
+    Tn8Params p8;
+    if (!c || check_conv(c, dtype, NEED_CIN | NEED_COUT)) return -1;
+    return eg_tn8_plan(c, dtype, p8, &ns) ? 2 : 1;
+}
+
 extern "C" size_t eg_conv_wgrad_ws_bytes(const eg_conv* c, int dtype) {
-    (void)dtype;
     int ns, rps;
+    Tn8Params p8;
+    if (c && !check_conv(c, dtype, NEED_CIN | NEED_COUT) && eg_tn8_plan(c, dtype, p8, &ns))
+        return (size_t)ns * c->Cout * 16 * c->Cin * sizeof(float);
     tn_plan(c, &ns, &rps);
     return (size_t)ns * c->Cout * c->k * c->k * c->Cin * sizeof(float);
 }
@@ -1514,6 +1527,19 @@ extern "C" int eg_conv_wgrad(const eg_conv* c, int dtype, const void* X, const v
     if (int e = check_conv(c, dtype, NEED_CIN | NEED_COUT)) return e;
     EG_REQUIRE(X && dY && slab && nsplit_out, "eg_conv_wgrad: null pointer");
     const int OH = conv_out_dim(c, c->H), OW = conv_out_dim(c, c->W);
+    {
+        // 16-bit 4x4 / stride-2 layers with channel counts in multiples of 128: the parity-class kernel (igemm_tn8.hip), same slab layout
+        Tn8Params p8;
+        int ns8 = 0;
+        if (eg_tn8_plan(c, dtype, p8, &ns8)) {
+            p8.P = dY; p8.src = X; p8.slab = slab;
+            if (dtype == EG_F16) eg_launch_tn8<f16_t>(p8, ns8, (hipStream_t)s);
+            else eg_launch_tn8<bf16_t>(p8, ns8, (hipStream_t)s);
+            *nsplit_out = ns8;
+            EG_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     TnParams p;
     memset(&p, 0, sizeof(p));
     p.P = dY; p.src = X; p.slab = slab;

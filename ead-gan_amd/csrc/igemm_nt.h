@@ -54,6 +54,22 @@ struct Nt8pGeom {
 };
 #define EG_P8P_SLOTS 448
 
+// launch parameters of igemm_tn8_kernel (igemm_tn8.hip): weight gradients of the 4x4 / stride-2 layers, taps grouped by input parity
+struct Tn8Params {
+    const void* P;      // [M][N]
+    const void* src;    // [B,H,W,C]
+    float* slab;        // [nsplit][N][16][C]
+    int B, H, W, C, N;
+    int lOH, lOW, M;
+    int rows_per_split; // multiple of 64
+    int ntn, ntc;
+    int nimg, OHt, PH, PW, npix, npp;       // per 64-row K step: images, output rows per image, patch lattice, pixels, X pieces per wave
+    unsigned inv_pw, inv_plane;             // x / PW, x / (PH * PW) as (x * inv) >> 20 for x < 512
+};
+
+#define EG_TN8_XSLOTS 136                   // patch pixel slots per stage (34 pieces of 4 pixels x 256 B)
+
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline int bk_of(int dtype) { return dtype == EG_F32 ? 32 : 64; }
 static inline int vec_of(int dtype) { return dtype == EG_F32 ? 4 : 8; }

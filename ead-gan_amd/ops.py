@@ -123,7 +123,7 @@ def _timed(kind, c, dtype, args, ep=None):
     x_elems, y_elems, w_elems = c.B * c.H * c.W * c.Cin, M * c.Cout, c.Cout * c.Cin * c.k * c.k
     tname = {EG_F32: "float", EG_BF16: "bf16", EG_F16: "f16"}[dtype]
     if kind == "tn":
-        label = f"igemm_tn_kernel<{tname}>"
+        label = f"igemm_tn8_kernel<{tname}>" if lib().query("eg_conv_wgrad_variant", ctypes.byref(c), dtype) == 2 else f"igemm_tn_kernel<{tname}>"
         nbytes = (x_elems + y_elems) * es + w_elems * 4                     # activations + output gradients in, fp32 weight gradient out
     else:
         tile = lib().query("eg_igemm_nt_tile", ctypes.byref(c), dtype, int(kind == "bwd"), ep.nt_variant if ep is not None else 0,

@@ -99,7 +99,10 @@ int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, const void* wp
 int eg_igemm_nt_tile(const eg_conv* c, int dtype, int bwd, int variant, int splitk);
 /* bytes of eg_epilogue.splitk_ws that let eg_conv_fwd (bwd = 0) / eg_conv_bwd_data (bwd = 1) split as far as the policy wants */
 size_t eg_conv_splitk_ws_bytes(const eg_conv* c, int dtype, int bwd);
-/* dW partial slabs: slab[split][Cout][k*k][Cin] fp32.  Returns the split count through *nsplit. */
+/* dW partial slabs: slab[split][Cout][k*k][Cin] fp32.  Returns the split count through *nsplit.  16-bit 4x4 / stride-2 / pad-1 layers
+ * whose channel counts are multiples of 128 run on the parity-class kernel (igemm_tn8.hip: the four taps of an input-parity class share
+ * one input patch and one tile of dY per K step), everything else on the per-tap kernel; eg_conv_wgrad_variant tells which (2 / 1). */
+int eg_conv_wgrad_variant(const eg_conv* c, int dtype);
 size_t eg_conv_wgrad_ws_bytes(const eg_conv* c, int dtype);
 int eg_conv_wgrad(const eg_conv* c, int dtype, const void* X, const void* dY, float* slab, int* nsplit,
                   eg_stream_t s);

@@ -140,6 +140,45 @@ def test_conv_wgrad(case, dtype):
     torch.testing.assert_close(grad2.cpu(), want, rtol=rt * 2, atol=at * 8)
 
 
+# B, H (input), Cin, Cout: 4x4 / stride-2 / pad-1 layers with channel counts in multiples of 128 -> the parity-class weight-gradient
+# kernel (igemm_tn8.hip).  Output lattices 16x16 (bands of 4 rows per K step), 8x8 (one image per step), 4x4 (four images per step),
+# 32x32 (2 rows per step), 2x2 (16 images per step); several splits over m; both channel tilings > 1
+TN8_CASES = [(8, 32, 128, 256), (12, 16, 256, 128), (16, 8, 128, 128), (4, 64, 128, 128), (64, 4, 256, 256), (5 * 4, 16, 128, 128)]
+
+
+@pytest.mark.parametrize("dtype", [1, 2])
+@pytest.mark.parametrize("case", TN8_CASES)
+def test_conv_wgrad_parity_class_kernel(case, dtype):
+    """igemm_tn8: every tap of every parity class lands in the right slab row with the right border handling -- compared with the
+    autograd weight gradient of the same 16-bit-rounded operands, per tap."""
+    B, H, Cin, Cout = case
+    g = torch.Generator().manual_seed(31)
+    x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
+    w = (torch.randn(Cout, Cin, 4, 4, generator=g) * 0.1).requires_grad_(True)
+    y = F.conv2d(x, w, None, 2, 1)
+    dy = rq(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    c = ops.make_conv(B, H, H, Cin, Cout, 4, 2, 1)
+    import ctypes
+    assert eg._lib.lib().query("eg_conv_wgrad_variant", ctypes.byref(c), dtype) == 2
+    nbytes = ops.conv_wgrad_ws_bytes(c, dtype)
+    slab = torch.full((nbytes // 4,), float("nan"), device=DEV)
+    ns = ops.conv_wgrad(c, dtype, nhwc(x, dtype), nhwc(dy, dtype), slab)
+    assert nbytes == ns * Cout * 16 * Cin * 4
+    grad = torch.zeros(Cout, Cin, 4, 4, device=DEV)
+    ops.wgrad_reduce(slab, ns, Cout, Cout, Cin, 16, grad, accumulate=True)
+    torch.cuda.synchronize()
+    rt, at = tol(dtype, B * y.shape[-1] ** 2)
+    got, want = grad.cpu(), w.grad
+    for t in range(16):
+        torch.testing.assert_close(got[:, :, t // 4, t % 4], want[:, :, t // 4, t % 4], rtol=rt, atol=at * 4, msg=lambda m, t=t: f"tap {t}: {m}")
+    # deterministic: no atomics, fixed reduction order
+    slab2 = torch.zeros_like(slab)
+    ops.conv_wgrad(c, dtype, nhwc(x, dtype), nhwc(dy, dtype), slab2)
+    torch.cuda.synchronize()
+    assert torch.equal(slab, slab2)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 8, 64, 1e-5, 2), (3, 16, 24, 0.8, 1), (4, 4, 128, 1e-5, 0)])
 def test_batchnorm(shape, dtype):
