@@ -50,6 +50,7 @@ def parse():
                     "inside the captured step (default: uint8 dataset in HBM + counter-based z / code / labels, i.e. the timed iteration includes "
                     "the whole input pipeline and every step sees new inputs)")
     ap.add_argument("--sync-bn", action="store_true", help="data parallel: BatchNorm statistics over the global batch (dp.SyncBN); default per-rank")
+    ap.add_argument("--wire", default="f32", choices=["f32", "bf16"], help="data parallel: element type of the gradient buckets on the links")
     ap.add_argument("--no-overlap", action="store_true", help="single stream: no side lanes for weight-gradient chains / re-packing")
     ap.add_argument("--workload", default="celeba", choices=["celeba", "mnist", "dsprites", "colored", "pxy"],
                     help="celeba = the headline metric (default); mnist = BASELINE config[1] (use --batch 256 --dtype f32); "
@@ -165,7 +166,8 @@ def main_mnist(a, eg, rank, world, local, dev):
     G, D, E = eg.mnist.Generator(dtype=a.dtype).to(dev), eg.mnist.Discriminator(dtype=a.dtype).to(dev), eg.mnist.Encoder(dtype=a.dtype).to(dev)
     for m in (G, D, E):
         m.apply(eg.mnist.weights_init_normal)
-    tr = eg.mnist.MnistTrainer(G, D, E, B, dtype=a.dtype, allreduce=eg.dp.GradAllReduce(world) if world > 1 else None)
+    tr = eg.mnist.MnistTrainer(G, D, E, B, dtype=a.dtype, allreduce=eg.dp.GradAllReduce(world, wire=a.wire) if world > 1 else None,
+                               sync_bn=eg.dp.SyncBN(world, rank) if (a.sync_bn and world > 1) else None)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     tr.load_inputs(torch.rand((B, 1, 32, 32), device=dev, generator=g) * 2 - 1, torch.randn((B, 62), device=dev, generator=g),
                    torch.rand((B, 7), device=dev, generator=g) * 2 - 1, torch.randint(0, 10, (B,), device=dev, generator=g))
@@ -205,8 +207,9 @@ def main_sprites(a, eg, rank, world, local, dev):
     torch.manual_seed(0)
     P, G, D, E = mod.Encoder_pxy(dtype=a.dtype).to(dev), mod.Generator(dtype=a.dtype).to(dev), mod.Discriminator(dtype=a.dtype).to(dev), mod.Encoder(dtype=a.dtype).to(dev)
     P.load_state_dict(do.make_encoder_pxy(654 if color else 321, ch=3 if color else 1, pxy_out=6 if color else 3))
-    ar = eg.dp.GradAllReduce(world) if world > 1 else None
-    tr = (mod.ColoredTrainer if color else mod.DspritesTrainer)(P, G, D, E, B, dtype=a.dtype, allreduce=ar)
+    ar = eg.dp.GradAllReduce(world, wire=a.wire) if world > 1 else None
+    tr = (mod.ColoredTrainer if color else mod.DspritesTrainer)(P, G, D, E, B, dtype=a.dtype, allreduce=ar,
+                                                                 sync_bn=eg.dp.SyncBN(world, rank) if (a.sync_bn and world > 1) else None)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     sprites = do.synthetic_sprites(B, seed=7 + rank).to(dev)
     cd = 7 if color else 4
@@ -252,7 +255,7 @@ def main_pxy(a, eg, rank, world, local, dev):
     B = a.batch
     torch.manual_seed(0)
     P = eg.dsprites.Encoder_pxy(dtype=a.dtype).to(dev)
-    tr = eg.dsprites.PxyTrainer(P, B, dtype=a.dtype, allreduce=eg.dp.GradAllReduce(world) if world > 1 else None)
+    tr = eg.dsprites.PxyTrainer(P, B, dtype=a.dtype, allreduce=eg.dp.GradAllReduce(world, wire=a.wire) if world > 1 else None)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     tr.load_inputs(do.synthetic_sprites(B, seed=7 + rank).to(dev), torch.rand((B, 3), device=dev, generator=g) * 2 - 1)
     tr.step_resident()
@@ -300,7 +303,7 @@ def main():
     torch.manual_seed(0)                                 # identical replicas on every rank
     G = eg.celeba.Generator(dtype=a.dtype).to(dev)
     D = eg.celeba.Discriminator(dtype=a.dtype).to(dev)
-    allreduce = eg.dp.GradAllReduce(world, force=a.force_dist) if (world > 1 or a.force_dist) else None
+    allreduce = eg.dp.GradAllReduce(world, force=a.force_dist, wire=a.wire) if (world > 1 or a.force_dist) else None
     sync = eg.dp.SyncBN(world, rank) if (a.sync_bn and world > 1) else None
     tr = eg.celeba.CelebATrainer(G, D, B, dtype=a.dtype, allreduce=allreduce, overlap=not a.no_overlap, sync_bn=sync)
 

@@ -101,6 +101,13 @@ class _GenEngine:
     def _p(self, idx, kind):
         return getattr(self.gen.conv_blocks[idx], kind)
 
+    # gradient buckets in the order the backward pass completes them: (tag of the lane chain that writes it last, parameter names)
+    BUCKETS = (("G4", ("conv_blocks.10.weight", "conv_blocks.10.bias")),
+               ("G3", ("conv_blocks.7.weight", "conv_blocks.7.bias", "conv_blocks.8.weight", "conv_blocks.8.bias")),
+               ("G2", ("conv_blocks.4.weight", "conv_blocks.4.bias", "conv_blocks.5.weight", "conv_blocks.5.bias")),
+               ("G1", ("conv_blocks.1.weight", "conv_blocks.1.bias", "conv_blocks.2.weight", "conv_blocks.2.bias")),
+               ("G0", ("conv_blocks.0.weight", "conv_blocks.0.bias")))
+
     def repack(self):
         g, dt = self.gen, self.dtype
         w0 = self._p(0, "weight")                                      # [cin][1024][4][4]
@@ -150,11 +157,11 @@ class _GenEngine:
         dt, B, W, ws, gen = self.dtype, self.B, G_WIDTHS, self.ws, self.gen
         gof = lambda name: gen.arena.grad_of(name, grad)
         C, S = gen.channels, self.img.shape[-1]
-        def wgrad_side(fn, lane):                       # issued by the flush() that follows the next main-stream kernel (engine.SideStream)
+        def wgrad_side(fn, lane, tag=None):             # issued by the flush() that follows the next main-stream kernel (engine.SideStream)
             if side is None:
                 fn(ws)
             else:
-                side.defer(lane, fn)
+                side.defer(lane, fn, tag)
         flush = side.flush if side is not None else (lambda: None)
 
         # tanh backward fused with the bias gradient of the last ConvTranspose2d
@@ -165,7 +172,7 @@ class _GenEngine:
         def l4_wgrad(wsw):
             ns = ops.conv_wgrad(self.l4p.c, dt, self.patches, self.a[2], wsw.slab)
             ops.wgrad_reduce(wsw.slab, ns, W[3], W[3], self.kp, 1, gof("conv_blocks.10.weight"))
-        wgrad_side(l4_wgrad, 0)
+        wgrad_side(l4_wgrad, 0, "G4")
         ops.conv_fwd(self.l4p.c, dt, self.patches, self.l4p.wp_fwd, self.da[2], None)
         flush()
         # L3..L1
@@ -188,7 +195,7 @@ class _GenEngine:
                 ns = ops.conv_wgrad(r.c, dt, self.dz[i], x_in, wsw.slab)
                 ops.wgrad_reduce(wsw.slab, ns, r.Cout, r.Cout, r.Cin, 16, gof(f"conv_blocks.{idx}.weight"))
                 ops.bias_grad(dt, self.dz[i], M, W[i + 1], wsw.small, gof(f"conv_blocks.{idx}.bias"))
-            wgrad_side(mid_wgrad, i + 1)
+            wgrad_side(mid_wgrad, i + 1, f"G{i + 1}")
             ops.conv_fwd(r.c, dt, self.dz[i], r.wp_fwd, self.da[i - 1] if i > 0 else self.dh0, None)
             flush()
 
@@ -197,7 +204,7 @@ class _GenEngine:
             ns = ops.conv_wgrad(self.l0w.c, dt, self.dh0, self.inp, wsw.slab)
             ops.wgrad_reduce(wsw.slab, ns, self.cpad, self.cin, W[0], 16, gof("conv_blocks.0.weight"))
             ops.bias_grad(dt, self.dh0, B * 16, W[0], wsw.small, gof("conv_blocks.0.bias"))
-        wgrad_side(l0_wgrad, 0)                         # stays pending: the caller's next main-stream kernel goes first
+        wgrad_side(l0_wgrad, 0, "G0")                   # stays pending: the caller's next main-stream kernel goes first
 
 
 class _HipModule(nn.Module):
@@ -316,6 +323,9 @@ class _DiscEngine:
     (<G_t,W>/sigma_t^2 = sum dzs_t * (z_t - bias)), never from a second sweep over the weights."""
 
     NT = 3     # the info step runs three forwards before one backward (celebA/EAD-GAN_celebA.py:380-388)
+    # gradient buckets in the order the backward pass completes them (see _GenEngine.BUCKETS)
+    BUCKETS = (("D4", ("main.8.weight", "main.8.bias")), ("D3", ("main.6.bias", "main.6.weight_orig")), ("D2", ("main.4.bias", "main.4.weight_orig")),
+               ("D1", ("main.2.bias", "main.2.weight_orig")), ("D0", ("main.0.bias", "main.0.weight_orig")))
 
     def __init__(self, disc: "Discriminator", B: int, dtype: int):
         self.disc, self.B, self.dtype = disc, B, dtype
@@ -445,11 +455,11 @@ class _DiscEngine:
         g = self.geo[T]
         sl = lambda buf: buf[t0 * (buf.shape[0] // self.NT):]
         K = 16 * W[3]
-        def wgrad_side(fn, lane):                       # issued by the flush() that follows the next main-stream kernel (engine.SideStream)
+        def wgrad_side(fn, lane, tag=None):             # issued by the flush() that follows the next main-stream kernel (engine.SideStream)
             if side is None:
                 fn(ws)
             else:
-                side.defer(lane, fn)
+                side.defer(lane, fn, tag)
         flush = side.flush if side is not None else (lambda: None)
 
         if need_wgrad:
@@ -458,7 +468,7 @@ class _DiscEngine:
                 ns = ops.conv_wgrad(g["headw"], dt, sl(self.a[3]), self.dout_t, wsw.slab)
                 ops.wgrad_reduce(wsw.slab, ns, 32, self.nout, W[3], 16, gof("main.8.weight"))
                 ops.dense_small_bgrad(dout, gof("main.8.bias"), T * B, self.nout)
-            wgrad_side(head_wgrad, 0)
+            wgrad_side(head_wgrad, 0, "D4")
         # dzs_3 = (W5^T dout) * lrelu'(a3) / sigma_3[tape]
         ops.dense_small_bwd(dt, dout, self.head.wp_fwd, sl(self.a[3]), sl(self.dz[3]), T * B, K, self.head.Kpad_fwd, self.nout, ACT_LRELU, LRELU_SLOPE,
                             self.sigma[3][t0:], B)
@@ -475,7 +485,7 @@ class _DiscEngine:
                     taps = 16 if i > 0 else 1
                     ops.wgrad_reduce_rank1(wsw.slab, ns, W[i], W[i], self.cin[i], taps, gof(f"main.{2 * i}.weight_orig"), T, self.coef[i],
                                            self.u[i][t0:], self.v[i][t0:])
-                wgrad_side(layer_wgrad, i + 1)
+                wgrad_side(layer_wgrad, i + 1, f"D{i}")
             if i > 0:
                 # dzs_{i-1} = conv^T(dzs_i, W_i) * lrelu'(a_{i-1}) / sigma_{i-1}[tape]
                 ops.conv_bwd_data(geo, dt, sl(self.dz[i]), self.mid[i - 1].wp_bwd, sl(self.dz[i - 1]),
@@ -707,6 +717,19 @@ class CelebATrainer:
         self.side = SideStream(dev, Workspace.get(dev), lanes=int(os.environ.get("EG_LANES", "4"))) if overlap else None
 
     # -- the hot path ---------------------------------------------------------------------------------
+    def _buckets(self, arena):
+        """(tag, lo, hi) element ranges of `arena` per layer bucket, in completion order; the ranges tile the arena"""
+        eng = self.ge if arena is self.G.arena else self.de
+        out, covered = [], 0
+        for tag, names in eng.BUCKETS:
+            offs = [arena.slices[n] for n in names]
+            lo, hi = min(o for o, _ in offs), max(o + k for o, k in offs)
+            assert sum(k for _, k in offs) == hi - lo, (tag, "bucket parameters are not contiguous in the arena")
+            out.append((tag, lo, hi))
+            covered += hi - lo
+        assert covered == arena.numel, "buckets do not tile the arena"
+        return out
+
     def _adam(self, arena, m, v, lr, slot, tick):
         ops.adam_step(arena.flat, arena.grad, m, v, arena.numel, lr, self.betas[0], self.betas[1], 1e-8, self.steps[slot:slot + 1], tick)
 
@@ -799,16 +822,22 @@ class CelebATrainer:
             main stream, once the weight-gradient lanes are done (RCCL's stream must only ever wait for the capture's origin stream: a
             lane that RCCL waited for and that later waits for RCCL is the stream-level back edge hipStreamEndCapture crashes on), and
             FINISHED on the optimizer lane, so the main stream waits neither for the collective nor for Adam / re-packing."""
-            h = None
+            hs = []
             if ar is not None:
-                side.join_lanes()
-                if ar_async:
-                    h = ar.start(arena.grad)
-                else:
-                    ar(arena.grad)
+                # one collective per layer bucket, started (from the main stream) as soon as the lane chain that completes the bucket has
+                # fired its event, in the order the backward pass finishes them: the first buckets are on the wire while the last
+                # weight-gradient chains still run, and the main stream only ever waits for ONE chain at a time
+                side.flush()
+                for tag, lo, hi in self._buckets(arena):
+                    side.wait(side.done.pop(tag))       # KeyError: a bucket whose chain was never forked
+                    if ar_async:
+                        hs.append(ar.start(arena.grad[lo:hi]))
+                    else:
+                        ar(arena.grad[lo:hi])
+                side.join_lanes()                      # chains without a tag (none today) and lanes this pass did not use
 
             def fn(_ws):
-                if h is not None:
+                for h in hs:
                     ar.finish(h)
                 self._adam(arena, m, v, lr, slot, tick)
                 if key_w:

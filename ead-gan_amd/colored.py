@@ -74,8 +74,9 @@ def affine_color_regularzier(real_code, trans_code):
 class ColoredTrainer(ds.DspritesTrainer):
     """One call == one iteration of colored_dSprites/rp_color.py:365-516 (both Adams lr 2e-4, :274-280)."""
 
-    def __init__(self, encoder_pxy, generator, discriminator, encoder, batch_size, dtype="f32", allreduce=None, lrs=(2e-4, 2e-4), betas=(0.5, 0.999)):
-        super().__init__(encoder_pxy, generator, discriminator, encoder, batch_size, dtype, allreduce, lrs, betas)
+    def __init__(self, encoder_pxy, generator, discriminator, encoder, batch_size, dtype="f32", allreduce=None, lrs=(2e-4, 2e-4), betas=(0.5, 0.999),
+                 sync_bn=None):
+        super().__init__(encoder_pxy, generator, discriminator, encoder, batch_size, dtype, allreduce, lrs, betas, sync_bn)
         dev = self.img.device
         self.tmp = torch.zeros_like(self.img)
         self.gains = torch.zeros(batch_size, 3, device=dev)

@@ -32,39 +32,61 @@ def init_from_env(backend: str | None = None):
 
 
 class GradAllReduce:
-    """callable(flat_grad): in-place mean over ranks.  One collective per arena per backward pass (the arenas are
-    58 MB / 45 MB fp32 on CelebA: large, few messages -- what per-link-bound xGMI rings want)."""
+    """callable(flat_grad): in-place mean over ranks.  The CelebA trainer hands it one bucket per layer group as soon as the group's
+    weight gradients are complete (celeba.py BUCKETS: 5 buckets of 0.2-33 MB per network), the small-network trainers one arena per
+    backward pass -- few, large messages, what per-link-bound xGMI rings want.
 
-    def __init__(self, world: int, group=None, force: bool = False):
-        self.world, self.group, self.force = world, group, force
+    ``wire="bf16"``: the bucket crosses the links as bf16 (half the bytes; the mean is taken on the bf16 values, the result is
+    widened back into the fp32 arena).  Changes the gradients by bf16 rounding (rel. 2^-9 per element): off by default, meant
+    for the 16-bit compute modes whose gradients carry that rounding already."""
+
+    def __init__(self, world: int, group=None, force: bool = False, wire: str = "f32"):
+        assert wire in ("f32", "bf16"), wire
+        self.world, self.group, self.force, self.wire = world, group, force, wire
         self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        self._stage = {}
+
+    def _staged(self, flat):
+        key = (flat.data_ptr(), flat.numel())
+        st = self._stage.get(key)
+        if st is None:
+            st = self._stage[key] = torch.empty(flat.numel(), device=flat.device, dtype=torch.bfloat16)
+        st.copy_(flat)
+        return st
+
+    def _launch(self, buf, async_op):
+        if self.backend == "nccl":
+            return dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+        return dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+
+    def _settle(self, flat, buf):
+        """after the collective: scale the SUM of the backends without AVG, widen the bf16 wire buffer back"""
+        if buf is not flat:
+            flat.copy_(buf)
+        if self.backend != "nccl":
+            flat.mul_(1.0 / self.world)
 
     def __call__(self, flat: torch.Tensor):
         if self.world <= 1 and not self.force:
             return
-        if self.backend == "nccl":
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
-        else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            flat.mul_(1.0 / self.world)
-
+        buf = self._staged(flat) if self.wire == "bf16" else flat
+        self._launch(buf, False)
+        self._settle(flat, buf)
 
     # asynchronous form: the collective runs on RCCL's own stream; compute enqueued after start() overlaps with it and
     # finish() makes the compute stream wait (works eagerly and under hipGraph capture: the dependency is an event edge)
     def start(self, flat: torch.Tensor):
         if self.world <= 1 and not self.force:
             return None
-        if self.backend == "nccl":
-            return (dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None)
-        return (dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat)
+        buf = self._staged(flat) if self.wire == "bf16" else flat
+        return (self._launch(buf, True), flat, buf)
 
     def finish(self, handle):
         if handle is None:
             return
-        work, flat = handle
+        work, flat, buf = handle
         work.wait()
-        if flat is not None:
-            flat.mul_(1.0 / self.world)
+        self._settle(flat, buf)
 
 
 class SyncBN:

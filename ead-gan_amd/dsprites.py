@@ -14,7 +14,7 @@ from torch.nn.utils import spectral_norm
 
 from . import ops
 from .celeba import IMG_GEMM, _HipModule, _require_cuda, transformation_2D      # noqa: F401
-from .engine import Arena, ConvRec, Workspace, capture_step, parse_dtype
+from .engine import Arena, ConvRec, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step, parse_dtype
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, EG_F32, OUT_NCHW_F32
 from .trunk import Head, TrunkEngine
 
@@ -216,6 +216,7 @@ class _GenEngine:
         self.a = [torch.empty_like(t) for t in self.z]
         self.mean = [f(64) for _ in range(3)]
         self.invstd = [f(64) for _ in range(3)]
+        self.sync_scratch = SyncScratch((64, 64, 64), dev)
         self.img = f(B, self.CH, 64, 64)
         self.dimg_z = torch.empty_like(self.img)
         self.patches = torch.zeros(B * 32 * 32, self.kp, device=dev, dtype=tdt)
@@ -246,8 +247,9 @@ class _GenEngine:
         ops.pack_strided(dt, cb[9].weight, self.l4p.wp_fwd, 64, self.k0, self.l4p.Kpad_fwd, 1, self.k0, 0, 1)
         ops.pack_strided(dt, cb[9].weight, self.l4g.wp_fwd, self.k0, 64, self.l4g.Kpad_fwd, self.CH, 1, 16, self.k0)     # wp[t*C + c][ci] = W[ci][c][t]
 
-    def forward(self, labels, code, training=True):
-        """z_c = cat(one-hot labels, code)  (rp.py:404-405).  ``training=False``: running-stat BatchNorm (module.eval())."""
+    def forward(self, labels, code, training=True, sync=None):
+        """z_c = cat(one-hot labels, code)  (rp.py:404-405).  ``training=False``: running-stat BatchNorm (module.eval()).  ``sync`` (a
+        dp.SyncBN): batch statistics over all ranks."""
         dt, B, g, ws = self.dtype, self.B, self.gen, self.ws
         cb = g.conv_block
         ops.concat_cast(dt, labels, code, None, self.inp, B, self.cpad)
@@ -259,8 +261,8 @@ class _GenEngine:
             ops.conv_bwd_data(r.c, dt, x, r.wp_bwd, self.z[i], ops.epilogue(bias=cb[idx].bias))
             bn = cb[idx + 1]
             if training:
-                ops.bn_fwd_train(dt, self.z[i], self.a[i], B * (8 << i) ** 2, 64, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
-                                 bn.num_batches_tracked, self.mean[i], self.invstd[i], ws.small, ACT_RELU)
+                bn_train_forward(dt, self.z[i], self.a[i], B * (8 << i) ** 2, 64, bn, self.mean[i], self.invstd[i], ws.small, ACT_RELU, 0.0, sync,
+                                 self.sync_scratch.stats[i])
             else:
                 ops.bn_fwd_eval(dt, self.z[i], self.a[i], B * (8 << i) ** 2, 64, bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, ws.small, ACT_RELU)
             x = self.a[i]
@@ -271,7 +273,7 @@ class _GenEngine:
             ops.conv_bwd_data(self.l4.c, dt, x, self.l4.wp_bwd, self.img, ops.epilogue(bias=cb[9].bias, act=ACT_SIGMOID, out_mode=OUT_NCHW_F32))
         return self.img
 
-    def backward(self, dimg, grad):
+    def backward(self, dimg, grad, sync=None):
         dt, B, g, ws = self.dtype, self.B, self.gen, self.ws
         cb = g.conv_block
         gof = lambda name: g.arena.grad_of(name, grad)
@@ -284,8 +286,8 @@ class _GenEngine:
             r = self.mid[i]
             bn = cb[idx + 1]
             M = B * (8 << i) ** 2
-            ops.bn_bwd(dt, self.z[i], self.da[i], self.dz[i], M, 64, bn.weight, bn.bias, self.mean[i], self.invstd[i], ACT_RELU, 0.0,
-                       gof(f"conv_block.{idx + 1}.weight"), gof(f"conv_block.{idx + 1}.bias"), ws.sums, ws.small)
+            bn_train_backward(dt, self.z[i], self.da[i], self.dz[i], M, 64, bn, self.mean[i], self.invstd[i], ACT_RELU, 0.0,
+                              gof(f"conv_block.{idx + 1}.weight"), gof(f"conv_block.{idx + 1}.bias"), ws, sync, self.sync_scratch.sums[i])
             x_in = self.a[i - 1] if i > 0 else self.h
             ns = ops.conv_wgrad(r.c, dt, self.dz[i], x_in, ws.slab)
             ops.wgrad_reduce(ws.slab, ns, 64, 64, 64, 16, gof(f"conv_block.{idx}.weight"))
@@ -568,8 +570,11 @@ class DspritesTrainer:
     relative-category step over G+E (Adam lr 1e-4).  optimizer_G of the reference is never stepped and is not created.
     Dead work removed: Encoder_pxy backward, the second (identical) alignment pass, D weight gradients in the joint step."""
 
-    def __init__(self, encoder_pxy, generator, discriminator, encoder, batch_size, dtype="f32", allreduce=None, lrs=(2e-4, 1e-4), betas=(0.5, 0.999)):
+    def __init__(self, encoder_pxy, generator, discriminator, encoder, batch_size, dtype="f32", allreduce=None, lrs=(2e-4, 1e-4), betas=(0.5, 0.999),
+                 sync_bn=None):
+        """``sync_bn`` (a dp.SyncBN): the generator's three BatchNorm layers use the statistics of the global batch."""
         self.P, self.G, self.D, self.E, self.B = encoder_pxy, generator, discriminator, encoder, batch_size
+        self.sync_bn = sync_bn
         dt = parse_dtype(dtype)
         for m in (encoder_pxy, generator, discriminator, encoder):
             m.set_compute_dtype(dt)
@@ -608,7 +613,7 @@ class DspritesTrainer:
         self._align()                                                                        # :374-377
         self._transform(self.code1, self.trans1)                                             # :396-400
         # ---- D step (:404-419): D(trans) then D(gen.detach()) ----
-        gen = ge.forward(self.onehot1, self.code1)
+        gen = ge.forward(self.onehot1, self.code1, sync=self.sync_bn)
         ops.fill_f32(da.grad)
         out = de.forward([self.trans1, gen])["fc2"]
         ops.loss_bce_sigmoid(out[:B], 1, 0, B, 1.0, 0.5, L[0:1], self.dout_d[:B])
@@ -621,7 +626,7 @@ class DspritesTrainer:
         # ---- joint step (:424-482) ----
         ops.fill_f32(ga.grad)
         ops.fill_f32(ea.grad)
-        gen = ge.forward(self.onehot2, self.code2)
+        gen = ge.forward(self.onehot2, self.code2, sync=self.sync_bn)
         self._transform(self.code2, self.trans2)
         eo = ee.forward([gen, self.align, self.trans2])
         cat, cont = eo["cat_layer.0"], eo["cont_layer.0"]
@@ -636,7 +641,7 @@ class DspritesTrainer:
         dimg_e = ee.backward(0, 3, {"cat_layer.0": self.d_cat, "cont_layer.0": self.d_cont}, ea.grad, need_dimg=True)
         ops.add_f32(self.dimg, dimg_e, dimg_d)
         pending = self.allreduce.start(ea.grad) if (self.allreduce is not None and hasattr(self.allreduce, "start")) else None
-        ge.backward(self.dimg, ga.grad)
+        ge.backward(self.dimg, ga.grad, sync=self.sync_bn)
         if self.allreduce is not None:
             self.allreduce(ga.grad)
             if pending is not None:

@@ -140,6 +140,7 @@ class SideStream:
         # holds for longer cycles: the waits among the non-origin streams must form a DAG (profiles/r01_timeline_notes.md item 10).
         self.prep = _Lane(device, like)
         self._pending = []
+        self.done = {}                                 # tag -> event behind a tagged lane chain (defer(..., tag=))
         self._flushing = False
         # issue order of forked work (see defer()): "0" at once (side work captured before the main stream's next kernel), "1" always
         # after it, "once" at once for a lane's first fork of the step and after it from then on
@@ -161,18 +162,20 @@ class SideStream:
     # another queue behind a cross-queue wait (10-18 us on MI355X, measured: profiles/r01_timeline_notes.md).  A fork therefore records
     # its event at once but its launches are issued by the next flush(), which the caller places right AFTER the next main-stream
     # kernel: the critical chain stays on one queue and the hop lands on the side work.  Dependencies are unchanged (the events).
-    def defer(self, i: int, fn):
-        """lane i runs fn(lane_workspace) behind everything enqueued on the current stream so far"""
-        self._pending.append(("lane", self.lane(i), self.mark(), fn))
+    def defer(self, i: int, fn, tag=None):
+        """lane i runs fn(lane_workspace) behind everything enqueued on the current stream so far.  ``tag``: an event is recorded on the
+        lane behind fn and kept in ``self.done[tag]`` (data parallel: the gradient bucket this chain completes can be reduced as soon
+        as the event fires, see CelebATrainer)."""
+        self._pending.append(("lane", self.lane(i), self.mark(), fn, tag))
         self._issue(("lane", i % len(self.lanes)))
 
     def defer_opt(self, fn):
         """the optimizer lane runs fn(ws) behind the current stream AND every weight-gradient chain forked so far"""
-        self._pending.append(("opt", self.opt, self.mark(), fn))
+        self._pending.append(("opt", self.opt, self.mark(), fn, None))
         self._issue("opt")
 
     def defer_prep(self, fn):
-        self._pending.append(("prep", self.prep, self.mark(), fn))
+        self._pending.append(("prep", self.prep, self.mark(), fn, None))
         self._issue("prep")
 
     def _issue(self, key):
@@ -189,7 +192,7 @@ class SideStream:
         self._flushing = True
         try:
             while self._pending:
-                kind, ln, ev, fn = self._pending.pop(0)
+                kind, ln, ev, fn, tag = self._pending.pop(0)
                 ln.ensure()
                 ln.stream.wait_event(ev)
                 if kind == "opt":
@@ -199,6 +202,8 @@ class SideStream:
                         ln.stream.wait_event(e2)
                 with ln:
                     fn(ln.ws)
+                    if tag is not None:
+                        self.done[tag] = self.mark()
         finally:
             self._flushing = False
 
@@ -249,6 +254,38 @@ class SideStream:
             ev = torch.cuda.Event()
             ev.record(ln.stream)
             cur.wait_event(ev)
+
+
+class SyncScratch:
+    """Per-engine scratch of synchronised BatchNorm: one [3*C] statistics block and one [2*C] backward-sum block per layer."""
+
+    def __init__(self, channels, device):
+        self.stats = [torch.empty(3 * c, device=device, dtype=torch.float32) for c in channels]
+        self.sums = [torch.empty(2 * c, device=device, dtype=torch.float32) for c in channels]
+
+
+def bn_train_forward(dt, x, y, M, C, bn, mean, invstd, ws_small, act, slope=0.0, sync=None, stats=None):
+    """nn.BatchNorm2d in training mode (batch statistics, running statistics updated).  ``sync`` (a dp.SyncBN): statistics over the
+    global batch of all ranks -- local (n, mean, M2) -> one exchange of 3*C floats -> Chan-combined mean / variance."""
+    if sync is None:
+        ops.bn_fwd_train(dt, x, y, M, C, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var, bn.num_batches_tracked, mean, invstd,
+                         ws_small, act, slope)
+        return
+    ops.bn_stats_local(dt, x, M, C, ws_small, stats)
+    allst = sync.gather_stats(stats)
+    ops.bn_fwd_from_stats(dt, x, y, M, C, allst, sync.world, M * sync.world, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var,
+                          bn.num_batches_tracked, mean, invstd, ws_small, act, slope)
+
+
+def bn_train_backward(dt, z, da, dz, M, C, bn, mean, invstd, act, slope, dgamma, dbeta, ws, sync=None, sums=None):
+    """Backward of bn_train_forward (``ws``: a Workspace).  ``sync``: the two per-channel sums over the global batch (one exchange of
+    2*C floats); dgamma / dbeta are this rank's share -- the gradient all-reduce averages them like every other gradient."""
+    if sync is None:
+        ops.bn_bwd(dt, z, da, dz, M, C, bn.weight, bn.bias, mean, invstd, act, slope, dgamma, dbeta, ws.sums, ws.small)
+        return
+    ops.bn_bwd_sums_local(dt, z, da, M, C, bn.weight, bn.bias, mean, invstd, act, slope, dgamma, dbeta, sums, ws.small)
+    sync.reduce_sums(sums)
+    ops.bn_bwd_from_sums(dt, z, da, dz, M, C, sums, M * sync.world, bn.weight, bn.bias, mean, invstd, act, slope, ws.small)
 
 
 def capture_step(trainer, body):

@@ -15,7 +15,8 @@ from torch.nn.utils import spectral_norm
 
 from . import ops
 from .celeba import _HipModule, _require_cuda, transformation_2D      # noqa: F401  (same STN warp in both scripts)
-from .engine import Arena, ConvRec, SideStream, Workspace, capture_step, parse_dtype
+from .engine import (Arena, ConvRec, SideStream, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step,
+                     parse_dtype)
 from .ops import ACT_LRELU, ACT_NONE, ACT_TANH, EG_F32, OUT_NCHW_F32
 from .trunk import Head, TrunkEngine
 
@@ -73,6 +74,7 @@ class _GenEngine:
         self.img = f(B, self.CH, 4 * s, 4 * s)
         self.mean = [f(128), f(128), f(64)]
         self.invstd = [f(128), f(128), f(64)]
+        self.sync_scratch = SyncScratch((128, 128, 64), dev)
         self.dimg_z = torch.empty_like(self.img)
         self.p8 = e(B * (4 * s) ** 2, 8)
         self.da2, self.dz2 = torch.empty_like(self.a2), torch.empty_like(self.a2)
@@ -105,8 +107,9 @@ class _GenEngine:
         ops.pack_strided(EG_F32, g.conv_blocks[9].weight, self.w3pad, self.CH, 576, 576, 1, 576, 0, 1)
         self.c3.pack(self.w3pad)
 
-    def forward(self, noise, labels, code, training=True):
-        """``training=False``: BatchNorm with the running statistics, nothing updated (module.eval())."""
+    def forward(self, noise, labels, code, training=True, sync=None):
+        """``training=False``: BatchNorm with the running statistics, nothing updated (module.eval()).  ``sync`` (a dp.SyncBN):
+        batch statistics over all ranks."""
         dt, B, g, ws = self.dtype, self.B, self.gen, self.ws
         cb = g.conv_blocks
         ops.concat_cast(dt, noise, labels, code, self.inp, B, self.cpad)
@@ -116,8 +119,7 @@ class _GenEngine:
             if not training:
                 ops.bn_fwd_eval(dt, x, y, M, C, mod.weight, mod.bias, mod.eps, mod.running_mean, mod.running_var, ws.small, act, slope)
                 return
-            ops.bn_fwd_train(dt, x, y, M, C, mod.weight, mod.bias, mod.eps, mod.momentum, mod.running_mean, mod.running_var, mod.num_batches_tracked,
-                             self.mean[i], self.invstd[i], ws.small, act, slope)
+            bn_train_forward(dt, x, y, M, C, mod, self.mean[i], self.invstd[i], ws.small, act, slope, sync, self.sync_scratch.stats[i])
         s = g.init_size
         bn(self.h, self.a0, cb[0], 0, B * s * s, 128, ACT_NONE)
         ops.conv_fwd(self.c1.c, dt, self.a0, self.c1.wp_fwd, self.z1, ops.epilogue(bias=cb[2].bias))
@@ -127,7 +129,7 @@ class _GenEngine:
         ops.conv_fwd(self.c3f.c, dt, self.a2, self.c3f.wp_fwd, self.img, ops.epilogue(bias=cb[9].bias, act=ACT_TANH, out_mode=OUT_NCHW_F32))
         return self.img
 
-    def backward(self, dimg, grad, side=None):
+    def backward(self, dimg, grad, side=None, sync=None):
         """Accumulates d(loss)/d(params) into ``grad``.  With ``side`` (engine.SideStream) every layer's weight-gradient chain (TN GEMM, slab
         reduce, bias sums) is forked onto a lane as soon as the layer's output gradient exists, beside the backward-data chain of the
         layers below; the caller joins before it reads ``grad``.  Same kernels, same order inside every chain: bit-identical."""
@@ -155,8 +157,8 @@ class _GenEngine:
         flush()
 
         def bn_bwd(z, da, dz, mod, i, M, C, act, name):
-            ops.bn_bwd(dt, z, da, dz, M, C, mod.weight, mod.bias, self.mean[i], self.invstd[i], act, SLOPE, gof(name + ".weight"), gof(name + ".bias"),
-                       ws.sums, ws.small)
+            bn_train_backward(dt, z, da, dz, M, C, mod, self.mean[i], self.invstd[i], act, SLOPE, gof(name + ".weight"), gof(name + ".bias"), ws,
+                              sync, self.sync_scratch.sums[i])
         # conv2 (128 -> 64 on the 2x-upsampled a1)
         bn_bwd(self.z2, self.da2, self.dz2, cb[7], 2, B * S * S, 64, ACT_LRELU, "conv_blocks.7")
 
@@ -435,8 +437,11 @@ class MnistTrainer:
     info+affine step over G+E (lambda_cat 1, lambda_con .1, lambda_affine .1, :201-203), three Adams (:249-255)."""
 
     def __init__(self, generator, discriminator, encoder, batch_size, dtype="f32", allreduce=None, lr=1e-4, betas=(0.5, 0.999),
-                 lambda_cat=1.0, lambda_con=0.1, lambda_affine=0.1, lrs=None, overlap=False):
+                 lambda_cat=1.0, lambda_con=0.1, lambda_affine=0.1, lrs=None, overlap=False, sync_bn=None):
+        """``sync_bn`` (a dp.SyncBN): the generator's BatchNorm layers use the statistics of the global batch (N ranks == 1 rank at equal
+        global batch for the generator); BatchNorm layers of the other networks stay per-rank, as under torch DDP without SyncBatchNorm."""
         self.G, self.D, self.E, self.B = generator, discriminator, encoder, batch_size
+        self.sync_bn = sync_bn
         dt = parse_dtype(dtype)
         for m in (generator, discriminator, encoder):
             m.set_compute_dtype(dt)
@@ -485,13 +490,13 @@ class MnistTrainer:
         ops.warp_affine(self.real, self.theta, self.scaled, B, G.channels, G.img_size, G.img_size)   # :367
         # ---- 1) generator step (:375-388), LSGAN: MSE(validity, 1) ----
         ops.fill_f32(ga.grad)
-        gen = ge.forward(self.z, self.onehot, self.code)
+        gen = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
         out = de.forward([gen])["adv_layer.0"]
         ops.loss_mse(out, 1, 0, 1, B, None, 0, 1.0, 1.0, self.losses[0:1], self.dout_d[:B])
         dimg = de.backward(0, 1, {"adv_layer.0": self.dout_d[:B]}, da.grad, need_wgrad=False, need_dimg=True)
         side = self.side
         join = side.join if side is not None else (lambda: None)
-        ge.backward(dimg, ga.grad, side)
+        ge.backward(dimg, ga.grad, side, sync=self.sync_bn)
         join()
         if self.allreduce is not None:
             self.allreduce(ga.grad)
@@ -510,7 +515,7 @@ class MnistTrainer:
         # ---- 3) info + affine step (:415-446): E(gen), E(scaled), E(real) (BatchNorm -> one tape per forward) ----
         ops.fill_f32(ga.grad)
         ops.fill_f32(ea.grad)
-        gen = ge.forward(self.z, self.onehot, self.code)
+        gen = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
         outs = ee.forward([gen, self.scaled, self.real])
         cat, lat = outs["aux_layer.0"], outs["latent_layer.0"]
         ops.fill_f32(self.d_cat)
@@ -520,7 +525,7 @@ class MnistTrainer:
                                 self.d_code[B:2 * B], None, self.ws_aff)
         dimg = ee.backward(0, 3, {"aux_layer.0": self.d_cat, "latent_layer.0": self.d_code}, ea.grad, need_dimg=True)
         pending = self.allreduce.start(ea.grad) if (self.allreduce is not None and hasattr(self.allreduce, "start")) else None
-        ge.backward(dimg, ga.grad, side)                # overlaps with the encoder-gradient all-reduce
+        ge.backward(dimg, ga.grad, side, sync=self.sync_bn)    # overlaps with the encoder-gradient all-reduce
         join()
         if self.allreduce is not None:
             self.allreduce(ga.grad)

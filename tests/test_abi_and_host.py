@@ -80,6 +80,20 @@ g2 = torch.ones(6) * (rank + 1)
 h = ar.start(g2)            # asynchronous form used to overlap the all-reduce with the generator backward
 ar.finish(h)
 assert torch.allclose(g2, torch.ones(6) * 1.5), g2
+bw = eg.dp.GradAllReduce(world, wire="bf16")      # optional bf16 wire: mean of the bf16-rounded values, widened back to fp32
+g3 = torch.full((300,), 1.0 + 2.0 ** -10) * (rank + 1)
+keep = g3.clone()
+bw(g3)
+want3 = sum(float((keep / (rank + 1) * (r + 1)).bfloat16().float()[0]) for r in range(world)) / world
+assert g3.dtype == torch.float32 and torch.allclose(g3, torch.full((300,), want3), rtol=2 ** -8), (g3[:3], want3)
+h = bw.start(g3)
+bw.finish(h)
+# bucketed form of the CelebA trainer: slices of one arena, each started as its layers complete, all finished at the end
+arena = torch.arange(40, dtype=torch.float32) * (rank + 1)
+hs = [ar.start(arena[lo:hi]) for lo, hi in ((24, 40), (8, 24), (0, 8))]
+for h in hs:
+    ar.finish(h)
+assert torch.allclose(arena, torch.arange(40, dtype=torch.float32) * 1.5), arena
 t = eg.dp.max_over_ranks(float(rank + 1), torch.device("cpu"))
 assert t == float(world), t
 eg.dp.barrier()

@@ -65,6 +65,24 @@ def test_sync_batchnorm_two_ranks_equal_one_rank_at_the_same_global_batch():
         assert torch.allclose(r0[key], w[key], rtol=1e-4, atol=1e-6) and torch.equal(r0[key], r1[key]), key
 
 
+@pytest.mark.parametrize("family,port", [("mnist", 29551), ("dsprites", 29552)])
+def test_small_network_generators_sync_batchnorm_two_ranks(family, port):
+    """MNIST (mnist/EAD-GAN_MNIST.py:90-112) and dSprites (dSprites/rp.py:176-206) generators, three BatchNorm layers each: two ranks x 4
+    images with dp.SyncBN give the images of one rank x 8 images; the rank gradient shares sum to the whole-batch gradient; the running
+    statistics are those of the global batch on both ranks."""
+    B = 8
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(dp_worker.run_generator_sync, args=(2, port, d, family, B), nprocs=2, join=True)
+        mp.spawn(dp_worker.run_generator_sync, args=(1, port, d, family, B), nprocs=1, join=True)
+        r0, r1, w = (torch.load(os.path.join(d, f"{family}_rank{r}_of{n}.pt"), weights_only=True) for r, n in ((0, 2), (1, 2), (0, 1)))
+    img = torch.cat((r0["img"], r1["img"]))
+    assert float((img - w["img"]).norm() / w["img"].norm()) < 1e-5
+    gsum = r0["grad"] + r1["grad"]
+    assert float((gsum - w["grad"]).norm() / w["grad"].norm()) < 2e-3           # LeakyReLU / ReLU units within rounding of 0 may flip
+    assert torch.equal(r0["running"], r1["running"])
+    assert torch.allclose(r0["running"], w["running"], rtol=1e-4, atol=1e-6)
+
+
 def test_rccl_allreduce_inside_the_captured_step_child_process():
     """The data-parallel step with a real RCCL process group (one rank) captured into the hipGraph.  Run in a child process: the failure this
     guards against is a segfault inside hipStreamEndCapture (a side lane that RCCL's stream waited for and that later waits for RCCL's
