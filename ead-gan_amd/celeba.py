@@ -109,15 +109,23 @@ class _GenEngine:
                ("G0", ("conv_blocks.0.weight", "conv_blocks.0.bias")))
 
     def repack(self):
+        for tag, _ in self.BUCKETS:
+            self.repack_bucket(tag)
+
+    def repack_bucket(self, tag):
+        """re-pack the panels of one gradient bucket's layers (the optimizer lane updates bucket by bucket)"""
         g, dt = self.gen, self.dtype
-        w0 = self._p(0, "weight")                                      # [cin][1024][4][4]
-        ops.pack_strided(dt, w0, self.l0.wp_fwd, 16 * G_WIDTHS[0], self.cin, self.l0.Kpad_fwd, G_WIDTHS[0], 1, 16, 16 * G_WIDTHS[0])
-        for i, idx in enumerate((1, 4, 7)):
-            self.mid[i].pack(self._p(idx, "weight"))
-        self.l4.pack(self._p(10, "weight"))
-        ops.pack_strided(dt, self._p(10, "weight"), self.l4p.wp_fwd, G_WIDTHS[3], self.kp, self.l4p.Kpad_fwd, 1, self.kp, 0, 1)
-        # wp[t*C + c][ci] = W[ci][c][t]   (master [128][C][4][4])
-        ops.pack_strided(dt, self._p(10, "weight"), self.l4g.wp_fwd, self.kp, G_WIDTHS[3], self.l4g.Kpad_fwd, g.channels, 1, 16, self.kp)
+        if tag == "G0":
+            w0 = self._p(0, "weight")                                  # [cin][1024][4][4]
+            ops.pack_strided(dt, w0, self.l0.wp_fwd, 16 * G_WIDTHS[0], self.cin, self.l0.Kpad_fwd, G_WIDTHS[0], 1, 16, 16 * G_WIDTHS[0])
+        elif tag in ("G1", "G2", "G3"):
+            i = int(tag[1]) - 1
+            self.mid[i].pack(self._p((1, 4, 7)[i], "weight"))
+        else:
+            self.l4.pack(self._p(10, "weight"))
+            ops.pack_strided(dt, self._p(10, "weight"), self.l4p.wp_fwd, G_WIDTHS[3], self.kp, self.l4p.Kpad_fwd, 1, self.kp, 0, 1)
+            # wp[t*C + c][ci] = W[ci][c][t]   (master [128][C][4][4])
+            ops.pack_strided(dt, self._p(10, "weight"), self.l4g.wp_fwd, self.kp, G_WIDTHS[3], self.l4g.Kpad_fwd, g.channels, 1, 16, self.kp)
 
     def forward(self, noise, labels, code, training=True, sync=None):
         """``training=False``: BatchNorm with the running statistics, nothing updated (module.eval()).  ``sync`` (a dp.SyncBN):
@@ -389,13 +397,21 @@ class _DiscEngine:
         return self.disc.main[2 * i]
 
     def repack(self):
-        self.l1.pack(self._m(0).weight_orig)
-        # wp[t*C + c][co] = W[co][c][t]   (Conv2d master [128][C][4][4]; the transposed convolution reads it as [in = 128][out = C])
-        ops.pack_strided(self.dtype, self._m(0).weight_orig, self.l1g.wp_fwd, self.kp, D_WIDTHS[0], self.l1g.Kpad_fwd, self.C, 1, 16, self.kp)
-        ops.pack_strided(self.dtype, self._m(0).weight_orig, self.l1p.wp_fwd, D_WIDTHS[0], self.kp, self.l1p.Kpad_fwd, 1, self.kp, 0, 1)
-        for i in range(3):
+        for tag, _ in self.BUCKETS:
+            self.repack_bucket(tag)
+
+    def repack_bucket(self, tag):
+        """re-pack the panels of one gradient bucket's layer (see _GenEngine.repack_bucket)"""
+        if tag == "D0":
+            self.l1.pack(self._m(0).weight_orig)
+            # wp[t*C + c][co] = W[co][c][t]   (Conv2d master [128][C][4][4]; the transposed convolution reads it as [in = 128][out = C])
+            ops.pack_strided(self.dtype, self._m(0).weight_orig, self.l1g.wp_fwd, self.kp, D_WIDTHS[0], self.l1g.Kpad_fwd, self.C, 1, 16, self.kp)
+            ops.pack_strided(self.dtype, self._m(0).weight_orig, self.l1p.wp_fwd, D_WIDTHS[0], self.kp, self.l1p.Kpad_fwd, 1, self.kp, 0, 1)
+        elif tag in ("D1", "D2", "D3"):
+            i = int(tag[1]) - 1
             self.mid[i].pack(self._m(i + 1).weight_orig)
-        self.head.pack(self._m(4).weight)
+        else:
+            self.head.pack(self._m(4).weight)
 
     def rows(self, i):
         """lattice rows of one tape at the output of layer i"""
@@ -667,6 +683,9 @@ class DeviceInputs:
         ops.counter_add(self.step, 1)
 
 
+BUCKET_OPT = os.environ.get("EG_BUCKET_OPT", "g3")     # "0" never, "1" every update, "3" the info step's two updates, "g3" only its last (G)
+
+
 class CelebATrainer:
     """One call of :meth:`train_step` == one iteration of the reference loop body
     (celebA/EAD-GAN_celebA.py:299-401): G adversarial step, D step, info+affine step, three Adams
@@ -817,37 +836,54 @@ class CelebATrainer:
         ar = self.allreduce
         ar_async = ar is not None and hasattr(ar, "start")
 
-        def update(arena, m, v, lr, slot, tick, zero, repack, key=None, key_w=None):
-            """Queue one network's optimizer update on the optimizer lane.  Data parallel: the gradient all-reduce is STARTED here, on the
-            main stream, once the weight-gradient lanes are done (RCCL's stream must only ever wait for the capture's origin stream: a
-            lane that RCCL waited for and that later waits for RCCL is the stream-level back edge hipStreamEndCapture crashes on), and
-            FINISHED on the optimizer lane, so the main stream waits neither for the collective nor for Adam / re-packing."""
-            hs = []
+        def update(arena, m, v, lr, slot, tick, zero, eng, key=None, key_w=None, where=""):
+            """Queue one network's optimizer update on the optimizer lane, bucket by bucket in the order the backward pass completes them:
+            a bucket's Adam (+ gradient zeroing in the same pass) and panel re-packing wait only for the lane chain that completes the
+            bucket's gradients and for the main-stream kernels that still read its parameters (engine.SideStream.free), so the update of
+            the upper layers runs beside the backward pass of the lower ones and only the last bucket's update is behind all of it.
+            Data parallel: each bucket's all-reduce is STARTED here, on the main stream, once its chain is done (RCCL's stream must only
+            ever wait for the capture's origin stream: a lane that RCCL waited for and that later waits for RCCL is the stream-level back
+            edge hipStreamEndCapture crashes on), and FINISHED on the optimizer lane, so the main stream waits neither for the
+            collective nor for Adam / re-packing."""
+            side.flush()
+            side.close_tags()
+            buckets = self._buckets(arena)
+            hs = {}
             if ar is not None:
-                # one collective per layer bucket, started (from the main stream) as soon as the lane chain that completes the bucket has
-                # fired its event, in the order the backward pass finishes them: the first buckets are on the wire while the last
-                # weight-gradient chains still run, and the main stream only ever waits for ONE chain at a time
-                side.flush()
-                for tag, lo, hi in self._buckets(arena):
+                for tag, lo, hi in buckets:
                     side.wait(side.done.pop(tag))       # KeyError: a bucket whose chain was never forked
                     if ar_async:
-                        hs.append(ar.start(arena.grad[lo:hi]))
+                        hs[tag] = ar.start(arena.grad[lo:hi])
                     else:
                         ar(arena.grad[lo:hi])
-                side.join_lanes()                      # chains without a tag (none today) and lanes this pass did not use
-
-            def fn(_ws):
-                for h in hs:
-                    ar.finish(h)
-                self._adam(arena, m, v, lr, slot, tick)
-                if key_w:
-                    evs[key_w] = side.mark()            # master weights are new
-                if zero:
-                    ops.fill_f32(arena.grad)
-                repack()
-                if key:
-                    evs[key] = side.mark()              # panels are new, gradients zeroed
-            return fn
+            last = buckets[-1][0]
+            if not (BUCKET_OPT == "1" or (BUCKET_OPT == "3" and where in ("d3", "g3")) or BUCKET_OPT == where):     # A/B switch: the whole arena in one update behind ALL chains (round-1 schedule)
+                def whole(_ws):
+                    for tag in hs:
+                        ar.finish(hs[tag])
+                    ops.adam_step_zero(arena.flat, arena.grad, m, v, arena.numel, lr, self.betas[0], self.betas[1], 1e-8, self.steps[slot:slot + 1],
+                                       tick, zero)
+                    if key_w:
+                        evs[key_w] = side.mark()
+                    eng.repack()
+                    if key:
+                        evs[key] = side.mark()
+                side.done.clear()
+                side.free.clear()
+                side.defer_opt(whole)
+                return
+            for k, (tag, lo, hi) in enumerate(buckets):
+                def fn(_ws, tag=tag, lo=lo, hi=hi, first=(k == 0)):
+                    if tag in hs:
+                        ar.finish(hs[tag])
+                    ops.adam_step_zero(arena.flat[lo:hi], arena.grad[lo:hi], m[lo:hi], v[lo:hi], hi - lo, lr, self.betas[0], self.betas[1], 1e-8,
+                                       self.steps[slot:slot + 1], tick and first, zero)
+                    if key_w and tag == last:
+                        evs[key_w] = side.mark()        # master weights are new
+                    eng.repack_bucket(tag)
+                    if key and tag == last:
+                        evs[key] = side.mark()          # panels are new, gradients zeroed
+                side.defer_opt_after((tag,), fn)
 
         self._inputs_head()
         # ---- 1) generator adversarial step (:334-345); D(gen) lives in tape slot 2 so that step 2's tapes can be prepared meanwhile ----
@@ -869,7 +905,7 @@ class CelebATrainer:
         side.flush()
         dimg = de.backward(2, 1, self.dout[2 * B:], da.grad, need_wgrad=False, need_dimg=True)
         ge.backward(dimg, ga.grad, side, sync=self.sync_bn)
-        side.defer_opt(update(ga, self.mG, self.vG, self.lr[0], 0, True, True, ge.repack, key="g"))     # beside the whole of step 2
+        update(ga, self.mG, self.vG, self.lr[0], 0, True, True, ge, key="g")                            # beside the whole of step 2
         # ---- 2) discriminator step (:353-366); gen is the (detached) output of step 1; D(scaled) then D(gen), batched ----
         ops.fill_f32(da.grad)
         side.flush()
@@ -878,7 +914,7 @@ class CelebATrainer:
         ops.loss_bce_sigmoid(out[:B], 19, 0, B, 1.0, 0.5, self.losses[1:2], self.dout[:B])
         ops.loss_bce_sigmoid(out[B:], 19, 0, B, 0.0, 0.5, self.losses[1:2], self.dout[B:2 * B])
         de.backward(0, 2, self.dout[:2 * B], da.grad, side=side)
-        side.defer_opt(update(da, self.mD, self.vD, self.lr[1], 1, True, True, de.repack, key_w="dw"))  # beside step 3's generator forward
+        update(da, self.mD, self.vD, self.lr[1], 1, True, True, de, key_w="dw")                         # beside step 3's generator forward
 
         def prep3(_ws):                                 # step 3's three power iterations (new weights), patch rows of scaled / real
             side.wait(evs["dw"])
@@ -895,9 +931,9 @@ class CelebATrainer:
         ops.loss_affine_rpqxy(o_real, o_trans, 19, 1, B, self.code, cd, laff, self.losses[2:3], self.dout[2 * B:], self.dout[B:2 * B])
         dimg = de.backward(0, 3, self.dout, da.grad, need_dimg=True, side=side)
         # D's update beside the generator backward; it ticks optimizer_info's counter (shared by both arenas), G's does not
-        side.defer_opt(update(da, self.miD, self.viD, self.lr[2], 2, True, False, de.repack))
+        update(da, self.miD, self.viD, self.lr[2], 2, True, False, de, where="d3")
         ge.backward(dimg, ga.grad, side, sync=self.sync_bn)
-        side.defer_opt(update(ga, self.miG, self.viG, self.lr[2], 2, False, False, ge.repack))
+        update(ga, self.miG, self.viG, self.lr[2], 2, False, False, ge, where="g3")
         side.join()
 
     # -- public API -----------------------------------------------------------------------------------

@@ -224,25 +224,72 @@ extern "C" int eg_sn_power_iter_multi(const eg_sn_layer* layers, int nlayers, fl
 // ---- Adam -----------------------------------------------------------------------------------------
 __global__ void adam_tick_kernel(int* step) { step[0] += 1; }
 
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n,
-                            float lr, float b1, float b2, float eps, const int* __restrict__ step) {
+struct AdamCoef { float step_size, bc2_sqrt, w, b2, eps; };
+
+__device__ __forceinline__ AdamCoef adam_coef(float lr, float b1, float b2, float eps, const int* __restrict__ step) {
     const int t = step[0];
     const double bc1 = 1.0 - pow((double)b1, (double)t);
     const double bc2 = 1.0 - pow((double)b2, (double)t);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
-    const float w = 1.f - b1;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float gi = g[i];
-        float mi = m[i];
-        // exp_avg.lerp_(grad, 1-beta1) with ATen's two-sided formula
-        mi = (w < 0.5f) ? mi + w * (gi - mi) : gi - (gi - mi) * (1.f - w);
-        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+    return {(float)((double)lr / bc1), (float)sqrt(bc2), 1.f - b1, b2, eps};
+}
+
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamCoef& c) {
+#pragma clang fp contract(off)      // the float4 and the scalar paths must round alike (slice-wise == whole-arena, bit for bit)
+    // exp_avg.lerp_(grad, 1-beta1) with ATen's two-sided formula
+    m = (c.w < 0.5f) ? m + c.w * (g - m) : g - (g - m) * (1.f - c.w);
+    v = v * c.b2 + (1.f - c.b2) * g * g;
+    const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
+    p = p - c.step_size * (m / denom);
+}
+
+// elements [0, head) and [head + 4*nvec, n) one per thread (the unaligned ends of an arena slice), the middle as float4; the four arrays
+// are slices of sibling arenas at the same element offset, so one `head` aligns all of them.  ZERO: the gradient is cleared in the
+// same pass (optimizer.zero_grad() of the next backward pass that accumulates into it).
+template <bool ZERO>
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, size_t head,
+                            size_t nvec, float lr, float b1, float b2, float eps, const int* __restrict__ step) {
+    const AdamCoef c = adam_coef(lr, b1, b2, eps, step);
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    float4* p4 = reinterpret_cast<float4*>(p + head);
+    float4* g4 = reinterpret_cast<float4*>(g + head);
+    float4* m4 = reinterpret_cast<float4*>(m + head);
+    float4* v4 = reinterpret_cast<float4*>(v + head);
+    for (size_t i = tid; i < nvec; i += nth) {
+        float4 pi = p4[i], mi = m4[i], vi = v4[i];
+        const float4 gi = g4[i];
+        adam_elem(pi.x, gi.x, mi.x, vi.x, c);
+        adam_elem(pi.y, gi.y, mi.y, vi.y, c);
+        adam_elem(pi.z, gi.z, mi.z, vi.z, c);
+        adam_elem(pi.w, gi.w, mi.w, vi.w, c);
+        m4[i] = mi;
+        v4[i] = vi;
+        p4[i] = pi;
+        if (ZERO) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const size_t tail0 = head + 4 * nvec, nends = head + (n - tail0);
+    for (size_t e = tid; e < nends; e += nth) {
+        const size_t i = e < head ? e : tail0 + (e - head);
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_elem(pi, g[i], mi, vi, c);
         m[i] = mi;
         v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = p[i] - step_size * (mi / denom);
+        p[i] = pi;
+        if (ZERO) g[i] = 0.f;
     }
+}
+
+static void launch_adam(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int* step, int tick,
+                        bool zero, hipStream_t st) {
+    if (tick) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step);
+    size_t head = ((16 - ((uintptr_t)p & 15)) & 15) / 4;
+    const bool same = (((uintptr_t)p ^ (uintptr_t)g) & 15) == 0 && (((uintptr_t)p ^ (uintptr_t)m) & 15) == 0 && (((uintptr_t)p ^ (uintptr_t)v) & 15) == 0;
+    if (head > n) head = n;
+    const size_t nvec = same ? (n - head) / 4 : 0;
+    if (!same) head = 0;
+    const size_t work = same ? (nvec > 8 ? nvec : 8) : n;          // differently aligned slices: every element through the scalar loop
+    const int blocks = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
+    if (zero) hipLaunchKernelGGL(adam_kernel<true>, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, head, nvec, lr, b1, b2, eps, step);
+    else hipLaunchKernelGGL(adam_kernel<false>, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, head, nvec, lr, b1, b2, eps, step);
 }
 
 /* In-place Adam over a flat fp32 arena.  `step` is a device int32 incremented by this call (so a captured
@@ -250,10 +297,18 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
 extern "C" int eg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int* step,
                             int tick, eg_stream_t s) {
     EG_REQUIRE(p && g && m && v && step, "eg_adam_step: null pointer");
-    hipStream_t st = (hipStream_t)s;
-    if (tick) hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, step);
-    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
-    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, step);
+    launch_adam(p, const_cast<float*>(g), m, v, n, lr, b1, b2, eps, step, tick, false, (hipStream_t)s);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+/* The same update on a slice of the arena (one gradient bucket), clearing the gradient slice in the same pass when `zero_grad`:
+ * torch.optim.Adam.step() + optimizer.zero_grad() of the slice (celebA/EAD-GAN_celebA.py:344-345,365-366,400-401). */
+extern "C" int eg_adam_step_zero(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps, int* step,
+                                 int tick, int zero_grad, eg_stream_t s) {
+    EG_REQUIRE(p && g && m && v && step, "eg_adam_step_zero: null pointer");
+    if (n == 0) return 0;
+    launch_adam(p, g, m, v, n, lr, b1, b2, eps, step, tick, zero_grad != 0, (hipStream_t)s);
     EG_LAUNCH_CHECK();
     return 0;
 }

@@ -141,6 +141,11 @@ class SideStream:
         self.prep = _Lane(device, like)
         self._pending = []
         self.done = {}                                 # tag -> event behind a tagged lane chain (defer(..., tag=))
+        # tag -> main-stream event behind the last main-stream kernel that reads the tagged bucket's parameters or panels: the event of
+        # the NEXT tagged fork (the backward passes fork a layer's chain, then launch that layer's backward-data GEMM, then move on to
+        # the layer below), or close_tags() for the last one
+        self.free = {}
+        self._last_tag = None
         self._flushing = False
         # issue order of forked work (see defer()): "0" at once (side work captured before the main stream's next kernel), "1" always
         # after it, "once" at once for a lane's first fork of the step and after it from then on
@@ -166,8 +171,25 @@ class SideStream:
         """lane i runs fn(lane_workspace) behind everything enqueued on the current stream so far.  ``tag``: an event is recorded on the
         lane behind fn and kept in ``self.done[tag]`` (data parallel: the gradient bucket this chain completes can be reduced as soon
         as the event fires, see CelebATrainer)."""
-        self._pending.append(("lane", self.lane(i), self.mark(), fn, tag))
+        ev = self.mark()
+        if tag is not None:
+            if self._last_tag is not None:
+                self.free[self._last_tag] = ev
+            self._last_tag = tag
+        self._pending.append(("lane", self.lane(i), ev, fn, tag))
         self._issue(("lane", i % len(self.lanes)))
+
+    def close_tags(self):
+        """the current position of the current stream is behind every reader of the last tagged bucket"""
+        if self._last_tag is not None:
+            self.free[self._last_tag] = self.mark()
+            self._last_tag = None
+
+    def defer_opt_after(self, tags, fn):
+        """the optimizer lane runs fn(ws) behind the tagged chains ``tags`` and the main-stream readers of their buckets ONLY (not behind
+        the rest of the backward pass): bucket-wise optimizer updates start while the layers below are still in their backward pass"""
+        self._pending.append(("optb", self.opt, tuple(tags), fn, None))
+        self._issue("opt")
 
     def defer_opt(self, fn):
         """the optimizer lane runs fn(ws) behind the current stream AND every weight-gradient chain forked so far"""
@@ -194,7 +216,14 @@ class SideStream:
             while self._pending:
                 kind, ln, ev, fn, tag = self._pending.pop(0)
                 ln.ensure()
-                ln.stream.wait_event(ev)
+                if kind == "optb":
+                    for t in ev:
+                        d = self.done.pop(t, None)          # None: the caller already waited for it (data parallel)
+                        if d is not None:
+                            ln.stream.wait_event(d)
+                        ln.stream.wait_event(self.free.pop(t))
+                else:
+                    ln.stream.wait_event(ev)
                 if kind == "opt":
                     for other in self.lanes:
                         e2 = torch.cuda.Event()

@@ -357,6 +357,11 @@ def adam_step(p, g, m, v, n, lr, b1, b2, eps, step, tick=True):
     lib().call("eg_adam_step", _p(p), _p(g), _p(m), _p(v), n, lr, b1, b2, eps, _p(step), int(tick), _stream())
 
 
+def adam_step_zero(p, g, m, v, n, lr, b1, b2, eps, step, tick=True, zero_grad=False):
+    """Adam on a slice (views of the arena tensors), optionally clearing the gradient slice in the same pass"""
+    lib().call("eg_adam_step_zero", _p(p), _p(g), _p(m), _p(v), n, lr, b1, b2, eps, _p(step), int(tick), int(zero_grad), _stream())
+
+
 def clear_errors():
     return lib().query("eg_clear_errors")
 

@@ -260,6 +260,10 @@ int eg_sn_power_iter_multi(const eg_sn_layer* layers, int nlayers, float* ws, in
 /* --- Adam (torch.optim.Adam, celebA/EAD-GAN_celebA.py:211-217) over a flat fp32 arena ----------------------- */
 int eg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                  int* step, int tick, eg_stream_t s);
+/* the same update on a slice of the arena (one gradient bucket); zero_grad: the gradient slice is cleared in the same pass
+ * (optimizer.step() + optimizer.zero_grad(), celebA/EAD-GAN_celebA.py:344-345,365-366,400-401) */
+int eg_adam_step_zero(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
+                      int* step, int tick, int zero_grad, eg_stream_t s);
 int eg_fill_f32(float* p, size_t n, float val, eg_stream_t s);
 
 /* --- utility: generator input concat+cast, elementwise activation gradient, layout conversion -------------- */

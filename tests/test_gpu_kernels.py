@@ -317,6 +317,27 @@ def test_adam_matches_torch():
     torch.testing.assert_close(pd.cpu(), p.detach(), rtol=1e-6, atol=1e-7)
 
 
+def test_adam_bucket_slices_equal_the_whole_arena_update():
+    """The trainers update bucket by bucket (eg_adam_step_zero on slices whose ends are not 16-byte aligned, float4 middle + scalar
+    ends, gradient cleared in the same pass): bit-identical to one eg_adam_step over the arena; only the first slice ticks the counter."""
+    g = torch.Generator().manual_seed(9)
+    n = 10007
+    p0 = torch.randn(n, generator=g).to(DEV)
+    gr = torch.randn(n, generator=g).to(DEV)
+    m0, v0 = torch.rand(n, generator=g).to(DEV) * 1e-2, torch.rand(n, generator=g).to(DEV) * 1e-4
+    pa, ma, va, sa = p0.clone(), m0.clone(), v0.clone(), torch.full((1,), 3, dtype=torch.int32, device=DEV)
+    ops.adam_step(pa, gr, ma, va, n, 2e-4, 0.5, 0.999, 1e-8, sa, True)
+    pb, mb, vb, gb, sb = p0.clone(), m0.clone(), v0.clone(), gr.clone(), torch.full((1,), 3, dtype=torch.int32, device=DEV)
+    cuts = [0, 3, 4, 6147, 6150, 9001, n]
+    for k, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+        ops.adam_step_zero(pb[lo:hi], gb[lo:hi], mb[lo:hi], vb[lo:hi], hi - lo, 2e-4, 0.5, 0.999, 1e-8, sb, k == 0, k % 2 == 0)
+    torch.cuda.synchronize()
+    assert int(sa) == 4 and int(sb) == 4
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    for k, (lo, hi) in enumerate(zip(cuts[:-1], cuts[1:])):
+        assert torch.equal(gb[lo:hi], torch.zeros(hi - lo, device=DEV) if k % 2 == 0 else gr[lo:hi]), k
+
+
 def test_warp_and_theta_match_golden():
     import os
     from conftest import GOLDEN
