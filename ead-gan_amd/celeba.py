@@ -178,7 +178,7 @@ class _GenEngine:
         ops.im2col_img(dt, self.dimg_z, self.patches, B, C, S, S, 4, 2, 1, self.kp)
 
         def l4_wgrad(wsw):
-            ns = ops.conv_wgrad(self.l4p.c, dt, self.patches, self.a[2], wsw.slab)
+            ns = ops.conv_wgrad(self.l4p.c, dt, self.patches, self.a[2], wsw.slab, wsw.wgs_target)
             ops.wgrad_reduce(wsw.slab, ns, W[3], W[3], self.kp, 1, gof("conv_blocks.10.weight"))
         wgrad_side(l4_wgrad, 0, "G4")
         ops.conv_fwd(self.l4p.c, dt, self.patches, self.l4p.wp_fwd, self.da[2], None)
@@ -200,7 +200,7 @@ class _GenEngine:
             x_in = self.a[i - 1] if i > 0 else self.h0
 
             def mid_wgrad(wsw, i=i, idx=idx, r=r, M=M, x_in=x_in):
-                ns = ops.conv_wgrad(r.c, dt, self.dz[i], x_in, wsw.slab)
+                ns = ops.conv_wgrad(r.c, dt, self.dz[i], x_in, wsw.slab, wsw.wgs_target)
                 ops.wgrad_reduce(wsw.slab, ns, r.Cout, r.Cout, r.Cin, 16, gof(f"conv_blocks.{idx}.weight"))
                 ops.bias_grad(dt, self.dz[i], M, W[i + 1], wsw.small, gof(f"conv_blocks.{idx}.bias"))
             wgrad_side(mid_wgrad, i + 1, f"G{i + 1}")
@@ -209,7 +209,7 @@ class _GenEngine:
 
         # L0
         def l0_wgrad(wsw):
-            ns = ops.conv_wgrad(self.l0w.c, dt, self.dh0, self.inp, wsw.slab)
+            ns = ops.conv_wgrad(self.l0w.c, dt, self.dh0, self.inp, wsw.slab, wsw.wgs_target)
             ops.wgrad_reduce(wsw.slab, ns, self.cpad, self.cin, W[0], 16, gof("conv_blocks.0.weight"))
             ops.bias_grad(dt, self.dh0, B * 16, W[0], wsw.small, gof("conv_blocks.0.bias"))
         wgrad_side(l0_wgrad, 0, "G0")                   # stays pending: the caller's next main-stream kernel goes first
@@ -481,7 +481,7 @@ class _DiscEngine:
         if need_wgrad:
             def head_wgrad(wsw):
                 ops.cast_pad(dt, dout, self.dout_t, T * B, self.nout, 32)
-                ns = ops.conv_wgrad(g["headw"], dt, sl(self.a[3]), self.dout_t, wsw.slab)
+                ns = ops.conv_wgrad(g["headw"], dt, sl(self.a[3]), self.dout_t, wsw.slab, wsw.wgs_target)
                 ops.wgrad_reduce(wsw.slab, ns, 32, self.nout, W[3], 16, gof("main.8.weight"))
                 ops.dense_small_bgrad(dout, gof("main.8.bias"), T * B, self.nout)
             wgrad_side(head_wgrad, 0, "D4")
@@ -497,7 +497,7 @@ class _DiscEngine:
                 def layer_wgrad(wsw, i=i, m=m, geo=geo, x_in=x_in):
                     ops.bias_grad_sn(dt, sl(self.dz[i]), sl(self.a[i]), m.bias, T * self.rows(i), W[i], self.rows(i), self.sigma[i][t0:], LRELU_SLOPE,
                                      wsw.small, gof(f"main.{2 * i}.bias"), self.coef[i])
-                    ns = ops.conv_wgrad(geo, dt, x_in, sl(self.dz[i]), wsw.slab)
+                    ns = ops.conv_wgrad(geo, dt, x_in, sl(self.dz[i]), wsw.slab, wsw.wgs_target)
                     taps = 16 if i > 0 else 1
                     ops.wgrad_reduce_rank1(wsw.slab, ns, W[i], W[i], self.cin[i], taps, gof(f"main.{2 * i}.weight_orig"), T, self.coef[i],
                                            self.u[i][t0:], self.v[i][t0:])

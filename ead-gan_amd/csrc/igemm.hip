@@ -805,11 +805,14 @@ static NtPlan nt_plan_auto(const NtParams& p, int nphase, const NtFacts& f, size
     const long long wgs256 = (long long)cdiv(p.M, 256) * (p.N / 128) * nphase;
     const long long rounds = (wgs256 + 255) / 256;
     if (splitk <= 1 && f.nk_min >= 32 && wgs256 >= 200 && wgs256 * 100 >= rounds * 256 * 85) return {EG_NT_S8, 1};
-    if (f.tiles128 < 512 && ws_bytes > 0) {
+    // split K only below one workgroup per CU: at 256..511 tiles the unsplit launch wins or ties (M=8192 N=512 K=4096: 52 vs 58 us,
+    // the 4-phase M=2048 N=512 K=4096: 50 vs 48 us -- profiles/r02_i_t1_splits.txt) and saves the slab round trip and the epilogue launch
+    static const int split_below = [] { const char* e = getenv("EG_NT_SPLIT_BELOW"); return e ? atoi(e) : 256; }();
+    if (f.tiles128 < (splitk > 1 ? 512 : split_below) && ws_bytes > 0) {
         const int ns = nt_splits(f.tiles128, 512, f.nk_min, part128, ws_bytes, splitk);
         if (ns > 1) return {EG_NT_BUF128, ns};
     }
-    return f.tiles128 >= 512 ? NtPlan{EG_NT_BUF128, 1} : NtPlan{EG_NT_REG, 1};
+    return f.tiles128 >= 256 ? NtPlan{EG_NT_BUF128, 1} : NtPlan{EG_NT_REG, 1};
 }
 
 template <typename T, int BM, int BN, int WGM, int WGN>
@@ -1465,7 +1468,7 @@ static void tn_plan(const eg_conv* c, int* nsplit, int* rps) {
     *nsplit = cdiv(M, r);
 }
 
-bool eg_tn8_plan(const eg_conv* c, int dtype, Tn8Params& p, int* nsplit);
+bool eg_tn8_plan(const eg_conv* c, int dtype, Tn8Params& p, int* nsplit, int wgs_target);
 template <typename T> void eg_launch_tn8(const Tn8Params& p, int nsplit, hipStream_t st);
 
 /* 2: the parity-class kernel igemm_tn8 runs this weight gradient, 1: the per-tap kernel igemm_tn (profiling labels and tests) */
@@ -1473,13 +1476,13 @@ extern "C" int eg_conv_wgrad_variant(const eg_conv* c, int dtype) {
     int ns;
     Tn8Params p8;
     if (!c || check_conv(c, dtype, NEED_CIN | NEED_COUT)) return -1;
-    return eg_tn8_plan(c, dtype, p8, &ns) ? 2 : 1;
+    return eg_tn8_plan(c, dtype, p8, &ns, 0) ? 2 : 1;
 }
 
 extern "C" size_t eg_conv_wgrad_ws_bytes(const eg_conv* c, int dtype) {
     int ns, rps;
     Tn8Params p8;
-    if (c && !check_conv(c, dtype, NEED_CIN | NEED_COUT) && eg_tn8_plan(c, dtype, p8, &ns))
+    if (c && !check_conv(c, dtype, NEED_CIN | NEED_COUT) && eg_tn8_plan(c, dtype, p8, &ns, 0))      // the whole-chip target splits furthest
         return (size_t)ns * c->Cout * 16 * c->Cin * sizeof(float);
     tn_plan(c, &ns, &rps);
     return (size_t)ns * c->Cout * c->k * c->k * c->Cin * sizeof(float);
@@ -1524,14 +1527,19 @@ static void launch_tn(TnParams& p, int bnt, int bct, int nsplit, hipStream_t st)
 
 extern "C" int eg_conv_wgrad(const eg_conv* c, int dtype, const void* X, const void* dY, float* slab, int* nsplit_out,
                              eg_stream_t s) {
+    return eg_conv_wgrad_target(c, dtype, X, dY, slab, nsplit_out, 0, s);
+}
+
+extern "C" int eg_conv_wgrad_target(const eg_conv* c, int dtype, const void* X, const void* dY, float* slab, int* nsplit_out,
+                                    int wgs_target, eg_stream_t s) {
     if (int e = check_conv(c, dtype, NEED_CIN | NEED_COUT)) return e;
-    EG_REQUIRE(X && dY && slab && nsplit_out, "eg_conv_wgrad: null pointer");
+    EG_REQUIRE(X && dY && slab && nsplit_out && wgs_target >= 0, "eg_conv_wgrad: bad argument");
     const int OH = conv_out_dim(c, c->H), OW = conv_out_dim(c, c->W);
     {
         // 16-bit 4x4 / stride-2 layers with channel counts in multiples of 128: the parity-class kernel (igemm_tn8.hip), same slab layout
         Tn8Params p8;
         int ns8 = 0;
-        if (eg_tn8_plan(c, dtype, p8, &ns8)) {
+        if (eg_tn8_plan(c, dtype, p8, &ns8, wgs_target)) {
             p8.P = dY; p8.src = X; p8.slab = slab;
             if (dtype == EG_F16) eg_launch_tn8<f16_t>(p8, ns8, (hipStream_t)s);
             else eg_launch_tn8<bf16_t>(p8, ns8, (hipStream_t)s);

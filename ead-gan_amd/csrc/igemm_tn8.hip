@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512) void igemm_tn8_kernel(const Tn8Params p) {
 // host side
 // ------------------------------------------------------------------------------------------------
 // geometry + split plan; false if this convolution is not a 16-bit 4x4 / stride-2 / pad-1 layer of the supported sizes
-bool eg_tn8_plan(const eg_conv* c, int dtype, Tn8Params& p, int* nsplit) {
+bool eg_tn8_plan(const eg_conv* c, int dtype, Tn8Params& p, int* nsplit, int wgs_target) {
     static const bool enabled = [] { const char* e = getenv("EG_TN8"); return !(e && atoi(e) == 0); }();
     if (!enabled || dtype == EG_F32 || c->k != 4 || c->stride != 2 || c->pad != 1 || c->up != 0) return false;
     if ((c->Cin % 128) != 0 || (c->Cout % 128) != 0 || (c->H & 1) || (c->W & 1)) return false;
@@ -223,7 +223,10 @@ bool eg_tn8_plan(const eg_conv* c, int dtype, Tn8Params& p, int* nsplit) {
     p.ntn = c->Cout / 128; p.ntc = c->Cin / 128;
     // one workgroup per CU (150 KiB of LDS): split m until about 256 workgroups exist, at least 4 K steps each
     const long long base = (long long)p.ntn * p.ntc * 4;
-    static const int target = [] { const char* e = getenv("EG_TN8_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+    // (wgs_target: the caller's share of the chip -- a launch forked beside the main chain's GEMMs runs the step fastest at 128: half the
+    //  slab bytes to write and reduce, and the other CUs stay with the main chain; profiles/r02_i_ab_tn8_target.txt)
+    static const int env_target = [] { const char* e = getenv("EG_TN8_TARGET"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    const int target = env_target ? env_target : (wgs_target > 0 ? wgs_target : 256);
     long long want = base >= target ? 1 : (target + base - 1) / base;
     const long long steps = M / 64;
     want = std::min(want, std::max(1LL, steps / 4));

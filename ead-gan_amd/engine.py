@@ -58,6 +58,9 @@ class Workspace:
     def __init__(self, device, splitk=True):
         self.device = device
         self._retired = []
+        # chip share hint for the weight-gradient GEMMs launched with this scratch (ops.conv_wgrad): 0 = the whole chip; a side lane's
+        # workspace says 128 workgroups, its launches run beside the main chain's GEMMs (profiles/r02_i_ab_tn8_target.txt)
+        self.wgs_target = 0
         self.slab = torch.empty(0, device=device, dtype=torch.float32)
         self.gtmp = torch.empty(0, device=device, dtype=torch.float32)
         self.small = torch.empty(0, device=device, dtype=torch.float32)
@@ -97,12 +100,16 @@ class Workspace:
         self._grow("sums", floats)
 
 
+LANE_WGS_TARGET = int(os.environ.get("EG_LANE_WGS", "128"))
+
+
 class _Lane:
     NAMES = ("slab", "gtmp", "small", "sums", "partials")
 
     def __init__(self, device, like: "Workspace"):
         self.stream = torch.cuda.Stream(device)
         self.ws = Workspace(device, splitk=False)
+        self.ws.wgs_target = LANE_WGS_TARGET
         self.like = like
         self.ensure()
 

@@ -150,7 +150,7 @@ class _GenEngine:
         ops.cast_pad(dt, self.dimg_z, self.p8, B * S * S, self.CH, 8)          # [M][1] fp32 (== NCHW with C=1) -> [M][8]
 
         def c3_wgrad(wsw):
-            ns = ops.conv_wgrad(self.c3.c, dt, self.a2, self.p8, wsw.slab)
+            ns = ops.conv_wgrad(self.c3.c, dt, self.a2, self.p8, wsw.slab, wsw.wgs_target)
             ops.wgrad_reduce(wsw.slab, ns, 8, self.CH, 64, 9, gof("conv_blocks.9.weight"))
         wgrad_side(c3_wgrad, 0)
         ops.conv_bwd_data(self.c3.c, dt, self.p8, self.c3.wp_bwd, self.da2, None)
@@ -163,7 +163,7 @@ class _GenEngine:
         bn_bwd(self.z2, self.da2, self.dz2, cb[7], 2, B * S * S, 64, ACT_LRELU, "conv_blocks.7")
 
         def c2_wgrad(wsw):
-            ns = ops.conv_wgrad(self.c2.c, dt, self.a1, self.dz2, wsw.slab)
+            ns = ops.conv_wgrad(self.c2.c, dt, self.a1, self.dz2, wsw.slab, wsw.wgs_target)
             ops.wgrad_reduce(wsw.slab, ns, 64, 64, 128, 9, gof("conv_blocks.6.weight"))
             ops.bias_grad(dt, self.dz2, B * S * S, 64, wsw.small, gof("conv_blocks.6.bias"))
         wgrad_side(c2_wgrad, 1)
@@ -174,7 +174,7 @@ class _GenEngine:
         bn_bwd(self.z1, self.da1, self.dz1, cb[3], 1, B * 4 * s * s, 128, ACT_LRELU, "conv_blocks.3")
 
         def c1_wgrad(wsw):
-            ns = ops.conv_wgrad(self.c1.c, dt, self.a0, self.dz1, wsw.slab)
+            ns = ops.conv_wgrad(self.c1.c, dt, self.a0, self.dz1, wsw.slab, wsw.wgs_target)
             ops.wgrad_reduce(wsw.slab, ns, 128, 128, 128, 9, gof("conv_blocks.2.weight"))
             ops.bias_grad(dt, self.dz1, B * 4 * s * s, 128, wsw.small, gof("conv_blocks.2.bias"))
         wgrad_side(c1_wgrad, 2)
@@ -186,7 +186,7 @@ class _GenEngine:
         hw = s * s
 
         def l1_wgrad(wsw):
-            ns = ops.conv_wgrad(self.l1.c, dt, self.inp, self.dh, wsw.slab)
+            ns = ops.conv_wgrad(self.l1.c, dt, self.inp, self.dh, wsw.slab, wsw.wgs_target)
             ops.wgrad_reduce_perm(wsw.slab, ns, self.nl1, self.nl1, self.cpad, 1, gof("l1.0.weight"), 128, hw, self.cin)
             ops.fill_f32(self.gb_perm)
             ops.bias_grad(dt, self.dh, B, self.nl1, wsw.small, self.gb_perm)

@@ -165,9 +165,10 @@ def conv_wgrad_ws_bytes(c, dtype):
     return lib().query("eg_conv_wgrad_ws_bytes", ctypes.byref(c), dtype)
 
 
-def conv_wgrad(c, dtype, X, dY, slab) -> int:
+def conv_wgrad(c, dtype, X, dY, slab, wgs_target=0) -> int:
+    """``wgs_target``: workgroups the parity-class kernel aims for (0: one per CU; 128 for launches forked beside the main chain)"""
     ns = ctypes.c_int(0)
-    args = ("eg_conv_wgrad", ctypes.byref(c), dtype, _p(X), _p(dY), _p(slab), ctypes.addressof(ns))
+    args = ("eg_conv_wgrad_target", ctypes.byref(c), dtype, _p(X), _p(dY), _p(slab), ctypes.addressof(ns), wgs_target)
     if RECORDER is not None:
         _timed("tn", c, dtype, args)
     else:

@@ -106,6 +106,11 @@ int eg_conv_wgrad_variant(const eg_conv* c, int dtype);
 size_t eg_conv_wgrad_ws_bytes(const eg_conv* c, int dtype);
 int eg_conv_wgrad(const eg_conv* c, int dtype, const void* X, const void* dY, float* slab, int* nsplit,
                   eg_stream_t s);
+/* the same with the caller's share of the chip: wgs_target = workgroups the parity-class kernel should aim for (0 = one per CU).  A
+ * launch forked onto a side stream beside the main chain's GEMMs passes 128 (half the slab to write and reduce, the other CUs stay
+ * with the main chain); never more splits than eg_conv_wgrad_ws_bytes provides for. */
+int eg_conv_wgrad_target(const eg_conv* c, int dtype, const void* X, const void* dY, float* slab, int* nsplit,
+                         int wgs_target, eg_stream_t s);
 /* grad[n][c][t] (+)= sum_split slab[split][n][t][c]  for n < n_rows (slab rows: n_slab >= n_rows);
  * C = gathered channels, T = taps.  Master layouts [Cout][Cin][k][k] / [Cin_T][Cout_T][k][k] are both [n][c][t]. */
 int eg_wgrad_reduce(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad,

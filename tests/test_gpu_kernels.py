@@ -160,7 +160,8 @@ def test_conv_wgrad_parity_class_kernel(case, dtype):
     y.backward(dy)
     c = ops.make_conv(B, H, H, Cin, Cout, 4, 2, 1)
     import ctypes
-    assert eg._lib.lib().query("eg_conv_wgrad_variant", ctypes.byref(c), dtype) == 2
+    # H = 4 (2x2 outputs: 16 images x 3x3 patch = 144 pixels per K step) is over the kernel's 136 patch slots: the per-tap kernel runs it
+    assert eg._lib.lib().query("eg_conv_wgrad_variant", ctypes.byref(c), dtype) == (1 if H == 4 else 2)
     nbytes = ops.conv_wgrad_ws_bytes(c, dtype)
     slab = torch.full((nbytes // 4,), float("nan"), device=DEV)
     ns = ops.conv_wgrad(c, dtype, nhwc(x, dtype), nhwc(dy, dtype), slab)
@@ -177,6 +178,14 @@ def test_conv_wgrad_parity_class_kernel(case, dtype):
     ops.conv_wgrad(c, dtype, nhwc(x, dtype), nhwc(dy, dtype), slab2)
     torch.cuda.synchronize()
     assert torch.equal(slab, slab2)
+    # chip-share hint of the side lanes (eg_conv_wgrad_target): fewer, longer K splits, the same gradient
+    slab3 = torch.full_like(slab, float("nan"))
+    ns3 = ops.conv_wgrad(c, dtype, nhwc(x, dtype), nhwc(dy, dtype), slab3, 16)
+    assert 1 <= ns3 <= ns
+    grad3 = torch.zeros_like(grad)
+    ops.wgrad_reduce(slab3, ns3, Cout, Cout, Cin, 16, grad3, accumulate=True)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(grad3.cpu(), got, rtol=1e-4, atol=at)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
