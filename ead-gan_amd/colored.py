@@ -75,10 +75,10 @@ class ColoredTrainer(ds.DspritesTrainer):
     """One call == one iteration of colored_dSprites/rp_color.py:365-516 (both Adams lr 2e-4, :274-280)."""
 
     def __init__(self, encoder_pxy, generator, discriminator, encoder, batch_size, dtype="f32", allreduce=None, lrs=(2e-4, 2e-4), betas=(0.5, 0.999),
-                 sync_bn=None):
-        super().__init__(encoder_pxy, generator, discriminator, encoder, batch_size, dtype, allreduce, lrs, betas, sync_bn)
+                 sync_bn=None, overlap=True):
+        super().__init__(encoder_pxy, generator, discriminator, encoder, batch_size, dtype, allreduce, lrs, betas, sync_bn, overlap)
         dev = self.img.device
-        self.tmp = torch.zeros_like(self.img)
+        self.tmp, self.tmp2 = torch.zeros_like(self.img), torch.zeros_like(self.img)
         self.gains = torch.zeros(batch_size, 3, device=dev)
 
     def _align(self):
@@ -88,11 +88,12 @@ class ColoredTrainer(ds.DspritesTrainer):
         ops.warp_affine(self.img, self.theta, self.tmp, B, 3, 64, 64)
         ops.color_scale(self.tmp, pcode, 6, 3, 0.1, True, self.align, B, 3, 64 * 64)      # :390-394
 
-    def _transform(self, code, out):
+    def _transform(self, code, out, second=False):
         B = self.B
-        ops.theta_rp(code, 7, B, self.theta)
-        ops.warp_affine(self.align, self.theta, self.tmp, B, 3, 64, 64)
-        ops.color_scale(self.tmp, code, 7, 4, 0.5, False, out, B, 3, 64 * 64)             # :415-424
+        theta, tmp = (self.theta2, self.tmp2) if second else (self.theta, self.tmp)
+        ops.theta_rp(code, 7, B, theta)
+        ops.warp_affine(self.align, theta, tmp, B, 3, 64, 64)
+        ops.color_scale(tmp, code, 7, 4, 0.5, False, out, B, 3, 64 * 64)                  # :415-424
 
     def _affine_loss(self, cont_align, cont_trans, loss, d_align, d_trans):
         ops.loss_affine_rp_color(cont_align, cont_trans, 7, 0, self.B, self.code2, 7, 1.0, loss, d_align, d_trans)

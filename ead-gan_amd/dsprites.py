@@ -14,7 +14,7 @@ from torch.nn.utils import spectral_norm
 
 from . import ops
 from .celeba import IMG_GEMM, _HipModule, _require_cuda, transformation_2D      # noqa: F401
-from .engine import Arena, ConvRec, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step, parse_dtype
+from .engine import Arena, ConvRec, SideStream, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step, parse_dtype
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, EG_F32, OUT_NCHW_F32
 from .trunk import Head, TrunkEngine
 
@@ -111,9 +111,9 @@ class _TrunkModule(_HipModule):
         cb = self.conv_block
         return [cb[i] for i in (0, 2, 4, 6)], [f"conv_block.{i}" for i in (0, 2, 4, 6)]
 
-    def engine(self, B) -> TrunkEngine:
+    def engine(self, B, slot=0) -> TrunkEngine:
         self.arena
-        key = (B, self.compute_dtype)
+        key = (B, self.compute_dtype) if slot == 0 else (B, self.compute_dtype, slot)
         if key not in self._engines:
             convs, names = self._convs()
             fcs, fnames = self._fcs()
@@ -324,9 +324,11 @@ class Generator(_HipModule):
         self.fc2 = nn.Sequential(nn.Linear(128, 64 * 4 * 4), nn.ReLU())
         self._init_engine_state(dtype)
 
-    def engine(self, B) -> _GenEngine:
+    def engine(self, B, slot=0) -> _GenEngine:
+        """``slot``: independent engines of one batch size (own activations and panels): the trainer's two generator forwards of an
+        iteration run on different chains"""
         self.arena
-        key = (B, self.compute_dtype)
+        key = (B, self.compute_dtype) if slot == 0 else (B, self.compute_dtype, slot)
         if key not in self._engines:
             self._engines[key] = _GenEngine(self, B, self.compute_dtype)
         return self._engines[key]
@@ -571,16 +573,28 @@ class DspritesTrainer:
     Dead work removed: Encoder_pxy backward, the second (identical) alignment pass, D weight gradients in the joint step."""
 
     def __init__(self, encoder_pxy, generator, discriminator, encoder, batch_size, dtype="f32", allreduce=None, lrs=(2e-4, 1e-4), betas=(0.5, 0.999),
-                 sync_bn=None):
-        """``sync_bn`` (a dp.SyncBN): the generator's three BatchNorm layers use the statistics of the global batch."""
+                 sync_bn=None, overlap=True):
+        """``sync_bn`` (a dp.SyncBN): the generator's three BatchNorm layers use the statistics of the global batch.
+        ``overlap``: the iteration runs as two chains (see _step_body); single-process only -- with ``allreduce`` / ``sync_bn`` the
+        collectives stay on one stream and the serial body runs."""
         self.P, self.G, self.D, self.E, self.B = encoder_pxy, generator, discriminator, encoder, batch_size
         self.sync_bn = sync_bn
+        self.overlap = bool(overlap) and allreduce is None and sync_bn is None
         dt = parse_dtype(dtype)
         for m in (encoder_pxy, generator, discriminator, encoder):
             m.set_compute_dtype(dt)
         B = batch_size
-        self.pe, self.ge, self.de, self.ee = encoder_pxy.engine(B), generator.engine(B), discriminator.engine(B), encoder.engine(B)
+        self.pe, self.ge, self.de = encoder_pxy.engine(B), generator.engine(B), discriminator.engine(B)
         dev = generator.arena.flat.device
+        if self.overlap:
+            # second chain: own stream, own scratch (split-K scratch included), own engines -- the encoder, and a second generator engine
+            # for the joint step's forward (and backward), so that it does not wait for the D step to release the first one's buffers
+            self.ws2 = Workspace(dev, register=False)
+            self.chain = torch.cuda.Stream(dev)
+            with Workspace.scope(self.ws2):
+                self.ee, self.ge2 = encoder.engine(B, slot=1), generator.engine(B, slot=1)
+        else:
+            self.ee, self.ge2 = encoder.engine(B), self.ge
         self.allreduce, self.lr, self.betas = allreduce, lrs, betas
         ga, da, ea = generator.arena, discriminator.arena, encoder.arena
         z = lambda *n: torch.zeros(*n, device=dev, dtype=torch.float32)
@@ -591,7 +605,7 @@ class DspritesTrainer:
         C = generator.channels
         self.nc, self.cd = generator.n_classes, generator.code_dim
         self.img = z(B, C, 64, 64)
-        self.theta = z(B, 2, 3)
+        self.theta, self.theta2 = z(B, 2, 3), z(B, 2, 3)
         self.align, self.trans1, self.trans2 = z(B, C, 64, 64), z(B, C, 64, 64), z(B, C, 64, 64)
         self.dimg = z(B, C, 64, 64)
         self.dout_d = z(2 * B, 1)
@@ -604,6 +618,65 @@ class DspritesTrainer:
         ops.adam_step(arena.flat, arena.grad, m, v, arena.numel, lr, self.betas[0], self.betas[1], 1e-8, self.steps[slot:slot + 1], tick)
 
     def _step_body(self):
+        """One iteration as TWO chains.  These networks are small (0.5 GFLOP per image): the step is a chain of ~200 launches of a few
+        microseconds each, bound by launch latency, not by the chip -- so independent parts run side by side:
+          main chain : align -> G(code1) -> D step (D forward x2, loss, backward, Adam, re-pack) -> D(gen2) -> d(img) through D
+          2nd chain  : G(code2) [second generator engine, behind G(code1): BatchNorm running statistics keep the reference's order]
+                       -> transform(code2) -> E forward x3 -> info / affine / relative-category losses -> E backward -> d(img) through E
+          joined     : d(img) sum -> G backward -> Adam(G), Adam(E) -> re-pack.
+        The joint step's generator and encoder passes read only G and E, which the D step does not touch (rp.py:404-482).  Same kernels
+        on the same operands as the serial body: bit-identical results (tests/test_gpu_dsprites.py)."""
+        if not self.overlap:
+            return self._step_body_serial()
+        B, nc, cd = self.B, self.nc, self.cd
+        ge, ge2, de, ee = self.ge, self.ge2, self.de, self.ee
+        ga, da, ea = self.G.arena, self.D.arena, self.E.arena
+        L = self.losses
+        mark = SideStream.mark
+        main, chain = torch.cuda.current_stream(), self.chain
+        ops.fill_f32(L)
+        self._align()                                                                        # :374-377
+        gen = ge.forward(self.onehot1, self.code1)
+        chain.wait_event(mark())
+        with torch.cuda.stream(chain), self.ws2.active():
+            ops.fill_f32(ga.grad)
+            ops.fill_f32(ea.grad)
+            gen2 = ge2.forward(self.onehot2, self.code2)
+            e_gen2 = mark()
+            self._transform(self.code2, self.trans2, second=True)
+            eo = ee.forward([gen2, self.align, self.trans2])
+            cat, cont = eo["cat_layer.0"], eo["cont_layer.0"]
+            ops.fill_f32(self.d_cat)
+            ops.loss_mutual_info(cat[:B], nc, 0, nc, B, self.onehot2, nc, 0, False, 1.0, L[2:3], self.d_cat[:B])
+            ops.loss_mse(cont[:B], cd, 0, cd, B, self.code2, cd, 0.0, 1.0, L[2:3], self.d_cont[:B])
+            self._affine_loss(cont[B:2 * B], cont[2 * B:], L[3:4], self.d_cont[B:2 * B], self.d_cont[2 * B:])
+            ops.loss_mutual_info(cat[2 * B:], nc, 0, nc, B, cat[B:2 * B], nc, 0, True, 1.0, L[4:5], self.d_cat[2 * B:])
+            dimg_e = ee.backward(0, 3, {"cat_layer.0": self.d_cat, "cont_layer.0": self.d_cont}, ea.grad, need_dimg=True)
+            e_chain = mark()
+        # ---- D step (:404-419): D(trans) then D(gen.detach()) ----
+        self._transform(self.code1, self.trans1)                                             # :396-400
+        ops.fill_f32(da.grad)
+        out = de.forward([self.trans1, gen])["fc2"]
+        ops.loss_bce_sigmoid(out[:B], 1, 0, B, 1.0, 0.5, L[0:1], self.dout_d[:B])
+        ops.loss_bce_sigmoid(out[B:], 1, 0, B, 0.0, 0.5, L[0:1], self.dout_d[B:])
+        de.backward(0, 2, {"fc2": self.dout_d}, da.grad)
+        self._adam(da, self.mD, self.vD, self.lr[0], 0, True)
+        de.repack()
+        # ---- joint step (:424-482): the generator's adversarial term needs the UPDATED discriminator ----
+        main.wait_event(e_gen2)
+        g_fake = de.forward([gen2])["fc2"]
+        ops.loss_bce_sigmoid(g_fake, 1, 0, B, 1.0, 1.0, L[1:2], self.dout_d[:B])
+        dimg_d = de.backward(0, 1, {"fc2": self.dout_d[:B]}, da.grad, need_wgrad=False, need_dimg=True)
+        main.wait_event(e_chain)
+        ops.add_f32(self.dimg, dimg_e, dimg_d)
+        ge2.backward(self.dimg, ga.grad)
+        self._adam(ga, self.miG, self.viG, self.lr[1], 1, True)
+        self._adam(ea, self.miE, self.viE, self.lr[1], 1, False)
+        ge.repack()
+        ge2.repack()
+        ee.repack()
+
+    def _step_body_serial(self):
         B, nc, cd = self.B, self.nc, self.cd
         pe, ge, de, ee = self.pe, self.ge, self.de, self.ee
         ga, da, ea = self.G.arena, self.D.arena, self.E.arena
@@ -661,10 +734,12 @@ class DspritesTrainer:
         ops.theta_pxy_align_inv(pcode, pcode.shape[1], B, self.theta)
         ops.warp_affine(self.img, self.theta, self.align, B, C, 64, 64)
 
-    def _transform(self, code, out):
+    def _transform(self, code, out, second=False):
+        """``second``: called from the second chain -- its own theta scratch"""
         B, C = self.B, self.G.channels
-        ops.theta_rp(code, self.cd, B, self.theta)
-        ops.warp_affine(self.align, self.theta, out, B, C, 64, 64)
+        theta = self.theta2 if second else self.theta
+        ops.theta_rp(code, self.cd, B, theta)
+        ops.warp_affine(self.align, theta, out, B, C, 64, 64)
 
     def _affine_loss(self, cont_align, cont_trans, loss, d_align, d_trans):
         ops.loss_affine_rp(cont_align, cont_trans, self.cd, 0, self.B, self.code2, self.cd, 1.0, loss, d_align, d_trans)

@@ -2,6 +2,7 @@
 workspace, and conv-layer records (geometry + packed weight panels) over the C ABI in :mod:`ops`."""
 from __future__ import annotations
 
+import contextlib
 import os
 
 import torch
@@ -55,7 +56,8 @@ class Workspace:
 
     _per_device = {}
 
-    def __init__(self, device, splitk=True):
+    def __init__(self, device, splitk=True, register=True):
+        """``register=False``: a second chain's private workspace (own split-K scratch too) -- it does not become the device default"""
         self.device = device
         self._retired = []
         # chip share hint for the weight-gradient GEMMs launched with this scratch (ops.conv_wgrad): 0 = the whole chip; a side lane's
@@ -69,10 +71,35 @@ class Workspace:
         # split-K partial tiles of the NT kernel: the planner splits up to ~2x512 tiles of 128x128 fp32 (64 KiB each)
         if splitk:
             self.splitk = torch.empty(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)
-            ops.set_splitk_workspace(self.splitk)
+            if register:
+                ops.set_splitk_workspace(self.splitk)
+
+    _scoped = None
+
+    @classmethod
+    @contextlib.contextmanager
+    def scope(cls, ws: "Workspace"):
+        """engines built inside take ``ws`` as their scratch (a chain that runs beside the main one must not share its scratch)"""
+        prev, cls._scoped = cls._scoped, ws
+        try:
+            yield ws
+        finally:
+            cls._scoped = prev
+
+    @contextlib.contextmanager
+    def active(self):
+        """launches enqueued inside split K into THIS workspace's scratch (ops.epilogue's default), not the device default"""
+        prev = ops.SPLITK_OVERRIDE
+        ops.SPLITK_OVERRIDE = self.splitk
+        try:
+            yield self
+        finally:
+            ops.SPLITK_OVERRIDE = prev
 
     @classmethod
     def get(cls, device) -> "Workspace":
+        if cls._scoped is not None:
+            return cls._scoped
         key = (device.type, device.index)
         if key not in cls._per_device:
             cls._per_device[key] = cls(device)

@@ -47,6 +47,7 @@ def make_conv(B, H, W, Cin, Cout, k, stride, pad, up=0) -> EgConv:
 
 # scratch lent to every conv launch for split-K (engine.Workspace owns and sizes it while engines are built)
 SPLITK_WS = {}
+SPLITK_OVERRIDE = None          # set while a second chain enqueues its launches (engine.Workspace.active)
 
 
 def set_splitk_workspace(t):
@@ -68,7 +69,7 @@ def epilogue(bias=None, bias_mod=0, sigma=None, act=ACT_NONE, slope=0.0, mask=No
     tensor lent for K splits (default: the device's registered workspace; None = never split)."""
     ws = splitk_ws
     if isinstance(ws, str):
-        ws = SPLITK_WS.get(torch.cuda.current_device()) if SPLITK_WS else None
+        ws = SPLITK_OVERRIDE if SPLITK_OVERRIDE is not None else (SPLITK_WS.get(torch.cuda.current_device()) if SPLITK_WS else None)
     return EgEpilogue(_p(bias), bias_mod, _p(sigma), act, slope, _p(mask), mask_act, mask_slope, out_mode, sigma_rows,
                       _p(ws), ws.numel() * ws.element_size() if ws is not None else 0, nt_variant, nt_splitk)
 

@@ -173,11 +173,13 @@ def test_train_step_bf16_tracks_oracle():
 
 
 def test_graph_replay_equals_eager():
+    """eager two-chain step == its hipGraph replay == the serial (one stream) body, bit for bit: losses and parameters after 3 steps"""
     B = 8
     res = []
-    for capture in (False, True):
+    for capture, overlap in ((False, True), (True, True), (False, False)):
         orc, P, G, D, E = build(7, "f32")
-        tr = eg.dsprites.DspritesTrainer(P, G, D, E, B, dtype="f32")
+        tr = eg.dsprites.DspritesTrainer(P, G, D, E, B, dtype="f32", overlap=overlap)
+        assert tr.overlap == overlap
         rng = np.random.RandomState(1)
         sprites = do.synthetic_sprites(B, seed=5).to(DEV)
         out = []
@@ -187,5 +189,8 @@ def test_graph_replay_equals_eager():
                 tr.capture()
             out.append(tr.step_resident().clone())
         torch.cuda.synchronize()
-        res.append(torch.stack(out).cpu())
-    assert torch.equal(res[0], res[1])
+        res.append((torch.stack(out).cpu(), G.arena.flat.clone().cpu(), D.arena.flat.clone().cpu(), E.arena.flat.clone().cpu(),
+                    G.state_dict()["conv_block.1.running_mean"].clone().cpu()))
+    for r in res[1:]:
+        for a, b in zip(r, res[0]):
+            assert torch.equal(a, b)
