@@ -5,6 +5,7 @@ entry :class:`DspritesTrainer` (loop body rp.py:365-482).  torch modules are par
 """
 from __future__ import annotations
 
+import os
 import argparse
 
 import numpy as np
@@ -273,14 +274,26 @@ class _GenEngine:
             ops.conv_bwd_data(self.l4.c, dt, x, self.l4.wp_bwd, self.img, ops.epilogue(bias=cb[9].bias, act=ACT_SIGMOID, out_mode=OUT_NCHW_F32))
         return self.img
 
-    def backward(self, dimg, grad, sync=None):
+    def backward(self, dimg, grad, sync=None, side=None):
+        """``side`` (engine.SideStream): the weight- / bias-gradient chains run on side lanes; the caller joins them before reading ``grad``"""
         dt, B, g, ws = self.dtype, self.B, self.gen, self.ws
         cb = g.conv_block
         gof = lambda name: g.arena.grad_of(name, grad)
+        nlane = [0]
+
+        def wgrad_side(fn):
+            if side is None:
+                fn(ws)
+            else:
+                side.defer(nlane[0], fn)
+                nlane[0] += 1
         ops.act_grad_mul_bias_nchw(dimg, self.img, self.dimg_z, B, self.CH, 64 * 64, ACT_SIGMOID, 0.0, ws.small, gof("conv_block.9.bias"))
         ops.im2col_img(dt, self.dimg_z, self.patches, B, self.CH, 64, 64, 4, 2, 1, self.kp)
-        ns = ops.conv_wgrad(self.l4p.c, dt, self.patches, self.a[2], ws.slab)
-        ops.wgrad_reduce_perm(ws.slab, ns, 64, 64, self.kp, 1, gof("conv_block.9.weight"), 0, 0, self.k0)
+
+        def l4_wgrad(wsw):
+            ns = ops.conv_wgrad(self.l4p.c, dt, self.patches, self.a[2], wsw.slab, wsw.wgs_target)
+            ops.wgrad_reduce_perm(wsw.slab, ns, 64, 64, self.kp, 1, gof("conv_block.9.weight"), 0, 0, self.k0)
+        wgrad_side(l4_wgrad)
         ops.conv_fwd(self.l4p.c, dt, self.patches, self.l4p.wp_fwd, self.da[2], None)
         for i, idx in ((2, 6), (1, 3), (0, 0)):
             r = self.mid[i]
@@ -289,24 +302,33 @@ class _GenEngine:
             bn_train_backward(dt, self.z[i], self.da[i], self.dz[i], M, 64, bn, self.mean[i], self.invstd[i], ACT_RELU, 0.0,
                               gof(f"conv_block.{idx + 1}.weight"), gof(f"conv_block.{idx + 1}.bias"), ws, sync, self.sync_scratch.sums[i])
             x_in = self.a[i - 1] if i > 0 else self.h
-            ns = ops.conv_wgrad(r.c, dt, self.dz[i], x_in, ws.slab)
-            ops.wgrad_reduce(ws.slab, ns, 64, 64, 64, 16, gof(f"conv_block.{idx}.weight"))
-            ops.bias_grad(dt, self.dz[i], M, 64, ws.small, gof(f"conv_block.{idx}.bias"))
+
+            def mid_wgrad(wsw, i=i, idx=idx, r=r, M=M, x_in=x_in):
+                ns = ops.conv_wgrad(r.c, dt, self.dz[i], x_in, wsw.slab, wsw.wgs_target)
+                ops.wgrad_reduce(wsw.slab, ns, 64, 64, 64, 16, gof(f"conv_block.{idx}.weight"))
+                ops.bias_grad(dt, self.dz[i], M, 64, wsw.small, gof(f"conv_block.{idx}.bias"))
+            wgrad_side(mid_wgrad)
             if i > 0:
                 ops.conv_fwd(r.c, dt, self.dz[i], r.wp_fwd, self.da[i - 1], None)
             else:                                    # into the ReLU output of fc2: mask fused into the epilogue
                 ops.conv_fwd(r.c, dt, self.dz[i], r.wp_fwd, self.dh, ops.epilogue(mask=self.h, mask_act=ACT_RELU))
+
         # fc2: dW[f][k] = sum_b dh[b][n'(f)] a1[b][k]
-        ns = ops.conv_wgrad(self.f2.c, dt, self.a1, self.dh, ws.slab)
-        ops.wgrad_reduce_perm(ws.slab, ns, 1024, 1024, 128, 1, gof("fc2.0.weight"), 64, 16, 0)
-        ops.fill_f32(self.gb2_perm)
-        ops.bias_grad(dt, self.dh, B, 1024, ws.small, self.gb2_perm)
-        ops.gather_add(gof("fc2.0.bias"), self.gb2_perm, 1024, 16, 1, 64)
+        def fc2_wgrad(wsw):
+            ns = ops.conv_wgrad(self.f2.c, dt, self.a1, self.dh, wsw.slab, wsw.wgs_target)
+            ops.wgrad_reduce_perm(wsw.slab, ns, 1024, 1024, 128, 1, gof("fc2.0.weight"), 64, 16, 0)
+            ops.fill_f32(self.gb2_perm)
+            ops.bias_grad(dt, self.dh, B, 1024, wsw.small, self.gb2_perm)
+            ops.gather_add(gof("fc2.0.bias"), self.gb2_perm, 1024, 16, 1, 64)
+        wgrad_side(fc2_wgrad)
         ops.conv_bwd_data(self.f2.c, dt, self.dh, self.f2.wp_bwd, self.dz1, ops.epilogue(mask=self.a1, mask_act=ACT_RELU))
+
         # fc1
-        ns = ops.conv_wgrad(self.f1.c, dt, self.inp, self.dz1, ws.slab)
-        ops.wgrad_reduce_perm(ws.slab, ns, 128, 128, self.cpad, 1, gof("fc1.0.weight"), 0, 0, self.cin)
-        ops.bias_grad(dt, self.dz1, B, 128, ws.small, gof("fc1.0.bias"))
+        def fc1_wgrad(wsw):
+            ns = ops.conv_wgrad(self.f1.c, dt, self.inp, self.dz1, wsw.slab, wsw.wgs_target)
+            ops.wgrad_reduce_perm(wsw.slab, ns, 128, 128, self.cpad, 1, gof("fc1.0.weight"), 0, 0, self.cin)
+            ops.bias_grad(dt, self.dz1, B, 128, wsw.small, gof("fc1.0.bias"))
+        wgrad_side(fc1_wgrad)
 
 
 class Generator(_HipModule):
@@ -591,6 +613,9 @@ class DspritesTrainer:
             # for the joint step's forward (and backward), so that it does not wait for the D step to release the first one's buffers
             self.ws2 = Workspace(dev, register=False)
             self.chain = torch.cuda.Stream(dev)
+            nl = int(os.environ.get("EG_SMALL_LANES", "0"))     # weight-gradient side lanes: slower here (profiles/r02_n_ab_small_lanes.txt), off
+            self.side_a = SideStream(dev, Workspace.get(dev), lanes=nl) if nl else None     # weight-gradient lanes of the main chain
+            self.side_b = SideStream(dev, self.ws2, lanes=nl) if nl else None               # ... and of the second chain
             with Workspace.scope(self.ws2):
                 self.ee, self.ge2 = encoder.engine(B, slot=1), generator.engine(B, slot=1)
         else:
@@ -634,6 +659,8 @@ class DspritesTrainer:
         L = self.losses
         mark = SideStream.mark
         main, chain = torch.cuda.current_stream(), self.chain
+        sa, sb = self.side_a, self.side_b
+        join = lambda sd: sd.join_lanes() if sd is not None else None
         ops.fill_f32(L)
         self._align()                                                                        # :374-377
         gen = ge.forward(self.onehot1, self.code1)
@@ -651,15 +678,30 @@ class DspritesTrainer:
             ops.loss_mse(cont[:B], cd, 0, cd, B, self.code2, cd, 0.0, 1.0, L[2:3], self.d_cont[:B])
             self._affine_loss(cont[B:2 * B], cont[2 * B:], L[3:4], self.d_cont[B:2 * B], self.d_cont[2 * B:])
             ops.loss_mutual_info(cat[2 * B:], nc, 0, nc, B, cat[B:2 * B], nc, 0, True, 1.0, L[4:5], self.d_cat[2 * B:])
-            dimg_e = ee.backward(0, 3, {"cat_layer.0": self.d_cat, "cont_layer.0": self.d_cont}, ea.grad, need_dimg=True)
-            e_chain = mark()
+            dimg_e = ee.backward(0, 3, {"cat_layer.0": self.d_cat, "cont_layer.0": self.d_cont}, ea.grad, need_dimg=True, side=sb)
+            e_dimg = mark()
+            evs = {}
+
+            def update_e(_ws):
+                # optimizer_info's step counter is shared by G and E: it ticks here, G's update (main chain, behind this event) reads it
+                self._adam(ea, self.miE, self.viE, self.lr[1], 1, True)
+                ee.repack()
+                evs["chain"] = mark()
+            if sb is not None:
+                # behind the encoder's weight-gradient lanes, on the lanes' optimizer stream: the second chain itself must never wait for
+                # its lanes (hipStreamEndCapture crashes on a stream-level cycle that does not pass through the capture's origin stream)
+                sb.defer_opt(update_e)
+            else:
+                update_e(None)
+            e_chain = evs["chain"]
         # ---- D step (:404-419): D(trans) then D(gen.detach()) ----
         self._transform(self.code1, self.trans1)                                             # :396-400
         ops.fill_f32(da.grad)
         out = de.forward([self.trans1, gen])["fc2"]
         ops.loss_bce_sigmoid(out[:B], 1, 0, B, 1.0, 0.5, L[0:1], self.dout_d[:B])
         ops.loss_bce_sigmoid(out[B:], 1, 0, B, 0.0, 0.5, L[0:1], self.dout_d[B:])
-        de.backward(0, 2, {"fc2": self.dout_d}, da.grad)
+        de.backward(0, 2, {"fc2": self.dout_d}, da.grad, side=sa)
+        join(sa)
         self._adam(da, self.mD, self.vD, self.lr[0], 0, True)
         de.repack()
         # ---- joint step (:424-482): the generator's adversarial term needs the UPDATED discriminator ----
@@ -667,14 +709,14 @@ class DspritesTrainer:
         g_fake = de.forward([gen2])["fc2"]
         ops.loss_bce_sigmoid(g_fake, 1, 0, B, 1.0, 1.0, L[1:2], self.dout_d[:B])
         dimg_d = de.backward(0, 1, {"fc2": self.dout_d[:B]}, da.grad, need_wgrad=False, need_dimg=True)
-        main.wait_event(e_chain)
+        main.wait_event(e_dimg)
         ops.add_f32(self.dimg, dimg_e, dimg_d)
-        ge2.backward(self.dimg, ga.grad)
-        self._adam(ga, self.miG, self.viG, self.lr[1], 1, True)
-        self._adam(ea, self.miE, self.viE, self.lr[1], 1, False)
+        ge2.backward(self.dimg, ga.grad, side=sa)
+        join(sa)
+        main.wait_event(e_chain)
+        self._adam(ga, self.miG, self.viG, self.lr[1], 1, False)
         ge.repack()
         ge2.repack()
-        ee.repack()
 
     def _step_body_serial(self):
         B, nc, cd = self.B, self.nc, self.cd

@@ -240,9 +240,17 @@ class TrunkEngine:
         return {h.name: self.outs[h.name][t0 * B:(t0 + T) * B] for h in self.heads if h.compute}
 
     # ------------------------------------------------------------------------------------------------------------------
-    def _bwd_pass(self, t0, T, douts, grad, need_wgrad, need_dimg):
+    def _bwd_pass(self, t0, T, douts, grad, need_wgrad, need_dimg, side=None):
         dt, B, ws, L = self.dtype, self.B, self.ws, self.L
         gof = lambda name: self.owner.arena.grad_of(name, grad)
+        nlane = [0]
+
+        def wgrad_side(fn):                              # a layer's weight- / bias-gradient chain: on a side lane when there is one
+            if side is None:
+                fn(ws)
+            else:
+                side.defer(nlane[0], fn)
+                nlane[0] += 1
         g = self.geo[T]
         kpad = self.head_rec.Kpad_fwd
         rows = T * B
@@ -257,17 +265,19 @@ class TrunkEngine:
         nf = len(self.fcs)
         x = self.fa[-1][t0 * B:] if nf else self._inp(L, t0)
         if need_wgrad:
-            ns = ops.conv_wgrad(g["headw"], dt, x, dys_t, ws.slab)
-            tk = self.head_hk * self.head_hk
-            for h in gheads:
-                if not h.grad:
-                    continue
-                slab = ws.slab[h.off * self.K:]
-                if h.sn:
-                    ops.wgrad_reduce_rank1(slab, ns, 32, h.N, self.head_C, tk, gof(h.name + ".weight_orig"), T, self.hcoef[h.name],
-                                           self.hu[h.name][t0:], self.hv[h.name][t0:])
-                else:
-                    ops.wgrad_reduce(slab, ns, 32, h.N, self.head_C, tk, gof(h.name + ".weight"))
+            def head_wgrad(wsw):
+                ns = ops.conv_wgrad(g["headw"], dt, x, dys_t, wsw.slab, wsw.wgs_target)
+                tk = self.head_hk * self.head_hk
+                for h in gheads:
+                    if not h.grad:
+                        continue
+                    slab = wsw.slab[h.off * self.K:]
+                    if h.sn:
+                        ops.wgrad_reduce_rank1(slab, ns, 32, h.N, self.head_C, tk, gof(h.name + ".weight_orig"), T, self.hcoef[h.name],
+                                               self.hu[h.name][t0:], self.hv[h.name][t0:])
+                    else:
+                        ops.wgrad_reduce(slab, ns, 32, h.N, self.head_C, tk, gof(h.name + ".weight"))
+            wgrad_side(head_wgrad)
         last = L - 1
         if nf:
             ops.dense_small_bwd(dt, dys32, self.head_rec.wp_fwd, self.fa[-1][t0 * B:], self.fdz[-1][t0 * B:], rows, self.K, kpad, self.ncomb,
@@ -276,11 +286,14 @@ class TrunkEngine:
                 f, nm = self.fcs[i], self.fc_names[i]
                 xin = self.fa[i - 1][t0 * B:] if i > 0 else self._inp(L, t0)
                 if need_wgrad:
-                    ops.bias_grad_sn(dt, self.fdz[i][t0 * B:], self.fa[i][t0 * B:], f.bias, rows, self.fN[i], B, self.fsigma[i][t0:], self.slope, ws.small,
-                                     gof(nm + ".bias"), self.fcoef[i])
-                    ns = ops.conv_wgrad(g["fc"][i], dt, xin, self.fdz[i][t0 * B:], ws.slab)
-                    C, tk = (self.W[-1], self.hk * self.hk) if i == 0 else (self.fK[i], 1)
-                    ops.wgrad_reduce_rank1(ws.slab, ns, self.fN[i], self.fN[i], C, tk, gof(nm + ".weight_orig"), T, self.fcoef[i], self.fu[i][t0:], self.fv[i][t0:])
+                    def fc_wgrad(wsw, i=i, f=f, nm=nm, xin=xin):
+                        ops.bias_grad_sn(dt, self.fdz[i][t0 * B:], self.fa[i][t0 * B:], f.bias, rows, self.fN[i], B, self.fsigma[i][t0:], self.slope,
+                                         wsw.small, gof(nm + ".bias"), self.fcoef[i])
+                        ns = ops.conv_wgrad(g["fc"][i], dt, xin, self.fdz[i][t0 * B:], wsw.slab, wsw.wgs_target)
+                        C, tk = (self.W[-1], self.hk * self.hk) if i == 0 else (self.fK[i], 1)
+                        ops.wgrad_reduce_rank1(wsw.slab, ns, self.fN[i], self.fN[i], C, tk, gof(nm + ".weight_orig"), T, self.fcoef[i], self.fu[i][t0:],
+                                               self.fv[i][t0:])
+                    wgrad_side(fc_wgrad)
                 if i > 0:
                     ops.conv_bwd_data(g["fc"][i], dt, self.fdz[i][t0 * B:], self.frec[i].wp_bwd, self.fdz[i - 1][t0 * B:],
                                       ops.epilogue(sigma=self.fsigma[i - 1][t0:], sigma_rows=B, mask=self.fa[i - 1][t0 * B:], mask_act=ACT_LRELU, mask_slope=self.slope))
@@ -303,12 +316,13 @@ class TrunkEngine:
                                 ws.sums, ws.small, ACT_LRELU, self.slope, self.sigma[i][t0:t0 + 1])
             geo = g["l0p"] if i == 0 else g["mid"][i - 1]
             if need_wgrad:
-                nm = self.conv_names[i]
-                ops.bias_grad_sn(dt, self._sl(self.dz[i], t0), self._sl(self.a[i], t0), self.convs[i].bias, T * self.rows(i), self.W[i], self.rows(i),
-                                 self.sigma[i][t0:], self.slope, ws.small, gof(nm + ".bias"), self.coef[i])
-                ns = ops.conv_wgrad(geo, dt, self._inp(i, t0), self._sl(self.dz[i], t0), ws.slab)
-                ops.wgrad_reduce_rank1(ws.slab, ns, self.W[i], self.W[i], self.cin[i], self.taps if i > 0 else 1, gof(nm + ".weight_orig"), T, self.coef[i],
-                                       self.u[i][t0:], self.v[i][t0:], self.k0 if i == 0 else 0)
+                def layer_wgrad(wsw, i=i, geo=geo, nm=self.conv_names[i]):
+                    ops.bias_grad_sn(dt, self._sl(self.dz[i], t0), self._sl(self.a[i], t0), self.convs[i].bias, T * self.rows(i), self.W[i], self.rows(i),
+                                     self.sigma[i][t0:], self.slope, wsw.small, gof(nm + ".bias"), self.coef[i])
+                    ns = ops.conv_wgrad(geo, dt, self._inp(i, t0), self._sl(self.dz[i], t0), wsw.slab, wsw.wgs_target)
+                    ops.wgrad_reduce_rank1(wsw.slab, ns, self.W[i], self.W[i], self.cin[i], self.taps if i > 0 else 1, gof(nm + ".weight_orig"), T,
+                                           self.coef[i], self.u[i][t0:], self.v[i][t0:], self.k0 if i == 0 else 0)
+                wgrad_side(layer_wgrad)
             if i > 0:
                 if self.bns[i - 1] is not None:
                     ops.conv_bwd_data(geo, dt, self._sl(self.dz[i], t0), self.mid[i - 1].wp_bwd, self._sl(self.dyb[i - 1], t0), None)
@@ -325,14 +339,15 @@ class TrunkEngine:
             return self.dimg
         return None
 
-    def backward(self, t0, T, douts, grad, need_wgrad=True, need_dimg=False):
+    def backward(self, t0, T, douts, grad, need_wgrad=True, need_dimg=False, side=None):
         """douts: {head name: d(loss)/d(head output) [T*B, N] fp32} for every computed head (zeros where a head carries no
-        loss).  Accumulates into flat ``grad``; returns d(loss)/d(img) of tape t0 if ``need_dimg``."""
+        loss).  Accumulates into flat ``grad``; returns d(loss)/d(img) of tape t0 if ``need_dimg``.  ``side`` (engine.SideStream): each
+        layer's weight- / bias-gradient chain runs on a side lane; the caller joins the lanes before it reads ``grad``."""
         if self.has_bn and T > 1:
             dimg = None
             for kk in range(T):
                 sub = {k: v[kk * self.B:(kk + 1) * self.B] for k, v in douts.items()}
-                r = self._bwd_pass(t0 + kk, 1, sub, grad, need_wgrad, need_dimg and kk == 0)
+                r = self._bwd_pass(t0 + kk, 1, sub, grad, need_wgrad, need_dimg and kk == 0, side)
                 dimg = r if kk == 0 else dimg
             return dimg
-        return self._bwd_pass(t0, T, douts, grad, need_wgrad, need_dimg)
+        return self._bwd_pass(t0, T, douts, grad, need_wgrad, need_dimg, side)
