@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=5)
     ap.add_argument("--force-dist", action="store_true", help="initialise a process group and run the all-reduce hooks even with one rank "
                                                               "(rehearses the N>1 code path, incl. RCCL capture into the hipGraph, on one GPU)")
-    ap.add_argument("--resident-inputs", action="store_true", help="CelebA: replay ONE pre-loaded batch instead of drawing every batch on the device "
+    ap.add_argument("--resident-inputs", action="store_true", help="replay ONE pre-loaded batch instead of drawing every batch on the device "
                     "inside the captured step (default: uint8 dataset in HBM + counter-based z / code / labels, i.e. the timed iteration includes "
                     "the whole input pipeline and every step sees new inputs)")
     ap.add_argument("--sync-bn", action="store_true", help="data parallel: BatchNorm statistics over the global batch (dp.SyncBN); default per-rank")
@@ -157,12 +157,19 @@ def cpu_baseline(B, steps, warm=2):
             "sample": f"median of {steps} timed iterations of the same workload (B={B}, fp32, torch-CPU oracle) after {warm} warm-ups"}
 
 
+def synthetic_sprites(n, dev, gen):
+    """uint8 {0,1} [n,64,64]: one filled axis-aligned box per image (stands in for the dSprites .npz, which is not in the container)"""
+    r = lambda lo, hi: torch.randint(lo, hi, (n, 1, 1), device=dev, generator=gen)
+    cy, cx, hh, hw = r(20, 44), r(20, 44), r(4, 12), r(4, 12)
+    yy, xx = torch.arange(64, device=dev).view(1, 64, 1), torch.arange(64, device=dev).view(1, 1, 64)
+    return (((yy - cy).abs() < hh) & ((xx - cx).abs() < hw)).to(torch.uint8)
+
+
 def main_mnist(a, eg, rank, world, local, dev):
     """secondary line: MNIST/EAD-GAN_rpqmnxy.py iteration (1.403 GFLOP/img necessary); launch-bound, not MFMA-bound."""
-    from oracle import mnist_oracle as mo          # only for the seeded stand-in of the frozen approximator file
     B = a.batch
     torch.manual_seed(0)
-    eg.mnist.load_approximator(mo.make_approximator(123))
+    eg.mnist.load_approximator(eg.mnist.Affine_classifier().state_dict())      # seeded stand-in of the frozen rpqmnxy_approximator.pt (not in the container)
     G, D, E = eg.mnist.Generator(dtype=a.dtype).to(dev), eg.mnist.Discriminator(dtype=a.dtype).to(dev), eg.mnist.Encoder(dtype=a.dtype).to(dev)
     for m in (G, D, E):
         m.apply(eg.mnist.weights_init_normal)
@@ -171,8 +178,12 @@ def main_mnist(a, eg, rank, world, local, dev):
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     tr.load_inputs(torch.rand((B, 1, 32, 32), device=dev, generator=g) * 2 - 1, torch.randn((B, 62), device=dev, generator=g),
                    torch.rand((B, 7), device=dev, generator=g) * 2 - 1, torch.randint(0, 10, (B,), device=dev, generator=g))
+    inputs = None
+    if not a.resident_inputs:                            # synthetic uint8 "dataset" resident in HBM (64k digits = 67 MB), batches drawn on the device
+        inputs = eg.mnist.DeviceInputs(torch.randint(0, 256, (65536, 1, 32, 32), device=dev, dtype=torch.uint8, generator=g), seed=1000 + rank)
+        tr.inputs = inputs
     tr.step_resident()
-    use_graph = (not a.no_graph) and capture_or_eager(tr, rank)
+    use_graph = (not a.no_graph) and capture_or_eager(tr, rank, inputs=inputs)
     for _ in range(max(a.warmup - 1, 0)):
         tr.step_resident()
     eg.dp.barrier()
@@ -191,7 +202,7 @@ def main_mnist(a, eg, rank, world, local, dev):
         peak = PEAK_F32_TFLOPS if a.dtype == "f32" else PEAK_BF16_TFLOPS
         print(json.dumps({"metric": "imgs/sec per G+D+E train step, MNIST 32x32", "value": round(ips, 1), "unit": "imgs/s", "n_gpus": world,
                           "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+                          "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic" + ("" if a.resident_inputs else " (every batch drawn on the device inside the timed step)"),
                           "config": {"workload": f"EAD-GAN MNIST 32x32x1 full train iteration (G + D + info/affine over G+E), batch {B}/GPU, "
                                                  f"{'hipGraph replay' if use_graph else 'eager launches'}", "per_gpu_batch": B, "parallelism": f"dp{world}"},
                           "whole_step_mfma_frac": round(ips / world * 1.403 / 1e3 / peak, 5), "roofline": roof, "cpu_baseline": None,
@@ -201,17 +212,16 @@ def main_mnist(a, eg, rank, world, local, dev):
 
 def main_sprites(a, eg, rank, world, local, dev):
     """secondary lines: dSprites/rp.py (0.485 GFLOP/img) and colored_dSprites/rp_color.py (0.533 GFLOP/img) iterations."""
-    from oracle import dsprites_oracle as do        # only for the seeded stand-in of the frozen Encoder_pxy checkpoint / synthetic sprites
     B, color = a.batch, a.workload == "colored"
     mod = eg.colored if color else eg.dsprites
     torch.manual_seed(0)
     P, G, D, E = mod.Encoder_pxy(dtype=a.dtype).to(dev), mod.Generator(dtype=a.dtype).to(dev), mod.Discriminator(dtype=a.dtype).to(dev), mod.Encoder(dtype=a.dtype).to(dev)
-    P.load_state_dict(do.make_encoder_pxy(654 if color else 321, ch=3 if color else 1, pxy_out=6 if color else 3))
+    # (Encoder_pxy stays at its seeded default init: a stand-in of the frozen stage-1 checkpoint encoder_pxy_*.pt, which is not in the container)
     ar = eg.dp.GradAllReduce(world, wire=a.wire) if world > 1 else None
     tr = (mod.ColoredTrainer if color else mod.DspritesTrainer)(P, G, D, E, B, dtype=a.dtype, allreduce=ar,
                                                                  sync_bn=eg.dp.SyncBN(world, rank) if (a.sync_bn and world > 1) else None)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
-    sprites = do.synthetic_sprites(B, seed=7 + rank).to(dev)
+    sprites = synthetic_sprites(B, dev, g)
     cd = 7 if color else 4
     mk = lambda: (torch.rand((B, cd), device=dev, generator=g) * 2 - 1, torch.randint(0, 3, (B,), device=dev, generator=g))
     c1, l1 = mk()
@@ -220,8 +230,12 @@ def main_sprites(a, eg, rank, world, local, dev):
         tr.load_inputs(sprites, torch.rand((B, 3), device=dev, generator=g) * 0.5 + 0.5, c1, l1, c2, l2)
     else:
         tr.load_inputs(sprites, c1, l1, c2, l2)
+    inputs = None
+    if not a.resident_inputs:                            # synthetic uint8 sprite array resident in HBM (32k sprites = 134 MB), batches drawn on the device
+        inputs = mod.DeviceInputs(synthetic_sprites(32768, dev, g), seed=1000 + rank)
+        tr.inputs = inputs
     tr.step_resident()
-    use_graph = (not a.no_graph) and capture_or_eager(tr, rank)
+    use_graph = (not a.no_graph) and capture_or_eager(tr, rank, inputs=inputs)
     for _ in range(max(a.warmup - 1, 0)):
         tr.step_resident()
     eg.dp.barrier()
@@ -241,7 +255,7 @@ def main_sprites(a, eg, rank, world, local, dev):
         gf = 0.533 if color else 0.485
         print(json.dumps({"metric": f"imgs/sec per train step, {'colored ' if color else ''}dSprites 64x64", "value": round(ips, 1), "unit": "imgs/s",
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+                          "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic" + ("" if a.resident_inputs else " (every batch drawn on the device inside the timed step)"),
                           "config": {"workload": f"EAD-GAN {'colored ' if color else ''}dSprites full train iteration (D step + joint info/affine/G step), batch {B}/GPU, "
                                                  f"{'hipGraph replay' if use_graph else 'eager launches'}", "per_gpu_batch": B, "parallelism": f"dp{world}"},
                           "whole_step_mfma_frac": round(ips / world * gf / 1e3 / peak, 5), "roofline": roof, "cpu_baseline": None,
@@ -251,13 +265,12 @@ def main_sprites(a, eg, rank, world, local, dev):
 
 def main_pxy(a, eg, rank, world, local, dev):
     """secondary line: dSprites/pxy.py (stage-1 trainer of Encoder_pxy): 2 encoder forwards + backward per image, ~0.094 GFLOP/img."""
-    from oracle import dsprites_oracle as do        # synthetic sprites only
     B = a.batch
     torch.manual_seed(0)
     P = eg.dsprites.Encoder_pxy(dtype=a.dtype).to(dev)
     tr = eg.dsprites.PxyTrainer(P, B, dtype=a.dtype, allreduce=eg.dp.GradAllReduce(world, wire=a.wire) if world > 1 else None)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
-    tr.load_inputs(do.synthetic_sprites(B, seed=7 + rank).to(dev), torch.rand((B, 3), device=dev, generator=g) * 2 - 1)
+    tr.load_inputs(synthetic_sprites(B, dev, g), torch.rand((B, 3), device=dev, generator=g) * 2 - 1)
     tr.step_resident()
     use_graph = (not a.no_graph) and capture_or_eager(tr, rank)
     for _ in range(max(a.warmup - 1, 0)):

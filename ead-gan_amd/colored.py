@@ -142,3 +142,14 @@ class PxyColorTrainer(ds.PxyTrainer):
         """img_u8 uint8 [B,64,64]; gains [B,3] ~ U(.5,1); code [B,6] ~ U(-1,1) -> {'affine_loss'}"""
         self.load_inputs(img_u8, gains, code)
         return {"affine_loss": float(self.step_resident()[0])}
+
+
+class DeviceInputs(ds.DeviceInputs):
+    """colored_dSprites/rp_color.py:363-381: sprites repeated to three channels times per-image colour gains ~ U(.5, 1) (drawn FIRST,
+    :372), then the dSprites draws (:405-446)."""
+
+    def enqueue(self, tr: "ColoredTrainer"):
+        self.draw(ops.RNG_UNIFORM, tr.gains, 0.5, 1.0, 2)
+        ops.u8_colorize(self.sprites(tr), tr.gains, tr.img, tr.B, 3, 64 * 64)
+        self.codes_and_labels(tr, 3)
+        self.tick()

@@ -15,7 +15,7 @@ from torch.nn.utils import spectral_norm
 
 from . import ops
 from .celeba import IMG_GEMM, _HipModule, _require_cuda, transformation_2D      # noqa: F401
-from .engine import Arena, ConvRec, SideStream, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step, parse_dtype
+from .engine import Arena, ConvRec, DeviceSampler, ResidentStep, SideStream, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step, parse_dtype
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, EG_F32, OUT_NCHW_F32
 from .trunk import Head, TrunkEngine
 
@@ -589,7 +589,7 @@ class PxyTrainer:
         return {"affine_loss": float(self.step_resident()[0])}
 
 
-class DspritesTrainer:
+class DspritesTrainer(ResidentStep):
     """One call == one iteration of dSprites/rp.py:365-482: D step (Adam lr 2e-4), then the joint info + affine + adversarial-G +
     relative-category step over G+E (Adam lr 1e-4).  optimizer_G of the reference is never stepped and is not created.
     Dead work removed: Encoder_pxy backward, the second (identical) alignment pass, D weight gradients in the joint step."""
@@ -798,19 +798,30 @@ class DspritesTrainer:
             oh.zero_()
             oh.scatter_(1, lab.view(-1, 1), 1.0)
 
-    def capture(self, warmup=False):
-        if warmup:
-            self._step_body()
-        return capture_step(self, self._step_body)
-
-    def step_resident(self):
-        if self.graph is not None:
-            self.graph.replay()
-        else:
-            self._step_body()
-        return self.losses
-
     def train_step(self, img_u8, code1, labels1, code2, labels2):
         self.load_inputs(img_u8, code1, labels1, code2, labels2)
         l = self.step_resident().tolist()
         return dict(d_loss=l[0], g_loss=l[1], info_loss=l[2], affine_loss=l[3], relative_cat_loss=l[4])
+
+
+class DeviceInputs(DeviceSampler):
+    """Device-side replacement of the dSprites loop's host input work (dSprites/rp.py:236-262 the uint8 sprite array + DataLoader; :389-430
+    numpy draws in the reference's order: code ~ U(-1,1), labels ~ randint, then again for the joint step).  ``dataset_u8``: uint8
+    [N,64,64] sprites with values {0,1}."""
+
+    def sprites(self, tr):
+        B = tr.B
+        batch = self.buf("sprites", (B,) + tuple(self.data.shape[1:]), torch.uint8)
+        torch.index_select(self.data, 0, self.sample_indices(B, 1), out=batch)
+        return batch
+
+    def codes_and_labels(self, tr, first_stream):
+        self.draw(ops.RNG_UNIFORM, tr.code1, -1.0, 1.0, first_stream)
+        self.labels_onehot("labels1", tr.onehot1, tr.nc, first_stream + 1)
+        self.draw(ops.RNG_UNIFORM, tr.code2, -1.0, 1.0, first_stream + 2)
+        self.labels_onehot("labels2", tr.onehot2, tr.nc, first_stream + 3)
+
+    def enqueue(self, tr: "DspritesTrainer"):
+        ops.u8_to_f32(self.sprites(tr), tr.img)
+        self.codes_and_labels(tr, 2)
+        self.tick()

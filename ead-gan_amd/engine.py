@@ -351,6 +351,73 @@ def bn_train_backward(dt, z, da, dz, M, C, bn, mean, invstd, act, slope, dgamma,
     ops.bn_bwd_from_sums(dt, z, da, dz, M, C, sums, M * sync.world, bn.weight, bn.bias, mean, invstd, act, slope, ws.small)
 
 
+class DeviceSampler:
+    """Shared part of the trainers' device-side input pipelines: a uint8 dataset resident in HBM, a device step counter and
+    counter-based draws (ops.rng_fill: reproducible per (seed, step, stream), the reference's distributions, NOT numpy's stream --
+    parity tests keep feeding host draws through ``load_inputs``).  Sampling is with replacement (the reference's DataLoader shuffles
+    without replacement inside an epoch).  Subclasses implement ``enqueue(trainer)``: fill the trainer's static input slots, then tick
+    the counter; inside ``trainer.capture(inputs=...)`` those launches are part of the iteration's hipGraph."""
+
+    def __init__(self, dataset_u8: torch.Tensor, seed: int = 0):
+        if not dataset_u8.is_cuda or dataset_u8.dtype != torch.uint8:
+            raise ValueError("dataset must be a uint8 device tensor")
+        self.data = dataset_u8.contiguous()
+        self.seed = int(seed)
+        self.step = torch.zeros(1, device=dataset_u8.device, dtype=torch.int32)
+        self._buf = {}
+
+    def buf(self, name, shape, dtype):
+        t = self._buf.get(name)
+        if t is None or tuple(t.shape) != tuple(shape):
+            t = self._buf[name] = torch.empty(shape, device=self.data.device, dtype=dtype)
+        return t
+
+    def draw(self, kind, out, a, b, stream_id):
+        ops.rng_fill(kind, out, a, b, self.seed, self.step, stream_id)
+
+    def sample_indices(self, B, stream_id=1):
+        idx = self.buf("idx", (B,), torch.int64)
+        self.draw(ops.RNG_RANDINT, idx, 0, self.data.shape[0], stream_id)
+        return idx
+
+    def labels_onehot(self, name, onehot, n_classes, stream_id):
+        lab = self.buf(name, (onehot.shape[0],), torch.int64)
+        self.draw(ops.RNG_RANDINT, lab, 0, n_classes, stream_id)
+        ops.onehot(lab, onehot, onehot.shape[0], n_classes)
+        return lab
+
+    def tick(self):
+        ops.counter_add(self.step, 1)
+
+
+class ResidentStep:
+    """capture / replay plumbing shared by the small-network trainers (``_step_body`` = one iteration on the static input slots)"""
+
+    inputs = None
+    graph = None
+
+    def _step_with_inputs(self):
+        if self.inputs is not None:
+            self.inputs.enqueue(self)
+        self._step_body()
+
+    def capture(self, warmup=False, inputs=None):
+        """Capture the iteration into one hipGraph; with ``inputs`` (a DeviceSampler of this trainer's module) the graph first draws
+        the batch on the device, so a replay is a complete loop iteration without host work."""
+        if warmup:
+            self._step_body()
+        if inputs is not None:
+            self.inputs = inputs
+        return capture_step(self, self._step_with_inputs)
+
+    def step_resident(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._step_with_inputs()
+        return self.losses
+
+
 def capture_step(trainer, body):
     """Capture ``body()`` (one whole training iteration) into a hipGraph and store it as ``trainer.graph``.  If the capture fails
     (e.g. a collective that cannot be captured) the trainer stays usable for eager launches: torch.cuda.graph's exit raises

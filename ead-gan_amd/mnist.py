@@ -15,7 +15,7 @@ from torch.nn.utils import spectral_norm
 
 from . import ops
 from .celeba import _HipModule, _require_cuda, transformation_2D      # noqa: F401  (same STN warp in both scripts)
-from .engine import (Arena, ConvRec, SideStream, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step,
+from .engine import (Arena, ConvRec, DeviceSampler, ResidentStep, SideStream, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step,
                      parse_dtype)
 from .ops import ACT_LRELU, ACT_NONE, ACT_TANH, EG_F32, OUT_NCHW_F32
 from .trunk import Head, TrunkEngine
@@ -432,7 +432,7 @@ def affine_regularizer(real_code, trans_code):
 # ================================================================================================
 # fused train-loop entry
 # ================================================================================================
-class MnistTrainer:
+class MnistTrainer(ResidentStep):
     """One call of :meth:`train_step` == one iteration of MNIST/EAD-GAN_rpqmnxy.py:340-446: LSGAN G step, D step (lr x2),
     info+affine step over G+E (lambda_cat 1, lambda_con .1, lambda_affine .1, :201-203), three Adams (:249-255)."""
 
@@ -546,22 +546,26 @@ class MnistTrainer:
         self.onehot.zero_()
         self.onehot.scatter_(1, self.labels.view(-1, 1), 1.0)
 
-    def capture(self, warmup=False):
-        if warmup:
-            self._step_body()
-        return capture_step(self, self._step_body)
-
-    def step_resident(self):
-        if self.graph is not None:
-            self.graph.replay()
-        else:
-            self._step_body()
-        return self.losses
-
     def train_step(self, real_imgs, z, code, labels):
         self.load_inputs(real_imgs, z, code, labels)
         l = self.step_resident().tolist()
         return {"g_loss": l[0], "d_loss": l[1], "info_loss": l[2]}
+
+
+class DeviceInputs(DeviceSampler):
+    """Device-side replacement of the MNIST loop's host input work (MNIST/EAD-GAN_rpqmnxy.py:233-246 DataLoader + Resize(32) + ToTensor +
+    Normalize(.5,.5); :351-357 numpy draws in the reference's order: labels ~ randint(10), z ~ N(0,1), code ~ U(-1,1)).  ``dataset_u8``:
+    uint8 [N,1,32,32] (resized once on the way in)."""
+
+    def enqueue(self, tr: "MnistTrainer"):
+        B = tr.B
+        N, C, H, W = self.data.shape
+        ops.gather_u8_images(self.data, self.sample_indices(B, 1), None, tr.real, B, C, H, W, 2.0 / 255.0, -1.0)   # ToTensor + Normalize(.5,.5)
+        self.draw(ops.RNG_RANDINT, tr.labels, 0, tr.onehot.shape[1], 2)
+        ops.onehot(tr.labels, tr.onehot, B, tr.onehot.shape[1])
+        self.draw(ops.RNG_NORMAL, tr.z, 0.0, 1.0, 3)
+        self.draw(ops.RNG_UNIFORM, tr.code, -1.0, 1.0, 4)
+        self.tick()
 
 
 # ================================================================================================

@@ -98,3 +98,62 @@ def test_trainer_feeds_itself_from_the_captured_graph():
         runs.append((torch.stack(out).cpu(), [b[2].cpu() for b in batches]))
     assert torch.equal(runs[0][0], runs[1][0])
     assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
+
+
+def _run_small(family, capture, steps=4, B=8):
+    """one of the small-network trainers feeding itself from a DeviceInputs; returns (losses per step, label draws, sampler, trainer)"""
+    torch.manual_seed(0)
+    if family == "mnist":
+        from oracle import mnist_oracle as mo
+        orc = mo.MnistOracle(seed=2, mlp=mo.make_approximator(123))
+        eg.mnist.load_approximator(mo.make_approximator(123))
+        mods = [eg.mnist.Generator(dtype="f32").to(DEV), eg.mnist.Discriminator(dtype="f32").to(DEV), eg.mnist.Encoder(dtype="f32").to(DEV)]
+        for m, ref in zip(mods, (orc.G, orc.D, orc.E)):
+            m.load_state_dict({k: v.detach() for k, v in ref.items()})
+        tr = eg.mnist.MnistTrainer(*mods, B, dtype="f32")
+        data = torch.randint(0, 256, (97, 1, 32, 32), dtype=torch.uint8, generator=torch.Generator().manual_seed(4)).to(DEV)
+        inp = eg.mnist.DeviceInputs(data, seed=5)
+    else:
+        from oracle import dsprites_oracle as do
+        color = family == "colored"
+        mod = eg.colored if color else eg.dsprites
+        orc = (do.ColoredOracle if color else do.DspritesOracle)(seed=2)
+        mods = [mod.Encoder_pxy(dtype="f32").to(DEV), mod.Generator(dtype="f32").to(DEV), mod.Discriminator(dtype="f32").to(DEV), mod.Encoder(dtype="f32").to(DEV)]
+        for m, ref in zip(mods, (orc.P, orc.G, orc.D, orc.E)):
+            m.load_state_dict({k: v.detach() for k, v in ref.items()})
+        tr = (mod.ColoredTrainer if color else mod.DspritesTrainer)(*mods, B, dtype="f32")
+        inp = mod.DeviceInputs(do.synthetic_sprites(61, seed=4).to(DEV), seed=5)
+    tr.inputs = inp
+    out, draws = [], []
+    for i in range(steps):
+        if capture and i == 1:
+            tr.capture(inputs=inp)
+        out.append(tr.step_resident().clone())
+        draws.append(((tr.code if family == "mnist" else tr.code1).clone(), (tr.real if family == "mnist" else tr.img).clone()))
+    torch.cuda.synchronize()
+    return torch.stack(out).cpu(), draws, inp, tr
+
+
+@pytest.mark.parametrize("family", ["mnist", "dsprites", "colored"])
+def test_small_network_trainers_feed_themselves(family):
+    """SURVEY 8 row f1 for MNIST (rpqmnxy.py:233-246,351-357), dSprites (rp.py:236-262,389-430) and colored dSprites (rp_color.py:363-381):
+    dataset sampling, transforms and the per-step draws run on the device inside the (captured) iteration; eager and captured runs of one
+    seed see the same batches; the draws have the reference's ranges and change every step."""
+    eager, d0, inp0, tr0 = _run_small(family, False)
+    graph, d1, inp1, tr1 = _run_small(family, True)
+    assert int(inp0.step.item()) == 4 and int(inp1.step.item()) == 4
+    assert torch.isfinite(eager).all() and torch.equal(eager, graph)
+    for (c0, x0), (c1, x1) in zip(d0, d1):
+        assert torch.equal(c0, c1) and torch.equal(x0, x1)
+    codes = torch.stack([c for c, _ in d0])
+    assert float(codes.min()) >= -1.0 and float(codes.max()) < 1.0 and not torch.equal(codes[0], codes[1])
+    img = d0[-1][1]
+    if family == "mnist":
+        assert img.shape == (8, 1, 32, 32) and float(img.min()) >= -1.0 and float(img.max()) <= 1.0 + 2e-7           # ToTensor + Normalize(.5,.5)
+    elif family == "dsprites":
+        assert img.shape == (8, 1, 64, 64) and set(img.unique().tolist()) <= {0.0, 1.0}
+    else:
+        gains = tr0.gains
+        assert img.shape == (8, 3, 64, 64) and float(gains.min()) >= 0.5 and float(gains.max()) < 1.0
+        on = img.amax(dim=(2, 3))                                                                              # sprite pixels carry the gain
+        assert torch.allclose(on, gains, atol=1e-6)
