@@ -58,7 +58,7 @@ def parse():
     return ap.parse_args()
 
 
-def roofline_pass(eg, trainer, dtype, iters=3):
+def roofline_pass(eg, trainer, dtype, workload="celeba", iters=3):
     """Runs `iters` eager iterations with every implicit-GEMM launch bracketed by HIP events on the launch stream (the
     launches sit in their real place in the step, so cache state is the real one) and returns the per-kernel table +
     the roofline object of the dominant kernel (largest total time)."""
@@ -69,7 +69,7 @@ def roofline_pass(eg, trainer, dtype, iters=3):
     # profiles/ holds the rocprofv3 summaries of both commands; the per-kernel averages of the --no-overlap one agree with this table.
     # Rank 0 runs this pass alone: no collectives inside it (the other ranks are not calling them) -- gradient all-reduce AND
     # synchronised BatchNorm are switched off for its duration.
-    saved = {k: getattr(trainer, k, None) for k in ("side", "allreduce", "sync_bn")}
+    saved = {k: getattr(trainer, k, None) for k in ("side", "allreduce", "sync_bn", "overlap")}      # overlap: the small-network trainers' two chains
     for k in saved:
         if hasattr(trainer, k):
             setattr(trainer, k, None)
@@ -109,7 +109,7 @@ def roofline_pass(eg, trainer, dtype, iters=3):
     # HBM bytes per launch: NOT measured in this run -- read from the committed PMC passes of this code (rocprofv3 --pmc, FETCH_SIZE and
     # WRITE_SIZE in separate passes, gfx950 corrections per the microarchitecture guide), if this kernel is in them
     traffic = source = None
-    for name in ("r02_pmc_traffic.json",):
+    for name in ("r02_pmc_traffic.json" if workload == "celeba" else f"r02_pmc_traffic_{workload}.json",):     # PMC passes are per workload
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
         except OSError:
@@ -196,7 +196,7 @@ def main_mnist(a, eg, rank, world, local, dev):
     dt = eg.dp.max_over_ranks(time.perf_counter() - t0, dev)
     roof = table = None
     if not a.no_roofline and rank == 0:
-        roof, table = roofline_pass(eg, tr, a.dtype)
+        roof, table = roofline_pass(eg, tr, a.dtype, "mnist")
     if rank == 0:
         ips = B * world * a.steps / dt
         peak = PEAK_F32_TFLOPS if a.dtype == "f32" else PEAK_BF16_TFLOPS
@@ -248,7 +248,7 @@ def main_sprites(a, eg, rank, world, local, dev):
     dt = eg.dp.max_over_ranks(time.perf_counter() - t0, dev)
     roof = table = None
     if not a.no_roofline and rank == 0:
-        roof, table = roofline_pass(eg, tr, a.dtype)
+        roof, table = roofline_pass(eg, tr, a.dtype, a.workload)
     if rank == 0:
         ips = B * world * a.steps / dt
         peak = PEAK_F32_TFLOPS if a.dtype == "f32" else PEAK_BF16_TFLOPS

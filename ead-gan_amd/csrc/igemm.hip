@@ -808,7 +808,10 @@ static NtPlan nt_plan_auto(const NtParams& p, int nphase, const NtFacts& f, size
     // split K only below one workgroup per CU: at 256..511 tiles the unsplit launch wins or ties (M=8192 N=512 K=4096: 52 vs 58 us,
     // the 4-phase M=2048 N=512 K=4096: 50 vs 48 us -- profiles/r02_i_t1_splits.txt) and saves the slab round trip and the epilogue launch
     static const int split_below = [] { const char* e = getenv("EG_NT_SPLIT_BELOW"); return e ? atoi(e) : 256; }();
-    if (f.tiles128 < (splitk > 1 ? 512 : split_below) && ws_bytes > 0) {
+    // ... except very long K loops (>= 128 K tiles: the 512 -> 1024 layer, K = 8192), which still gain from two splits at 256 tiles
+    // (in-step 110 -> 79 us, profiles/r02_q_step_detail.txt)
+    const bool long_k = f.nk_min >= 128 && f.tiles128 <= 256;         // (at 384 tiles the split loses: 143 vs 116 us)
+    if ((f.tiles128 < (splitk > 1 ? 512 : split_below) || long_k) && ws_bytes > 0) {
         const int ns = nt_splits(f.tiles128, 512, f.nk_min, part128, ws_bytes, splitk);
         if (ns > 1) return {EG_NT_BUF128, ns};
     }
