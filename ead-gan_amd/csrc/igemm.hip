@@ -734,9 +734,9 @@ template <typename T> void eg_launch_nt8s(const NtParams& p, const Nt8pGeom& g, 
 struct NtPlan { int kind, ns; };
 
 // geometry facts every DMA variant needs
-struct NtFacts { bool dma_ok, c_tiles; int nk_min, nk_max; long long tiles128; };
+struct NtFacts { bool dma_ok, c_tiles; int nk_min, nk_max; long long tiles128; bool half; };
 static NtFacts nt_facts(const NtParams& p, int nphase, int vec, size_t esize) {
-    NtFacts f{false, false, 1 << 30, 0, 0};
+    NtFacts f{false, false, 1 << 30, 0, 0, esize == 2};
     f.tiles128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * nphase;
     if (p.out_mode != EG_OUT_NHWC || (p.N % 128) != 0 || (p.C % vec) != 0) return f;
     if ((size_t)p.B * p.H * p.W * p.C * esize >= 0x7fffffffull) return f;
@@ -804,6 +804,12 @@ static NtPlan nt_plan_auto(const NtParams& p, int nphase, const NtFacts& f, size
     // or fewer tiles run better as 128 x 128 tiles with two workgroups per CU (one's epilogue beside the other's K loop)
     const long long wgs256 = (long long)cdiv(p.M, 256) * (p.N / 128) * nphase;
     const long long rounds = (wgs256 + 255) / 256;
+    // Measured in the whole (overlapped) step, the big tile wins beyond the shapes where it wins back to back: S8 wherever it can run
+    // 4.70 ms, this rule set 4.76, 128 x 128 everywhere 4.93 (profiles/r02_r_ab_nt_variant.txt; EG_NT_AUTO_S8=0 restores the rule set)
+    static const bool all_s8 = [] { const char* e = getenv("EG_NT_AUTO_S8"); return !(e && atoi(e) == 0); }();
+    // (16-bit launches of at least 48 such tiles: below that -- the small networks' layers -- and in fp32 the rule set below stays ahead,
+    //  profiles/r02_r_ab_auto_s8.txt)
+    if (all_s8 && f.half && wgs256 >= 48) return {EG_NT_S8, nt_splits(wgs256, 224, f.nk_min, part256, ws_bytes, splitk)};
     if (splitk <= 1 && f.nk_min >= 32 && wgs256 >= 200 && wgs256 * 100 >= rounds * 256 * 85) return {EG_NT_S8, 1};
     // split K only below one workgroup per CU: at 256..511 tiles the unsplit launch wins or ties (M=8192 N=512 K=4096: 52 vs 58 us,
     // the 4-phase M=2048 N=512 K=4096: 50 vs 48 us -- profiles/r02_i_t1_splits.txt) and saves the slab round trip and the epilogue launch

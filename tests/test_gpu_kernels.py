@@ -568,8 +568,9 @@ def test_igemm_variants_match_register_staged_kernel(dtype):
     rt, at = tol(dtype, Cin * 16)
     for o in (outs[0], outs[2], outs[3]):
         torch.testing.assert_close(nchw(o), want, rtol=rt, atol=at)
-    # the planner on its own: one 256-row tile per CU needs a K loop of at least 32 K tiles (here: fp32, 32 elements per K tile)
-    assert nt_tile(c, dtype, 0, 0, 0) == (256147 if dtype == 0 else 128131)
+    # the planner on its own: 256 tiles of 256 x 128 -> the 8-wave kernel (16-bit: wherever it can run from 48 tiles up; fp32: a full round
+    # with a K loop of at least 32 K tiles, here 32 elements per K tile)
+    assert nt_tile(c, dtype, 0, 0, 0) == 256147
     # backward-data: dY [16,32,32,64] -> dX [16,64,64,128], 4 phases of M = 16384, two tapes
     B, H, Cin, Cout = 16, 64, 128, 64
     dy = rq(torch.randn(B, Cout, 32, 32, generator=g), dtype)
