@@ -844,7 +844,8 @@ static void launch_splitk_epilogue(const NtParams& q, int nphase, int Mpad, hipS
 
 template <typename T>
 static int launch_nt(const NtParams& p, int nphase, int variant, int splitk, hipStream_t st) {
-    const NtPlan plan = nt_plan(p, nphase, Elt<T>::VEC, sizeof(T), p.part ? p.part_bytes : 0, variant, splitk);
+    // the tail of the scratch is kept for igemm_nt8s's arrival counters: no variant's partial tiles may reach it
+    const NtPlan plan = nt_plan(p, nphase, Elt<T>::VEC, sizeof(T), (p.part && p.part_bytes > EG_SPLIT_CNT_BYTES) ? p.part_bytes - EG_SPLIT_CNT_BYTES : 0, variant, splitk);
     EG_REQUIRE(plan.kind > 0, "eg_epilogue.nt_variant %d cannot run this problem (M=%d N=%d C=%d)", variant, p.M, p.N, p.C);
     static const int xcd = [] { const char* e = getenv("EG_XCD_REMAP"); return e ? atoi(e) : 1; }();   // default on (7: + diagnostic piece skipping in PROF builds)
     if (plan.kind == EG_NT_S8 || plan.kind == EG_NT_S8P) {
@@ -854,8 +855,10 @@ static int launch_nt(const NtParams& p, int nphase, int variant, int splitk, hip
         Nt8pGeom g;
         memset(&g, 0, sizeof(g));
         if (plan.kind == EG_NT_S8P) EG_REQUIRE(eg_nt8p_geometry(p, nphase, g), "patch geometry");
-        eg_launch_nt8s<T>(q, g, plan.kind == EG_NT_S8P, nphase, plan.ns, st);
-        if (plan.ns > 1) launch_splitk_epilogue<T>(q, nphase, cdiv(p.M, 256) * 256, st);
+        static const bool inkernel = [] { const char* e = getenv("EG_NT_SPLIT_INKERNEL"); return !(e && atoi(e) == 0); }();
+        q.split_cnt = (plan.ns > 1 && inkernel) ? reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.part) + p.part_bytes - EG_SPLIT_CNT_BYTES) : nullptr;
+        eg_launch_nt8s<T>(q, g, plan.kind == EG_NT_S8P, nphase, plan.ns, st);      // K splits are reduced inside the launch (last-arriving workgroup)
+        if (plan.ns > 1 && !inkernel) launch_splitk_epilogue<T>(q, nphase, cdiv(p.M, 256) * 256, st);
         return 0;
     }
     if (plan.kind == EG_NT_PERS) {
@@ -1015,7 +1018,7 @@ extern "C" size_t eg_conv_splitk_ws_bytes(const eg_conv* c, int dtype, int bwd) 
     const NtPlan plan = nt_plan(p, nphase, vec_of(dtype), dtype == EG_F32 ? 4 : 2, (size_t)1 << 40, EG_NT_AUTO, 0);
     if (plan.ns <= 1) return 0;
     const int bm = plan.kind >= EG_NT_S8 ? 256 : 128;
-    return (size_t)plan.ns * nphase * cdiv(p.M, bm) * bm * p.N * 4;
+    return (size_t)plan.ns * nphase * cdiv(p.M, bm) * bm * p.N * 4 + EG_SPLIT_CNT_BYTES;      // + the arrival counters at the scratch's tail
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -40,8 +40,13 @@ struct NtParams {
     int xcd_remap;    // igemm_nt_buf: 1 = every XCD gets a contiguous range of M tiles (workgroups are dispatched round robin over the 8 XCDs)
     size_t part_bytes;
     int nsplit;
+    unsigned* split_cnt;   // igemm_nt8s with K splits: arrival counters, one per output tile (tail of the caller's split-K scratch; zero between launches)
     NtPhase ph[4];
 };
+// the last EG_SPLIT_CNT_BYTES of the caller-lent split-K scratch hold the arrival counters of igemm_nt8s's in-kernel reduction (at most 224
+// tiles split); no planner ever places partial tiles there.  The scratch must be zero when it is first lent; every launch leaves the
+// counters at zero again.
+#define EG_SPLIT_CNT_BYTES 4096
 
 // patch geometry of igemm_nt8p_kernel (igemm_nt8.hip): filter taps grouped into classes that walk one pixel lattice
 struct NtClass { int oy0, ox0, AH, AW, ty0, tys, tx0, txs; };       // source = stride * lattice + o0; tap(ay, ax) = (ty0 + ay*tys, tx0 + ax*txs)

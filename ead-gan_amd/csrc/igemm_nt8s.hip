@@ -433,16 +433,72 @@ __global__ __launch_bounds__(512) void igemm_nt8s_kernel(const NtParams p, const
     if (PROF) { pt[2] = __builtin_amdgcn_s_memtime(); pr[2] = __builtin_amdgcn_s_memrealtime(); }
     // ---- epilogue: all DMA has landed, all reads are retired, every wave is past the last barrier: the LDS is free ----
     if (SPLITK && nsplit > 1) {
+        // K splits reduce INSIDE the launch: every workgroup stores its partial tile, the one that arrives last at the tile's counter sums
+        // the partials in split order (its own from registers: the order does not depend on who is last -> deterministic) and runs the
+        // ordinary epilogue.  Cross-workgroup hand-off as measured safe on gfx950 (MI355X_MICROARCH.md, hand-off table, first row): 16-byte
+        // sc1 stores, every storing wave waits vmcnt(0), workgroup barrier, ONE lane adds to the tile's counter at agent scope; the
+        // workgroup whose add came last loads (sc1, 16 bytes) after its add has returned and a workgroup barrier.  One workgroup per CU.
         const int nphase = gridDim.z / nsplit;
-        float* part = p.part + ((size_t)(split * nphase + phase) * ((size_t)tiles_m * BM) + m0) * p.N + n0;
+        const size_t slab = (size_t)nphase * ((size_t)tiles_m * BM) * p.N;       // floats per split
+        float* part = p.part + ((size_t)phase * ((size_t)tiles_m * BM) + m0) * p.N + n0;
+        float* mine = part + (size_t)split * slab;
+        if (p.split_cnt == nullptr) {                  // A/B path (EG_NT_SPLIT_INKERNEL=0): plain partial stores, a second launch sums them
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 16 + frow;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) *reinterpret_cast<f32x4*>(mine + (size_t)row * p.N + (wn * TN + j) * 16 + fq * 4) = acc[i][j];
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int row = (wm * TM + i) * 16 + frow;
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                *reinterpret_cast<f32x4*>(part + (size_t)row * p.N + (wn * TN + j) * 16 + fq * 4) = acc[i][j];
+            for (int j = 0; j < TN; ++j) {
+                float* a = mine + (size_t)row * p.N + (wn * TN + j) * 16 + fq * 4;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(a), "v"(acc[i][j]) : "memory");
+            }
         }
-        return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* cnt = p.split_cnt + (size_t)phase * gridDim.x + blockIdx.x;
+        volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(smem);
+        if (tid == 0) flag[0] = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (flag[0] != (unsigned)(nsplit - 1)) return;
+        if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // zero again for the next launch
+        f32x4 sum[TM][TN];
+        for (int s = 0; s < nsplit; ++s) {             // uniform
+            if (s == split) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) sum[i][j] = s == 0 ? acc[i][j] : sum[i][j] + acc[i][j];
+                continue;
+            }
+            const float* other = part + (size_t)s * slab;
+            f32x4 ld[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 16 + frow;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float* a = other + (size_t)row * p.N + (wn * TN + j) * 16 + fq * 4;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(ld[i][j]) : "v"(a) : "memory");
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) sum[i][j] = s == 0 ? ld[i][j] : sum[i][j] + ld[i][j];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = sum[i][j];
+        __syncthreads();                               // the flag word is read; the epilogue stages through the same LDS
     }
     constexpr int PF = 8;
     NtEpiPre<T, TM, TN, PF> epi;

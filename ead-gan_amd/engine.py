@@ -70,7 +70,7 @@ class Workspace:
         self.sums = torch.empty(0, device=device, dtype=torch.float32)
         # split-K partial tiles of the NT kernel: the planner splits up to ~2x512 tiles of 128x128 fp32 (64 KiB each)
         if splitk:
-            self.splitk = torch.empty(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)
+            self.splitk = torch.zeros(SPLITK_WS_BYTES // 4, device=device, dtype=torch.float32)      # zeroed: its tail holds arrival counters
             if register:
                 ops.set_splitk_workspace(self.splitk)
 

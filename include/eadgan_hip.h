@@ -59,8 +59,10 @@ typedef struct eg_epilogue {
     float mask_slope;
     int out_mode;
     int sigma_rows;
-    void* splitk_ws;          /* optional caller-owned scratch: lets small-M / deep-K launches split K across workgroups */
-    size_t splitk_ws_bytes;   /* (fp32 partial tiles, summed in a fixed order by a second launch); NULL / 0 = never split */
+    void* splitk_ws;          /* optional caller-owned scratch: lets small-M / deep-K launches split K across workgroups (fp32 partial */
+    size_t splitk_ws_bytes;   /* tiles, summed in split order -- inside the launch by the last-arriving workgroup, or by a second launch); */
+                              /* NULL / 0 = never split.  ZERO it once before the first use: its last 4 KiB hold arrival counters that */
+                              /* every launch leaves at zero.  One scratch must not be lent to two launches that may run concurrently. */
     int nt_variant;           /* EG_NT_AUTO (0): the planner picks the kernel; otherwise force one (the call fails if it cannot run the problem) */
     int nt_splitk;            /* 0: the planner picks the K split; n >= 1: at most n splits (1 = never) */
 } eg_epilogue;

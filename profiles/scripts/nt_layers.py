@@ -43,7 +43,7 @@ def main():
     dt = a.dtype
     tdt = ops.torch_dtype(dt)
     dev = "cuda"
-    ws = torch.empty(96 << 20, device=dev, dtype=torch.float32)        # 384 MiB of split-K scratch
+    ws = torch.zeros(96 << 20, device=dev, dtype=torch.float32)        # 384 MiB of split-K scratch (zeroed: its tail holds arrival counters)
     cfgs = [tuple(int(v) for v in c.split(":")) for c in a.configs.split(",")]
     lib = eg._lib.lib()
     g = torch.Generator(device=dev).manual_seed(1)

@@ -674,11 +674,12 @@ def test_igemm_nt8s_short_k_loops(variant, nk_taps):
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_igemm_splitk_small_m_deep_k(dtype):
     """Few-row / deep-K launches (the last Discriminator conv: celebA/EAD-GAN_celebA.py:118) split K across workgroups into fp32
-    partial tiles that a second launch sums in a fixed order before the fused epilogue: forward (bias + LeakyReLU) and 4-phase
+    partial tiles summed in split order before the fused epilogue (by a second launch in the 128-row kernel, by the last-arriving workgroup
+    inside the launch in the 8-wave kernel -- its arrival counters at the scratch's tail are zero again afterwards): forward (bias + LeakyReLU) and 4-phase
     backward-data (1/sigma per tape + activation-gradient mask) against torch, and repeatable bit for bit -- planner's choice (128-row
     tiles at this M), and the 8-wave kernel forced with 4 to 16 splits in both modes."""
     lib = eg._lib.lib()
-    ws = torch.empty(16 << 20, device=DEV, dtype=torch.float32)
+    ws = torch.zeros(16 << 20, device=DEV, dtype=torch.float32)
     g = torch.Generator().manual_seed(23)
     B, H, Cin, Cout = 24, 8, 256, 256
     c = ops.make_conv(B, H, H, Cin, Cout, 4, 2, 1)
@@ -718,6 +719,7 @@ def test_igemm_splitk_small_m_deep_k(dtype):
         want[12:] /= 0.7
         rt, at = tol(dtype, Cout * 4)
         torch.testing.assert_close(nchw(dx), want, rtol=rt, atol=at)
+        assert int(ws[-1024:].view(torch.int32).abs().sum()) == 0          # the last 4 KiB: arrival counters, left at zero by every launch
 
 
 @pytest.mark.parametrize("variant", [0, NT_BUF128, NT_S8, NT_S8P])
@@ -725,7 +727,7 @@ def test_igemm_splitk_small_m_deep_k(dtype):
 def test_igemm_splitk_range_starting_inside_a_tap(dtype, variant):
     """3x3 conv whose K split boundaries fall inside filter taps (9 taps x 256 channels, 4 splits of 9 (bf16) / 18 (fp32) K steps
     against 4 / 8 steps per tap): the per-split start state (tap, channel offset) must be reconstructed exactly."""
-    ws = torch.empty(16 << 20, device=DEV, dtype=torch.float32)
+    ws = torch.zeros(16 << 20, device=DEV, dtype=torch.float32)
     g = torch.Generator().manual_seed(24)
     B, H, Cin, Cout = 8, 8, 256, 256
     c = ops.make_conv(B, H, H, Cin, Cout, 3, 1, 1)
