@@ -218,7 +218,7 @@ def main_sprites(a, eg, rank, world, local, dev):
     P, G, D, E = mod.Encoder_pxy(dtype=a.dtype).to(dev), mod.Generator(dtype=a.dtype).to(dev), mod.Discriminator(dtype=a.dtype).to(dev), mod.Encoder(dtype=a.dtype).to(dev)
     # (Encoder_pxy stays at its seeded default init: a stand-in of the frozen stage-1 checkpoint encoder_pxy_*.pt, which is not in the container)
     ar = eg.dp.GradAllReduce(world, wire=a.wire) if world > 1 else None
-    tr = (mod.ColoredTrainer if color else mod.DspritesTrainer)(P, G, D, E, B, dtype=a.dtype, allreduce=ar,
+    tr = (mod.ColoredTrainer if color else mod.DspritesTrainer)(P, G, D, E, B, dtype=a.dtype, allreduce=ar, overlap=not a.no_overlap,
                                                                  sync_bn=eg.dp.SyncBN(world, rank) if (a.sync_bn and world > 1) else None)
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     sprites = synthetic_sprites(B, dev, g)

@@ -14,13 +14,14 @@ import subprocess
 import sys
 from collections import defaultdict
 
-TYPES = {"unsigned short": "bf16", "__half": "f16", "_Float16": "f16", "float": "f32"}
+TYPES = {"unsigned short": "bf16", "__half": "f16", "_Float16": "f16", "half": "f16", "float": "float"}      # as ops._timed names them
 
 
 def demangle(names):
     """the rocpd database keeps mangled symbols (+ '.kd')"""
     tool = shutil.which("c++filt") or shutil.which("llvm-cxxfilt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
-    clean = [n[:-3] if n.endswith(".kd") else n for n in names]
+    # (binutils' c++filt predates the _Float16 mangling "DF16_": spell it as the older half type "Dh")
+    clean = [(n[:-3] if n.endswith(".kd") else n).replace("DF16_", "Dh") for n in names]
     out = subprocess.run([tool], input="\n".join(clean), capture_output=True, text=True, check=True).stdout.splitlines()
     return dict(zip(names, out))
 
