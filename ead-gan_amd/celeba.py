@@ -683,6 +683,11 @@ class DeviceInputs:
         ops.counter_add(self.step, 1)
 
 
+# 1: D(gen) of the generator step batched with the discriminator step's D(scaled), D(gen) as ONE three-tape forward (same weights: the
+# discriminator is not updated in between; each tape keeps its own power iteration in the reference's order).  Same results (tested with
+# the switch on), but SLOWER in the overlapped step, 4.75 -> 4.94 ms (profiles/r02_x_ab_batch_d12.txt): the discriminator step's forward
+# no longer runs beside the generator's weight-gradient lanes and update.  Default 0: two forwards (T = 1, T = 2).
+BATCH_D12 = os.environ.get("EG_BATCH_D12", "0") != "0"
 BUCKET_OPT = os.environ.get("EG_BUCKET_OPT", "g3")     # "0" never, "1" every update, "3" the info step's two updates, "g3" only its last (G)
 
 
@@ -774,6 +779,19 @@ class CelebATrainer:
         else:
             ar(flat)
 
+    def _sn_d12(self):
+        """power iterations of the three D forwards of steps 1 and 2 in the reference's order: D(gen) of step 1 (tape 2), then D(scaled),
+        D(gen) of step 2 (tapes 0, 1); all read the same weights"""
+        for t in (2, 0, 1):
+            self.de._sn_tape(t)
+
+    def _forward_d12(self, gen, prepared=False):
+        """ONE forward over tapes 0 = D(scaled), 1 = D(gen) [step 2], 2 = D(gen) [step 1]  (celebA/EAD-GAN_celebA.py:338,357-358)"""
+        if not prepared:
+            self._sn_d12()
+            self.de._im2col_tape(0, self.scaled)
+        return self.de.forward([self.scaled, gen, gen], 0, prepared=(True, False, False))
+
     def _step_body_serial(self):
         """one stream, program order of the reference loop body (overlap=False; the pipelined body below is bit-identical)"""
         G, D, ge, de, B = self.G, self.D, self.ge, self.de, self.B
@@ -784,7 +802,11 @@ class CelebATrainer:
         # ---- 1) generator adversarial step (:334-345) ----
         ops.fill_f32(ga.grad)
         gen = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
-        out = de.forward([gen], 2)
+        if BATCH_D12:
+            out12 = self._forward_d12(gen)
+            out = out12[2 * B:]
+        else:
+            out = de.forward([gen], 2)
         ops.loss_bce_sigmoid(out, 19, 0, B, 1.0, 1.0, self.losses[0:1], self.dout[2 * B:])
         dimg = de.backward(2, 1, self.dout[2 * B:], da.grad, need_wgrad=False, need_dimg=True)
         ge.backward(dimg, ga.grad, None, sync=self.sync_bn)
@@ -793,7 +815,7 @@ class CelebATrainer:
         ge.repack()
         # ---- 2) discriminator step (:353-366); gen is the (detached) output of step 1; D(scaled) then D(gen), batched ----
         ops.fill_f32(da.grad)
-        out = de.forward([self.scaled, gen], 0)
+        out = out12 if BATCH_D12 else de.forward([self.scaled, gen], 0)
         ops.loss_bce_sigmoid(out[:B], 19, 0, B, 1.0, 0.5, self.losses[1:2], self.dout[:B])
         ops.loss_bce_sigmoid(out[B:], 19, 0, B, 0.0, 0.5, self.losses[1:2], self.dout[B:2 * B])
         de.backward(0, 2, self.dout[:2 * B], da.grad)
@@ -888,19 +910,27 @@ class CelebATrainer:
         self._inputs_head()
         # ---- 1) generator adversarial step (:334-345); D(gen) lives in tape slot 2 so that step 2's tapes can be prepared meanwhile ----
 
-        def sn1(_ws):                                   # D(gen)'s power iteration only needs D's weights: beside the generator forward
-            de._sn_tape(2)
+        def sn1(_ws):                                   # the power iterations only need D's weights: beside the generator forward
+            if BATCH_D12:
+                self._sn_d12()
+                de._im2col_tape(0, self.scaled)
+            else:
+                de._sn_tape(2)
             evs["sn1"] = side.mark()
         side.defer_prep(sn1)
         ops.fill_f32(ga.grad)
         gen = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
         side.wait(evs["sn1"])
-        out = de.forward([gen], 2, prepared=(False,))
+        if BATCH_D12:
+            out12 = self._forward_d12(gen, prepared=True)
+            out = out12[2 * B:]
+        else:
+            out = de.forward([gen], 2, prepared=(False,))
 
-        def prep2(_ws):                                 # step 2's power iterations (after step 1's in the u/v chain) and patch rows
-            de.prepare(0, [self.scaled, gen])
-            evs["prep2"] = side.mark()
-        side.defer_prep(prep2)
+            def prep2(_ws):                             # step 2's power iterations (after step 1's in the u/v chain) and patch rows
+                de.prepare(0, [self.scaled, gen])
+                evs["prep2"] = side.mark()
+            side.defer_prep(prep2)
         ops.loss_bce_sigmoid(out, 19, 0, B, 1.0, 1.0, self.losses[0:1], self.dout[2 * B:])
         side.flush()
         dimg = de.backward(2, 1, self.dout[2 * B:], da.grad, need_wgrad=False, need_dimg=True)
@@ -909,8 +939,11 @@ class CelebATrainer:
         # ---- 2) discriminator step (:353-366); gen is the (detached) output of step 1; D(scaled) then D(gen), batched ----
         ops.fill_f32(da.grad)
         side.flush()
-        side.wait(evs["prep2"])
-        out = de.forward([self.scaled, gen], 0, prepared=(True, True))
+        if BATCH_D12:
+            out = out12
+        else:
+            side.wait(evs["prep2"])
+            out = de.forward([self.scaled, gen], 0, prepared=(True, True))
         ops.loss_bce_sigmoid(out[:B], 19, 0, B, 1.0, 0.5, self.losses[1:2], self.dout[:B])
         ops.loss_bce_sigmoid(out[B:], 19, 0, B, 0.0, 0.5, self.losses[1:2], self.dout[B:2 * B])
         de.backward(0, 2, self.dout[:2 * B], da.grad, side=side)
