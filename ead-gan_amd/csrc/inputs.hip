@@ -122,3 +122,45 @@ extern "C" int eg_onehot(const long long* labels, float* out, int B, int n, eg_s
     EG_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- Resize + CenterCrop of the uint8 dataset on its way into HBM (celebA/EAD-GAN_celebA.py:194-196: transforms.Resize(img_size) =
+// PIL bilinear with antialiasing, then CenterCrop) ------------------------------------------------------------------------------------
+// One separable pass along x (axis = 1) or y (axis = 0) of planar uint8 images with the fixed-point coefficients PIL uses for 8-bit
+// images (22 fractional bits, ksize taps from bounds[2*o] on, rounded with +2^21 and clamped): out = clip8((2^21 + sum src*k) >> 22).
+// The host computes the tables exactly as PIL's precompute_coeffs / normalize_coeffs_8bpc do (double arithmetic), so the two passes
+// (horizontal first, 8-bit intermediate, like ImagingResample) reproduce PIL's output bit for bit.  Only the output window
+// [o0, o0 + on) along the axis is produced (the crop); the other axis is copied through a window [c0, c0 + cn) of the source.
+__global__ void resample_u8_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int planes, int in_h, int in_w,
+                                   int axis, const int* __restrict__ bounds, const int* __restrict__ kk, int ksize, int o0, int on, int c0,
+                                   int cn) {
+    const int out_h = axis == 0 ? on : cn, out_w = axis == 0 ? cn : on;
+    const size_t total = (size_t)planes * out_h * out_w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % out_w), y = (int)((i / out_w) % out_h);
+        const size_t pl = i / ((size_t)out_w * out_h);
+        const int o = (axis == 0 ? y : x) + o0, c = (axis == 0 ? x : y) + c0;
+        const int lo = bounds[2 * o], n = bounds[2 * o + 1];
+        const int* k = kk + (size_t)o * ksize;
+        const unsigned char* p = src + pl * (size_t)in_h * in_w;
+        int acc = 1 << 21;
+        if (axis == 0)
+            for (int t = 0; t < n; ++t) acc += (int)p[(size_t)(lo + t) * in_w + c] * k[t];
+        else
+            for (int t = 0; t < n; ++t) acc += (int)p[(size_t)c * in_w + lo + t] * k[t];
+        acc >>= 22;
+        dst[i] = (unsigned char)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+    }
+}
+
+extern "C" int eg_resample_u8(const unsigned char* src, unsigned char* dst, int planes, int in_h, int in_w, int axis, const int* bounds,
+                              const int* kk, int ksize, int o0, int on, int c0, int cn, eg_stream_t s) {
+    EG_REQUIRE(src && dst && bounds && kk && planes > 0 && in_h > 0 && in_w > 0 && (axis == 0 || axis == 1) && ksize > 0 && on > 0 && cn > 0 &&
+                   o0 >= 0 && c0 >= 0 && c0 + cn <= (axis == 0 ? in_w : in_h),
+               "eg_resample_u8: bad argument");
+    const size_t total = (size_t)planes * on * cn;
+    const int blocks = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+    hipLaunchKernelGGL(resample_u8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, src, dst, planes, in_h, in_w, axis, bounds, kk, ksize, o0,
+                       on, c0, cn);
+    EG_LAUNCH_CHECK();
+    return 0;
+}

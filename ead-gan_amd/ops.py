@@ -483,6 +483,10 @@ def gather_u8_images(data, idx, flip, out, B, C, H, W, scale, shift):
     lib().call("eg_gather_u8_images", _p(data), _p(idx), _p(flip), _p(out), B, C, H, W, float(scale), float(shift), _stream())
 
 
+def resample_u8(src, dst, planes, in_h, in_w, axis, bounds, kk, ksize, o0, on, c0, cn):
+    lib().call("eg_resample_u8", _p(src), _p(dst), planes, in_h, in_w, axis, _p(bounds), _p(kk), ksize, o0, on, c0, cn, _stream())
+
+
 def onehot(labels, out, B, n):
     lib().call("eg_onehot", _p(labels), _p(out), B, n, _stream())
 

@@ -357,6 +357,13 @@ int eg_counter_add(int* counter, int v, eg_stream_t s);
 int eg_gather_u8_images(const unsigned char* data, const long long* idx, const unsigned char* flip, float* out, int B, int C, int H,
                         int W, float scale, float shift, eg_stream_t s);
 int eg_onehot(const long long* labels, float* out, int B, int n, eg_stream_t s);          /* to_categorical (celebA.py:59-64) */
+/* transforms.Resize (PIL bilinear, antialiased) + CenterCrop of the uint8 dataset on its way into HBM (celebA.py:194-196): ONE separable
+ * pass along y (axis 0) or x (axis 1) of `planes` planar uint8 images [in_h][in_w] with PIL's 8-bit fixed-point coefficient tables
+ * (bounds[2*o] = first tap, bounds[2*o+1] = tap count, kk[o*ksize + t], 22 fractional bits; the host builds them as PIL does); produces
+ * outputs o0 .. o0+on-1 along the axis and copies columns / rows c0 .. c0+cn-1 of the other axis: dst is [planes][on][cn] (axis 0) or
+ * [planes][cn][on] (axis 1).  Horizontal pass first, then vertical, reproduces Image.resize(..., BILINEAR) bit for bit. */
+int eg_resample_u8(const unsigned char* src, unsigned char* dst, int planes, int in_h, int in_w, int axis, const int* bounds,
+                   const int* kk, int ksize, int o0, int on, int c0, int cn, eg_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -4,6 +4,7 @@ is the reference's numpy one-hot (row a6, :63-68; celebA/EAD-GAN_celebA.py:56-62
 import importlib
 
 import numpy as np
+import pytest
 import torch
 import torch.nn as nn
 
@@ -61,3 +62,41 @@ def test_to_categorical_is_the_reference_one_hot():
         assert got.dtype == torch.float32 and tuple(got.shape) == (5, 10)
         np.testing.assert_array_equal(got.cpu().numpy(), want)
     assert eg.mnist.to_categorical(torch.tensor([2, 2]).numpy(), num_columns=3).sum().item() == 2.0
+
+
+def _pil_resize_center_crop(img_hwc, size):
+    """transforms.Resize(size) + CenterCrop(size) on a PIL image, as torchvision computes sizes and offsets (celebA/EAD-GAN_celebA.py:194-196)"""
+    from PIL import Image
+    H, W = img_hwc.shape[:2]
+    ow, oh = (size, int(size * H / W)) if W <= H else (int(size * W / H), size)
+    im = Image.fromarray(img_hwc).resize((ow, oh), Image.BILINEAR)
+    top, left = int(round((oh - size) / 2.0)), int(round((ow - size) / 2.0))
+    return np.asarray(im.crop((left, top, left + size, top + size)))
+
+
+@pytest.mark.parametrize("hw", [(218, 178), (178, 218), (100, 64), (70, 200), (64, 64)])
+def test_pil_bilinear_tables_reproduce_pil(hw):
+    """f1: the fixed-point coefficient tables eg_resample_u8 runs on are Pillow's (precompute_coeffs + normalize_coeffs_8bpc): a numpy
+    emulation of the two passes with them equals Image.resize(..., BILINEAR) bit for bit (the GPU suite runs the kernel against PIL)."""
+    from PIL import Image
+    H, W = hw
+    size = 64
+    img = np.random.RandomState(H * 1000 + W).randint(0, 256, (H, W, 3), dtype=np.uint8)
+    ow, oh = (size, int(size * H / W)) if W <= H else (int(size * W / H), size)
+    bh, kh, ksh = eg.celeba.pil_bilinear_tables(W, ow)
+    bv, kv, ksv = eg.celeba.pil_bilinear_tables(H, oh)
+    assert kh.shape == (ow, ksh) and kv.shape == (oh, ksv)
+
+    def one_pass(a, b, k, axis):
+        a = np.moveaxis(a, axis, 0).astype(np.int64)
+        out = np.zeros((b.shape[0],) + a.shape[1:], dtype=np.int64)
+        for o in range(b.shape[0]):
+            lo, n = b[o]
+            acc = np.full(a.shape[1:], 1 << 21, dtype=np.int64)
+            for t in range(n):
+                acc += a[lo + t] * int(k[o, t])
+            out[o] = np.clip(acc >> 22, 0, 255)
+        return np.moveaxis(out, 0, axis).astype(np.uint8)
+    tmp = one_pass(img, bh, kh, 1) if ow != W else img
+    got = one_pass(tmp, bv, kv, 0) if oh != H else tmp
+    assert np.array_equal(got, np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR)))

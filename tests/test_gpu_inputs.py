@@ -157,3 +157,19 @@ def test_small_network_trainers_feed_themselves(family):
         assert img.shape == (8, 3, 64, 64) and float(gains.min()) >= 0.5 and float(gains.max()) < 1.0
         on = img.amax(dim=(2, 3))                                                                              # sprite pixels carry the gain
         assert torch.allclose(on, gains, atol=1e-6)
+
+
+@pytest.mark.parametrize("hw", [(218, 178), (178, 218), (100, 64), (70, 200), (64, 64)])
+def test_resize_center_crop_matches_pil(hw):
+    """f1 remainder: transforms.Resize(64) + CenterCrop(64) (celebA/EAD-GAN_celebA.py:194-196) on the device, bit for bit against PIL
+    (CelebA's 218 x 178 portraits, a landscape, one edge already 64, no resize at all)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_dropin_host import _pil_resize_center_crop
+    H, W = hw
+    rng = np.random.RandomState(7)
+    imgs = rng.randint(0, 256, (5, H, W, 3), dtype=np.uint8)
+    got = eg.celeba.resize_center_crop_u8(torch.from_numpy(imgs).permute(0, 3, 1, 2).contiguous().to(DEV), 64)
+    assert got.shape == (5, 3, 64, 64) and got.dtype == torch.uint8
+    want = np.stack([_pil_resize_center_crop(im, 64) for im in imgs]).transpose(0, 3, 1, 2)
+    assert np.array_equal(got.cpu().numpy(), want)
