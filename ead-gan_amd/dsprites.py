@@ -613,9 +613,15 @@ class DspritesTrainer(ResidentStep):
             # for the joint step's forward (and backward), so that it does not wait for the D step to release the first one's buffers
             self.ws2 = Workspace(dev, register=False)
             self.chain = torch.cuda.Stream(dev)
-            nl = int(os.environ.get("EG_SMALL_LANES", "0"))     # weight-gradient side lanes: slower here (profiles/r02_n_ab_small_lanes.txt), off
+            # weight-gradient side lanes under the two chains: slower (profiles/r02_n_ab_small_lanes.txt), off.  "tailN": N lanes for the
+            # generator backward only -- the one phase in which a single chain is active
+            # (colored dSprites B = 512: 3.47 -> 3.34 ms with tail2; dSprites B = 128: 1.71 -> 1.73: on from batch 256 up,
+            #  profiles/r02_z_ab_tail_lanes.txt)
+            env = os.environ.get("EG_SMALL_LANES", "tail2" if B >= 256 else "0")
+            self.tail_lanes = env.startswith("tail")
+            nl = int(env[4:] or 2) if self.tail_lanes else int(env)
             self.side_a = SideStream(dev, Workspace.get(dev), lanes=nl) if nl else None     # weight-gradient lanes of the main chain
-            self.side_b = SideStream(dev, self.ws2, lanes=nl) if nl else None               # ... and of the second chain
+            self.side_b = SideStream(dev, self.ws2, lanes=nl) if (nl and not self.tail_lanes) else None    # ... and of the second chain
             with Workspace.scope(self.ws2):
                 self.ee, self.ge2 = encoder.engine(B, slot=1), generator.engine(B, slot=1)
         else:
@@ -660,6 +666,7 @@ class DspritesTrainer(ResidentStep):
         mark = SideStream.mark
         main, chain = torch.cuda.current_stream(), self.chain
         sa, sb = self.side_a, self.side_b
+        sa_d = None if getattr(self, "tail_lanes", False) else sa          # lanes of the D step's backward
         join = lambda sd: sd.join_lanes() if sd is not None else None
         ops.fill_f32(L)
         self._align()                                                                        # :374-377
@@ -700,8 +707,8 @@ class DspritesTrainer(ResidentStep):
         out = de.forward([self.trans1, gen])["fc2"]
         ops.loss_bce_sigmoid(out[:B], 1, 0, B, 1.0, 0.5, L[0:1], self.dout_d[:B])
         ops.loss_bce_sigmoid(out[B:], 1, 0, B, 0.0, 0.5, L[0:1], self.dout_d[B:])
-        de.backward(0, 2, {"fc2": self.dout_d}, da.grad, side=sa)
-        join(sa)
+        de.backward(0, 2, {"fc2": self.dout_d}, da.grad, side=sa_d)
+        join(sa_d)
         self._adam(da, self.mD, self.vD, self.lr[0], 0, True)
         de.repack()
         # ---- joint step (:424-482): the generator's adversarial term needs the UPDATED discriminator ----
