@@ -722,6 +722,40 @@ def test_igemm_splitk_small_m_deep_k(dtype):
         assert int(ws[-1024:].view(torch.int32).abs().sum()) == 0          # the last 4 KiB: arrival counters, left at zero by every launch
 
 
+def test_igemm_splitk_inkernel_reduction_repeatable_under_load():
+    """The 8-wave kernel's in-launch K-split reduction hands partial tiles from workgroup to workgroup (sc1 stores / loads + an arrival
+    counter): 60 launches of a production shape (CelebA 256 -> 512 at B = 128, 4 splits) with other kernels interleaved must all give
+    the first launch's bytes, and leave the counters at zero.  (profiles/scripts/splitk_race_screen.py is the long version.)"""
+    dtype = 1
+    ws = torch.zeros(24 << 20, device=DEV, dtype=torch.float32)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    B, H, Cin, Cout = 128, 16, 256, 512
+    c = ops.make_conv(B, H, H, Cin, Cout, 4, 2, 1)
+    assert nt_tile(c, dtype, 0, NT_S8, 4) == 256148
+    w = (torch.rand(Cout, Cin, 4, 4, device=DEV, generator=g) - 0.5) * 0.1
+    wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=ops.torch_dtype(dtype))
+    ops.pack_fwd(c, dtype, w, wp)
+    x = (torch.rand(B, H, H, Cin, device=DEV, generator=g) * 2 - 1).to(ops.torch_dtype(dtype))
+    run = lambda out: ops.conv_fwd(c, dtype, x, wp, out, ops.epilogue(act=ops.ACT_LRELU, slope=0.1, nt_variant=NT_S8, nt_splitk=4, splitk_ws=ws))
+    ref = torch.empty(B, H // 2, H // 2, Cout, device=DEV, dtype=ops.torch_dtype(dtype))
+    run(ref)
+    filler = torch.randn(1024, 1024, device=DEV)
+    bad = torch.zeros(1, device=DEV, dtype=torch.int64)
+    for r in range(60):
+        out = torch.full_like(ref, 3.0)
+        if r % 3 == 1:
+            filler @ filler
+        run(out)
+        bad += (out != ref).any().to(torch.int64)
+    torch.cuda.synchronize()
+    assert int(bad) == 0 and int(ws[-1024:].view(torch.int32).abs().sum()) == 0
+    # and the sum itself: against the unsplit launch to 16-bit rounding of the output
+    plain = torch.empty_like(ref)
+    ops.conv_fwd(c, dtype, x, wp, plain, ops.epilogue(act=ops.ACT_LRELU, slope=0.1, nt_variant=NT_S8, nt_splitk=1, splitk_ws=None))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(ref.float(), plain.float(), rtol=2e-2, atol=2e-2)
+
+
 @pytest.mark.parametrize("variant", [0, NT_BUF128, NT_S8, NT_S8P])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_igemm_splitk_range_starting_inside_a_tap(dtype, variant):
