@@ -67,12 +67,12 @@ struct Tn8Params {
     int B, H, W, C, N;
     int lOH, lOW, M;
     int rows_per_split; // multiple of 64
-    int ntn, ntc;
+    int ntn, ntc, ch;   // tiles; channels per tile on both sides (128 or 64)
     int nimg, OHt, PH, PW, npix, npp;       // per 64-row K step: images, output rows per image, patch lattice, pixels, X pieces per wave
     unsigned inv_pw, inv_plane;             // x / PW, x / (PH * PW) as (x * inv) >> 20 for x < 512
 };
 
-#define EG_TN8_XSLOTS 136                   // patch pixel slots per stage (34 pieces of 4 pixels x 256 B)
+#define EG_TN8_XSLOTS 136                   // patch pixel slots per stage (34 pieces of 4 pixels x 256 B, or 17 of 8 pixels x 128 B)
 
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }

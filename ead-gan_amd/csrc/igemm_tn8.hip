@@ -38,16 +38,23 @@ __device__ __forceinline__ void tn8_wait(int n) {        // vmcnt(n) lgkmcnt(0) 
     }
 }
 
-template <typename T>
+// CH: channels per tile on both sides (128: the CelebA layers; 64: the dSprites networks) = 16-bit elements per LDS row
+template <typename T, int CH>
 __global__ __launch_bounds__(512) void igemm_tn8_kernel(const Tn8Params p) {
-    constexpr int STAGE_P = 64 * 256, STAGE_X = EG_TN8_XSLOTS * 256, STAGE = STAGE_P + STAGE_X;
+    constexpr int ROWB = CH * 2;                         // bytes per LDS row (a K row of P, a patch pixel of X)
+    constexpr int RPP = 1024 / ROWB;                     // rows per 1 KiB DMA piece
+    constexpr int CPR = ROWB / 16;                       // 16-byte chunks per row
+    constexpr int NBLK = ROWB / 32;                      // 32-byte (16-channel) blocks per row: the swizzle unit
+    constexpr int NI = CH / 32, NJ = CH / 16;            // MFMA tiles per wave: output channels (half of CH) x input channels
+    constexpr int NPP_P = 64 / RPP / 8;                  // P pieces per wave and K step
+    constexpr int STAGE_P = 64 * ROWB, STAGE_X = EG_TN8_XSLOTS * ROWB, STAGE = STAGE_P + STAGE_X;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tp = wave >> 1, nh = wave & 1;             // this wave's tap of the class and half of the 128 output channels
     const int ay = tp >> 1, ax = tp & 1;
     const int tn_i = blockIdx.x / p.ntc, tc_i = blockIdx.x - tn_i * p.ntc;
-    const int n0 = tn_i * 128, c0 = tc_i * 128;
+    const int n0 = tn_i * CH, c0 = tc_i * CH;
     const int ry = blockIdx.y >> 1, rx = blockIdx.y & 1;  // parity class: taps (ry + 2 ay, rx + 2 ax), source = 2 * lattice + (r - 1)
     const int mbeg = blockIdx.z * p.rows_per_split;
     const int mend = min(p.M, mbeg + p.rows_per_split);
@@ -61,36 +68,36 @@ __global__ __launch_bounds__(512) void igemm_tn8_kernel(const Tn8Params p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = (i >> 1) * 32 + 8 * g + (i & 1) * 4 + q;
-        prow[i] = r * 256 + (tn8_fsw(r) & 7);
+        prow[i] = r * ROWB + (tn8_fsw(r) & (NBLK - 1));
         int img, oy;
         if (p.nimg == 1) { img = 0; oy = r >> p.lOW; }
         else { img = r >> (p.lOH + p.lOW); oy = (r >> p.lOW) & OHm; }
         const int px = (img * p.PH + oy + ay) * p.PW + (r & OWm) + ax;
-        xrow[i] = px * 256 + (tn8_fsw(px) & 7);
+        xrow[i] = px * ROWB + (tn8_fsw(px) & (NBLK - 1));
     }
     auto frag_addr = [&](int rowkey, int blk) { return (rowkey & ~7) + (((blk ^ (rowkey & 7)) << 5) | (pc << 3)); };
 
     // ---- DMA source offsets ----
-    const int c16 = lane & 15, rsub = lane >> 4;         // a piece = 4 rows x 256 B; lane -> (row, 16-byte chunk)
+    const int c16 = lane % CPR, rsub = lane / CPR;       // a piece = RPP rows x ROWB bytes; lane -> (row, 16-byte chunk)
     const u32x4_t srdP = eg_make_srd(p.P, (unsigned)((size_t)p.M * p.N * 2));
     const u32x4_t srdX = eg_make_srd(p.src, (unsigned)((size_t)p.B * p.H * p.W * p.C * 2));
-    unsigned vP[2];
+    unsigned vP[NPP_P];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = 4 * (wave + 8 * j) + rsub;
-        const int src16 = (((c16 >> 1) ^ (tn8_fsw(r) & 7)) << 1) | (c16 & 1);
+    for (int j = 0; j < NPP_P; ++j) {
+        const int r = RPP * (wave + 8 * j) + rsub;
+        const int src16 = (((c16 >> 1) ^ (tn8_fsw(r) & (NBLK - 1))) << 1) | (c16 & 1);
         vP[j] = (unsigned)r * (unsigned)p.N * 2u + (unsigned)n0 * 2u + (unsigned)src16 * 16u;
     }
     // patch pieces w, w + 8, ...: lane part of the source offset, source row relative to the step's first source row, x validity
     int xa[5], xdy[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-        const unsigned ps = (unsigned)(4 * (wave + 8 * j) + rsub);
+        const unsigned ps = (unsigned)(RPP * (wave + 8 * j) + rsub);
         const unsigned img = (ps * p.inv_plane) >> 20;
         const unsigned rem = ps - img * (unsigned)(p.PH * p.PW);
         const unsigned qy = (rem * p.inv_pw) >> 20, qx = rem - qy * (unsigned)p.PW;
         const int ix = (int)qx * 2 + rx - 1;
-        const int src16 = (((c16 >> 1) ^ (tn8_fsw((int)ps) & 7)) << 1) | (c16 & 1);
+        const int src16 = (((c16 >> 1) ^ (tn8_fsw((int)ps) & (NBLK - 1))) << 1) | (c16 & 1);
         const bool ok = (int)ps < p.npix && ix >= 0 && ix < p.W;
         xdy[j] = (int)qy * 2 + ry - 1;                  // source row = 2 * (first lattice row of the step) + xdy
         xa[j] = ok ? (int)(((img * (unsigned)(p.H * p.W) + (unsigned)ix) * row_bytes) + (unsigned)c0 * 2u + (unsigned)src16 * 16u) : -1;
@@ -102,14 +109,14 @@ __global__ __launch_bounds__(512) void igemm_tn8_kernel(const Tn8Params p) {
         const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)stage * STAGE);
         const unsigned soffP = (unsigned)m0s * (unsigned)p.N * 2u;
         eg_bufdma1f<0>(srdP, vP[0], soffP, base);
-        eg_bufdma1f<0x2000>(srdP, vP[1], soffP, base);
+        if constexpr (NPP_P > 1) eg_bufdma1f<0x2000>(srdP, vP[NPP_P - 1], soffP, base);
         const int b_s = m0s >> (p.lOH + p.lOW);
         const int oy_s = p.nimg == 1 ? ((m0s >> p.lOW) & OHm) : 0;
         const int ybase = oy_s * 2;
         const int pixbase = (b_s * p.H + ybase) * p.W;   // source pixel of (image b_s, row 2 * oy_s, column 0)
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
-            if (j < p.npp && (wave + 8 * j) * 4 < p.npix) {         // (pieces past the patch would land in the next stage)
+            if (j < p.npp && (wave + 8 * j) * RPP < p.npix) {       // (pieces past the patch would land in the next stage)
                 const int iy = ybase + xdy[j];
                 const bool ok = xa[j] >= 0 && iy >= 0 && iy < p.H;
                 const unsigned v = ok ? (unsigned)(xa[j] + (pixbase + xdy[j] * p.W) * (int)row_bytes) : EG_OOB;
@@ -122,11 +129,11 @@ __global__ __launch_bounds__(512) void igemm_tn8_kernel(const Tn8Params p) {
         }
     };
 
-    f32x4 acc[4][8];
+    f32x4 acc[NI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
     auto tr2 = [&](const char* base, int a_lo, int a_hi) {          // 8 K-consecutive 16-bit elements of one column: two transposed reads
@@ -140,15 +147,15 @@ __global__ __launch_bounds__(512) void igemm_tn8_kernel(const Tn8Params p) {
         const char* sx = sp + STAGE_P;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            uint4 af[4], bfr[8];
+            uint4 af[NI], bfr[NJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = tr2(sp, frag_addr(prow[2 * kb], nh * 4 + i), frag_addr(prow[2 * kb + 1], nh * 4 + i));
+            for (int i = 0; i < NI; ++i) af[i] = tr2(sp, frag_addr(prow[2 * kb], nh * NI + i), frag_addr(prow[2 * kb + 1], nh * NI + i));
 #pragma unroll
-            for (int j = 0; j < 8; ++j) bfr[j] = tr2(sx, frag_addr(xrow[2 * kb], j), frag_addr(xrow[2 * kb + 1], j));
+            for (int j = 0; j < NJ; ++j) bfr[j] = tr2(sx, frag_addr(xrow[2 * kb], j), frag_addr(xrow[2 * kb + 1], j));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     if constexpr (std::is_same<T, f16_t>::value)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, af[i]), __builtin_bit_cast(f16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
                     else
@@ -162,8 +169,8 @@ __global__ __launch_bounds__(512) void igemm_tn8_kernel(const Tn8Params p) {
     };
 
     // ring: K step s lives in stage s % 3; steps s + 1 and s + 2 are in flight while step s is multiplied
-    int per = 2;                                         // pieces this wave issues per K step
-    for (int j = 0; j < p.npp; ++j) per += (wave + 8 * j) * 4 < p.npix;
+    int per = NPP_P;                                     // pieces this wave issues per K step
+    for (int j = 0; j < p.npp; ++j) per += (wave + 8 * j) * RPP < p.npix;
     if (nk > 0) issue(0, 0);
     if (nk > 1) issue(1, 1);
     tn8_wait(nk > 1 ? per : 0);
@@ -184,13 +191,13 @@ __global__ __launch_bounds__(512) void igemm_tn8_kernel(const Tn8Params p) {
     const int tap = (ry + 2 * ay) * 4 + (rx + 2 * ax);
     float* slab = p.slab + (size_t)blockIdx.z * p.N * 16 * p.C;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int n = n0 + (nh * 4 + i) * 16 + g * 4 + r;
+            const int n = n0 + (nh * NI + i) * 16 + g * 4 + r;
             float* row = slab + ((size_t)n * 16 + tap) * p.C + c0 + li;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) row[j * 16] = acc[i][j][r];
+            for (int j = 0; j < NJ; ++j) row[j * 16] = acc[i][j][r];
         }
 }
 
@@ -201,7 +208,8 @@ __global__ __launch_bounds__(512) void igemm_tn8_kernel(const Tn8Params p) {
 bool eg_tn8_plan(const eg_conv* c, int dtype, Tn8Params& p, int* nsplit, int wgs_target) {
     static const bool enabled = [] { const char* e = getenv("EG_TN8"); return !(e && atoi(e) == 0); }();
     if (!enabled || dtype == EG_F32 || c->k != 4 || c->stride != 2 || c->pad != 1 || c->up != 0) return false;
-    if ((c->Cin % 128) != 0 || (c->Cout % 128) != 0 || (c->H & 1) || (c->W & 1)) return false;
+    const int ch = ((c->Cin % 128) == 0 && (c->Cout % 128) == 0) ? 128 : (((c->Cin % 64) == 0 && (c->Cout % 64) == 0) ? 64 : 0);
+    if (ch == 0 || (c->H & 1) || (c->W & 1)) return false;
     const int OH = c->H / 2, OW = c->W / 2;
     const int lOH = ilog2_exact(OH), lOW = ilog2_exact(OW);
     const long long M = (long long)c->B * OH * OW;
@@ -215,12 +223,15 @@ bool eg_tn8_plan(const eg_conv* c, int dtype, Tn8Params& p, int* nsplit, int wgs
     p.PH = p.OHt + 1; p.PW = OW + 1;
     p.npix = p.nimg * p.PH * p.PW;
     if (p.npix > EG_TN8_XSLOTS) return false;
-    p.npp = ((p.npix + 3) / 4 + 7) / 8;
+    p.ch = ch;
+    const int rpp = 1024 / (ch * 2);                    // patch pixels per DMA piece
+    p.npp = ((p.npix + rpp - 1) / rpp + 7) / 8;
+    if (p.npp > 5) return false;
     p.inv_pw = (1u << 20) / (unsigned)p.PW + 1;
     p.inv_plane = (1u << 20) / (unsigned)(p.PH * p.PW) + 1;
     for (unsigned x = 0; x < 512; ++x)
         if (((x * p.inv_pw) >> 20) != x / (unsigned)p.PW || ((x * p.inv_plane) >> 20) != x / (unsigned)(p.PH * p.PW)) return false;
-    p.ntn = c->Cout / 128; p.ntc = c->Cin / 128;
+    p.ntn = c->Cout / ch; p.ntc = c->Cin / ch;
     // one workgroup per CU (150 KiB of LDS): split m until about 256 workgroups exist, at least 4 K steps each
     const long long base = (long long)p.ntn * p.ntc * 4;
     // (wgs_target: the caller's share of the chip -- a launch forked beside the main chain's GEMMs runs the step fastest at 128: half the
@@ -236,15 +247,21 @@ bool eg_tn8_plan(const eg_conv* c, int dtype, Tn8Params& p, int* nsplit, int wgs
     return true;
 }
 
-template <typename T>
-void eg_launch_tn8(const Tn8Params& p, int nsplit, hipStream_t st) {
-    constexpr size_t lds = 3 * (64 * 256 + EG_TN8_XSLOTS * 256);
+template <typename T, int CH>
+static void launch_tn8_ch(const Tn8Params& p, int nsplit, hipStream_t st) {
+    constexpr size_t lds = 3 * (size_t)(64 + EG_TN8_XSLOTS) * CH * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_tn8_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_tn8_kernel<T, CH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((igemm_tn8_kernel<T>), dim3(p.ntn * p.ntc, 4, nsplit), dim3(512), lds, st, p);
+    hipLaunchKernelGGL((igemm_tn8_kernel<T, CH>), dim3(p.ntn * p.ntc, 4, nsplit), dim3(512), lds, st, p);
+}
+
+template <typename T>
+void eg_launch_tn8(const Tn8Params& p, int nsplit, hipStream_t st) {
+    if (p.ch == 64) launch_tn8_ch<T, 64>(p, nsplit, st);
+    else launch_tn8_ch<T, 128>(p, nsplit, st);
 }
 template void eg_launch_tn8<bf16_t>(const Tn8Params&, int, hipStream_t);
 template void eg_launch_tn8<f16_t>(const Tn8Params&, int, hipStream_t);

@@ -143,7 +143,9 @@ def test_conv_wgrad(case, dtype):
 # B, H (input), Cin, Cout: 4x4 / stride-2 / pad-1 layers with channel counts in multiples of 128 -> the parity-class weight-gradient
 # kernel (igemm_tn8.hip).  Output lattices 16x16 (bands of 4 rows per K step), 8x8 (one image per step), 4x4 (four images per step),
 # 32x32 (2 rows per step), 2x2 (16 images per step); several splits over m; both channel tilings > 1
-TN8_CASES = [(8, 32, 128, 256), (12, 16, 256, 128), (16, 8, 128, 128), (4, 64, 128, 128), (64, 4, 256, 256), (5 * 4, 16, 128, 128)]
+TN8_CASES = [(8, 32, 128, 256), (12, 16, 256, 128), (16, 8, 128, 128), (4, 64, 128, 128), (64, 4, 256, 256), (5 * 4, 16, 128, 128),
+             # 64-channel tiles (the dSprites networks' layers; 192 = 3 tiles of 64)
+             (8, 64, 64, 64), (16, 32, 64, 64), (16, 16, 64, 192), (32, 8, 64, 64), (24, 8, 192, 64)]
 
 
 @pytest.mark.parametrize("dtype", [1, 2])
