@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying one hipGraph")
     ap.add_argument("--graph-dist", action="store_true", help="N > 1: capture the iteration (RCCL collectives included) into one hipGraph.  Default at "
                     "N > 1 is eager launches: the captured multi-rank path could only be rehearsed with a 1-rank group on the build's one-GPU box, "
-                    "a capture that fails in the runtime cannot always be caught from Python, and eager costs 0.5 %% (4.73 vs 4.70 ms at N = 1)")
+                    "a capture that fails in the runtime cannot always be caught from Python, and eager costs 2 %% (4.73 vs 4.63 ms at N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5)
