@@ -1027,9 +1027,8 @@ class CelebATrainer:
         side.join()                                     # D's panels, power iterations, patch rows
         out = de.forward([gen, self.scaled, self.real], 0, prepared=(False, True, True))
         o_gen, o_trans, o_real = out[:B], out[B:2 * B], out[2 * B:]
-        ops.loss_mse(o_gen, 19, 1, cd, B, self.code, cd, 0.0, lcon, self.losses[2:3], self.dout[:B])
-        ops.loss_ce_softmaxed(o_gen, 19, cd + 1, nc, B, self.labels, lcat, self.losses[2:3], self.dout[:B])
-        ops.loss_affine_rpqxy(o_real, o_trans, 19, 1, B, self.code, cd, laff, self.losses[2:3], self.dout[2 * B:], self.dout[B:2 * B])
+        ops.loss_info_rpqxy(o_gen, o_trans, o_real, 19, 1, cd, nc, B, self.code, cd, self.labels, lcat, lcon, laff, self.losses[2:3], self.dout[:B],
+                            self.dout[B:2 * B], self.dout[2 * B:])               # the three losses in one launch
         dimg = de.backward(0, 3, self.dout, da.grad, need_dimg=True, side=side)
         # D's update beside the generator backward; it ticks optimizer_info's counter (shared by both arenas), G's does not
         update(da, self.miD, self.viD, self.lr[2], 2, True, False, de, where="d3")

@@ -103,9 +103,9 @@ extern "C" int eg_loss_bce_sigmoid(const float* o, int ld, int col, int B, float
 }
 
 // MSE(o[:,col0:col0+n], target) * scale  (target: per-element tensor tgt[B][ldt] or constant when tgt==null)
-__global__ void mse_kernel(const float* __restrict__ o, int ld, int col0, int n, int B, const float* __restrict__ tgt, int ldt, float tconst,
-                           float scale, float* loss, float* __restrict__ dout, int zero_rows) {
-    __shared__ float sm[16];
+// (the three bodies are real function calls: the fused launch and the stand-alone launches then run the SAME machine code and give the same bits)
+__device__ __attribute__((noinline)) void mse_body(const float* __restrict__ o, int ld, int col0, int n, int B, const float* __restrict__ tgt, int ldt, float tconst,
+                                         float scale, float* loss, float* __restrict__ dout, int zero_rows, float* sm) {
     float acc = 0.f;
     const float gs = 2.f * scale / (float)(B * n);
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
@@ -120,6 +120,11 @@ __global__ void mse_kernel(const float* __restrict__ o, int ld, int col0, int n,
     const float tot = block_sum(acc, sm);
     if (threadIdx.x == 0 && loss) loss[0] += scale * tot / (float)(B * n);
 }
+__global__ void mse_kernel(const float* __restrict__ o, int ld, int col0, int n, int B, const float* __restrict__ tgt, int ldt, float tconst,
+                           float scale, float* loss, float* __restrict__ dout, int zero_rows) {
+    __shared__ float sm[16];
+    mse_body(o, ld, col0, n, B, tgt, ldt, tconst, scale, loss, dout, zero_rows, sm);
+}
 
 extern "C" int eg_loss_mse(const float* o, int ld, int col0, int n, int B, const float* tgt, int ldt, float tconst, float scale, float* loss,
                            float* dout, int zero_rows, eg_stream_t s) {
@@ -132,9 +137,8 @@ extern "C" int eg_loss_mse(const float* o, int ld, int col0, int n, int B, const
 // CrossEntropyLoss applied to softmax(o[:,c0:c0+n]) (the reference feeds probabilities, i.e. a double softmax:
 // celebA/EAD-GAN_celebA.py:132,383 ; MNIST/EAD-GAN_rpqmnxy.py:161,427).  Adds into dout (does not zero).
 #define EG_MAXCAT 16
-__global__ void ce_softmaxed_kernel(const float* __restrict__ o, int ld, int c0, int n, int B, const long long* __restrict__ labels,
-                                    float scale, float* loss, float* __restrict__ dout) {
-    __shared__ float sm[16];
+__device__ __attribute__((noinline)) void ce_softmaxed_body(const float* __restrict__ o, int ld, int c0, int n, int B, const long long* __restrict__ labels,
+                                                  float scale, float* loss, float* __restrict__ dout, float* sm) {
     float acc = 0.f;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         float q[EG_MAXCAT], r[EG_MAXCAT];
@@ -159,6 +163,11 @@ __global__ void ce_softmaxed_kernel(const float* __restrict__ o, int ld, int c0,
     const float tot = block_sum(acc, sm);
     if (threadIdx.x == 0 && loss) loss[0] += scale * tot / (float)B;
 }
+__global__ void ce_softmaxed_kernel(const float* __restrict__ o, int ld, int c0, int n, int B, const long long* __restrict__ labels,
+                                    float scale, float* loss, float* __restrict__ dout) {
+    __shared__ float sm[16];
+    ce_softmaxed_body(o, ld, c0, n, B, labels, scale, loss, dout, sm);
+}
 
 extern "C" int eg_loss_ce_softmaxed(const float* o, int ld, int c0, int n, int B, const long long* labels, float scale, float* loss,
                                     float* dout, eg_stream_t s) {
@@ -170,13 +179,14 @@ extern "C" int eg_loss_ce_softmaxed(const float* o, int ld, int c0, int n, int B
 
 // affine-consistency loss, CelebA variant:  MSE(regulariser(real_code, trans_code), code[:, :5]) * scale
 // o_real / o_trans: head outputs [B][ld], codes start at column c0.  d_real / d_trans rows are zero-filled.
-__global__ void affine_reg_rpqxy_kernel(const float* __restrict__ o_real, const float* __restrict__ o_trans, int ld, int c0, int B,
-                                        const float* __restrict__ code, int ldc, float scale, float* loss, float* __restrict__ d_real,
-                                        float* __restrict__ d_trans, float* __restrict__ pred_out) {
-    __shared__ float sm[16];
+// nthr: threads that take samples (the stand-alone launch has 128; inside the fused info-loss launch the other waves add zeros to the
+// block sum, which keeps the summation order of the stand-alone kernel)
+__device__ __attribute__((noinline)) void affine_reg_rpqxy_body(const float* __restrict__ o_real, const float* __restrict__ o_trans, int ld, int c0, int B,
+                                                      const float* __restrict__ code, int ldc, float scale, float* loss, float* __restrict__ d_real,
+                                                      float* __restrict__ d_trans, float* __restrict__ pred_out, int nthr, float* sm) {
     float acc = 0.f;
     const float gs = 2.f * scale / (float)(B * 5);
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    for (int b = threadIdx.x; b < B && (int)threadIdx.x < nthr; b += nthr) {
         Dual<10> rc[5], tc[5], out[5];
         for (int i = 0; i < 5; ++i) {
             rc[i] = dvar<10>(o_real[(size_t)b * ld + c0 + i], i);
@@ -198,6 +208,38 @@ __global__ void affine_reg_rpqxy_kernel(const float* __restrict__ o_real, const 
     }
     const float tot = block_sum(acc, sm);
     if (threadIdx.x == 0 && loss) loss[0] += scale * tot / (float)(B * 5);
+}
+__global__ void affine_reg_rpqxy_kernel(const float* __restrict__ o_real, const float* __restrict__ o_trans, int ld, int c0, int B,
+                                        const float* __restrict__ code, int ldc, float scale, float* loss, float* __restrict__ d_real,
+                                        float* __restrict__ d_trans, float* __restrict__ pred_out) {
+    __shared__ float sm[16];
+    affine_reg_rpqxy_body(o_real, o_trans, ld, c0, B, code, ldc, scale, loss, d_real, d_trans, pred_out, blockDim.x, sm);
+}
+
+// the three losses of the CelebA info step in ONE launch (celebA/EAD-GAN_celebA.py:390-396: lambda_con * MSE(cont, code) + lambda_cat *
+// CE(cat, labels) on D(gen), lambda_affine * MSE(affine_regularzier(D(real), D(trans)), code[:, :5])): one block runs the three bodies one
+// after the other -- they add to the same loss scalar and to the same gradient rows, in the order of the three stand-alone launches.
+__global__ __launch_bounds__(256) void info_losses_rpqxy_kernel(const float* __restrict__ o_gen, const float* __restrict__ o_trans, const float* __restrict__ o_real,
+                                                                int ld, int c_cont, int n_cont, int n_cat, int B, const float* __restrict__ code, int ldc,
+                                                                const long long* __restrict__ labels, float lcat, float lcon, float laff, float* loss,
+                                                                float* __restrict__ d_gen, float* __restrict__ d_trans, float* __restrict__ d_real) {
+    __shared__ float sm[16];
+    mse_body(o_gen, ld, c_cont, n_cont, B, code, ldc, 0.f, lcon, loss, d_gen, 1, sm);
+    __syncthreads();
+    ce_softmaxed_body(o_gen, ld, c_cont + n_cont, n_cat, B, labels, lcat, loss, d_gen, sm);
+    __syncthreads();
+    affine_reg_rpqxy_body(o_real, o_trans, ld, c_cont, B, code, ldc, laff, loss, d_real, d_trans, nullptr, 128, sm);
+}
+
+extern "C" int eg_loss_info_rpqxy(const float* o_gen, const float* o_trans, const float* o_real, int ld, int c_cont, int n_cont, int n_cat, int B,
+                                  const float* code, int ldc, const long long* labels, float lcat, float lcon, float laff, float* loss, float* d_gen,
+                                  float* d_trans, float* d_real, eg_stream_t s) {
+    EG_REQUIRE(o_gen && o_trans && o_real && code && labels && loss && d_gen && d_trans && d_real && B > 0 && n_cat <= EG_MAXCAT && n_cont >= 5,
+               "eg_loss_info_rpqxy: bad argument");
+    hipLaunchKernelGGL(info_losses_rpqxy_kernel, dim3(1), dim3(256), 0, (hipStream_t)s, o_gen, o_trans, o_real, ld, c_cont, n_cont, n_cat, B, code, ldc,
+                       labels, lcat, lcon, laff, loss, d_gen, d_trans, d_real);
+    EG_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int eg_loss_affine_rpqxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc, float scale,

@@ -466,6 +466,12 @@ def loss_affine_rpqxy(o_real, o_trans, ld, c0, B, code, ldc, scale, loss, d_real
     lib().call("eg_loss_affine_rpqxy", _p(o_real), _p(o_trans), ld, c0, B, _p(code), ldc, scale, _p(loss), _p(d_real), _p(d_trans), _p(pred_out), _stream())
 
 
+def loss_info_rpqxy(o_gen, o_trans, o_real, ld, c_cont, n_cont, n_cat, B, code, ldc, labels, lcat, lcon, laff, loss, d_gen, d_trans, d_real):
+    """loss_mse + loss_ce_softmaxed + loss_affine_rpqxy of the CelebA info step as one launch (same numbers)"""
+    lib().call("eg_loss_info_rpqxy", _p(o_gen), _p(o_trans), _p(o_real), ld, c_cont, n_cont, n_cat, B, _p(code), ldc, _p(labels), lcat, lcon, laff,
+               _p(loss), _p(d_gen), _p(d_trans), _p(d_real), _stream())
+
+
 # ---- device-side input pipeline -------------------------------------------------------------------
 RNG_UNIFORM, RNG_NORMAL, RNG_RANDINT, RNG_BERNOULLI = 0, 1, 2, 3
 

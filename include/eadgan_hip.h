@@ -317,6 +317,13 @@ int eg_add_f32(float* out, const float* a, const float* b, size_t n, eg_stream_t
 int eg_u8_to_f32(const unsigned char* x, float* y, size_t n, eg_stream_t s);            /* uint8 sprites -> float (rp.py:369-370) */
 int eg_loss_affine_rpqxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc,
                          float scale, float* loss, float* d_real, float* d_trans, float* pred_out, eg_stream_t s);
+/* the info step's three losses in one launch (celebA.py:390-396): lcon * MSE(o_gen[:, c_cont : c_cont+n_cont], code) + lcat *
+ * CE(softmax(o_gen[:, c_cont+n_cont : +n_cat]), labels) into d_gen (rows zeroed first), laff * MSE(affine_regularzier(o_real, o_trans),
+ * code[:, :5]) into d_real / d_trans; all three add to loss[0] in that order -- the same numbers as eg_loss_mse, eg_loss_ce_softmaxed and
+ * eg_loss_affine_rpqxy launched one after the other */
+int eg_loss_info_rpqxy(const float* o_gen, const float* o_trans, const float* o_real, int ld, int c_cont, int n_cont, int n_cat, int B,
+                       const float* code, int ldc, const long long* labels, float lcat, float lcon, float laff, float* loss, float* d_gen,
+                       float* d_trans, float* d_real, eg_stream_t s);
 
 /* regression target of the approximator fit (MNIST/approximate_rpqmnxy.py:43-60,119-136): affine parameters of a code */
 int eg_affine_para_rpqmnxy(const float* code, int ldc, int B, float* para, eg_stream_t s);

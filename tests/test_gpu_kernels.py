@@ -349,6 +349,33 @@ def test_adam_bucket_slices_equal_the_whole_arena_update():
         assert torch.equal(gb[lo:hi], torch.zeros(hi - lo, device=DEV) if k % 2 == 0 else gr[lo:hi]), k
 
 
+def test_info_losses_in_one_launch_equal_the_three_launches():
+    """eg_loss_info_rpqxy (the CelebA info step's MSE + CE + affine-consistency losses, celebA/EAD-GAN_celebA.py:390-396, as one launch)
+    against eg_loss_mse, eg_loss_ce_softmaxed and eg_loss_affine_rpqxy launched one after the other: the same loss and the same three
+    gradient blocks, bit for bit (the bodies are shared, non-inlined device functions)."""
+    B, cd, nc = 37, 8, 10
+    g = torch.Generator().manual_seed(12)
+    out = torch.randn(3 * B, 19, generator=g).to(DEV)
+    code = (torch.rand(B, cd, generator=g) * 2 - 1).to(DEV)
+    labels = torch.randint(0, nc, (B,), generator=g).to(DEV)
+    o_gen, o_trans, o_real = out[:B], out[B:2 * B], out[2 * B:]
+
+    def three():
+        L, d = torch.zeros(4, device=DEV), torch.full((3 * B, 19), 7.0, device=DEV)
+        ops.loss_mse(o_gen, 19, 1, cd, B, code, cd, 0.0, 0.7, L[2:3], d[:B])
+        ops.loss_ce_softmaxed(o_gen, 19, cd + 1, nc, B, labels, 1.3, L[2:3], d[:B])
+        ops.loss_affine_rpqxy(o_real, o_trans, 19, 1, B, code, cd, 0.9, L[2:3], d[2 * B:], d[B:2 * B])
+        return L, d
+
+    def one():
+        L, d = torch.zeros(4, device=DEV), torch.full((3 * B, 19), 7.0, device=DEV)
+        ops.loss_info_rpqxy(o_gen, o_trans, o_real, 19, 1, cd, nc, B, code, cd, labels, 1.3, 0.7, 0.9, L[2:3], d[:B], d[B:2 * B], d[2 * B:])
+        return L, d
+    (La, da), (Lb, db) = three(), one()
+    torch.cuda.synchronize()
+    assert torch.equal(La, Lb) and torch.equal(da, db) and float(La[2]) > 0
+
+
 def test_warp_and_theta_match_golden():
     import os
     from conftest import GOLDEN
