@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--graph-dist", action="store_true", help="N > 1: capture the iteration (RCCL collectives included) into one hipGraph.  Default at "
                     "N > 1 is eager launches: the captured multi-rank path could only be rehearsed with a 1-rank group on the build's one-GPU box, "
                     "a capture that fails in the runtime cannot always be caught from Python, and eager costs 2 %% (4.73 vs 4.63 ms at N = 1)")
+    ap.add_argument("--no-probe", action="store_true", help="skip the child-process capture probe (see decide_graph) and capture directly; a capture "
+                    "failure then ends this process with a non-zero exit code")
+    ap.add_argument("--probe-capture", action="store_true", help=argparse.SUPPRESS)     # internal: this process IS the probe child
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=5)
@@ -137,17 +140,61 @@ def want_graph(a, world):
     return world == 1 or a.graph_dist
 
 
-def capture_or_eager(tr, rank, **kw):
-    """hipGraph capture of the resident step (RCCL collectives included when world > 1); a capture that fails -- e.g. a collective that
-    refuses it -- leaves the trainer on eager launches, and the bench line says so in config.workload."""
+def decide_graph(a, world):
+    """hipGraph replay or eager launches?  Decided BEFORE this process touches the GPU.  A failed hipGraph capture cannot be recovered from
+    inside the process on ROCm 7.2 (engine.CaptureFailed: streams forked into the invalidated capture crash the runtime later), so when a
+    graph is wanted the same command is first run as a child process with --probe-capture: it builds the trainer, runs one eager
+    iteration, captures, replays twice and exits 0 -- or prints the reason and exits non-zero.  Only after a clean probe does this process
+    capture; otherwise it launches eagerly and says so in config.workload.  (N > 1 with --graph-dist: every rank probes with its own
+    child, the children form their own process group on MASTER_PORT + 1, and the ranks agree on the minimum of their verdicts.)
+    Returns (use_graph, note)."""
+    if not want_graph(a, world):
+        return False, ""
+    if a.no_probe or a.probe_capture:
+        return True, ""
+    import subprocess
+    env = dict(os.environ)
+    if "MASTER_PORT" in env:
+        env["MASTER_PORT"] = str(int(env["MASTER_PORT"]) + 1)
+    argv = [x for x in sys.argv[1:] if x not in ("--no-cpu-baseline", "--no-roofline")]
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--probe-capture", "--no-cpu-baseline", "--no-roofline"]
+    try:
+        rc = subprocess.run(cmd, env=env, stdout=subprocess.DEVNULL, timeout=600).returncode
+    except subprocess.TimeoutExpired:
+        rc = -999
+    if rc == 0:
+        return True, ""
+    print(f"[bench] capture probe exited with code {rc}: launching eagerly", file=sys.stderr, flush=True)
+    return False, f" (hipGraph capture failed in the probe process, rc {rc})"
+
+
+def agree_on_graph(eg, use_graph, dev):
+    """all ranks capture, or none does"""
+    if not torch.distributed.is_initialized() or torch.distributed.get_world_size() == 1:
+        return use_graph
+    t = torch.tensor([1.0 if use_graph else 0.0], device=dev)
+    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+    return bool(t.item() > 0.5)
+
+
+def capture_or_exit(eg, tr, **kw):
+    """hipGraph capture of the resident step (RCCL collectives included when world > 1).  A failure ends the process with a non-zero exit
+    code and the reason on stderr (engine.exit_after_capture_failure): there is no in-process fallback."""
     try:
         tr.capture(**kw)
-        return True
-    except Exception as exc:
-        print(f"[bench] hipGraph capture failed on rank {rank} ({type(exc).__name__}: {exc}); falling back to eager launches", file=sys.stderr)
-        tr.graph = None
-        torch.cuda.synchronize()
-        return False
+    except eg.engine.CaptureFailed as exc:
+        eg.engine.exit_after_capture_failure(exc)
+    return True
+
+
+def probe_exit(tr):
+    """the probe child's job is done once two replays have completed"""
+    tr.step_resident()
+    tr.step_resident()
+    torch.cuda.synchronize()
+    print("[bench] capture probe ok", file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    os._exit(0)
 
 
 def cpu_baseline(B, steps, warm=2):
@@ -193,7 +240,9 @@ def main_mnist(a, eg, rank, world, local, dev):
         inputs = eg.mnist.DeviceInputs(torch.randint(0, 256, (65536, 1, 32, 32), device=dev, dtype=torch.uint8, generator=g), seed=1000 + rank)
         tr.inputs = inputs
     tr.step_resident()
-    use_graph = want_graph(a, world) and capture_or_eager(tr, rank, inputs=inputs)
+    use_graph = agree_on_graph(eg, a.use_graph, dev) and capture_or_exit(eg, tr, inputs=inputs)
+    if a.probe_capture:
+        probe_exit(tr)
     for _ in range(max(a.warmup - 1, 0)):
         tr.step_resident()
     eg.dp.barrier()
@@ -214,7 +263,7 @@ def main_mnist(a, eg, rank, world, local, dev):
                           "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic" + ("" if a.resident_inputs else " (every batch drawn on the device inside the timed step)"),
                           "config": {"workload": f"EAD-GAN MNIST 32x32x1 full train iteration (G + D + info/affine over G+E), batch {B}/GPU, "
-                                                 f"{'hipGraph replay' if use_graph else 'eager launches'}", "per_gpu_batch": B, "parallelism": f"dp{world}"},
+                                                 f"{'hipGraph replay' if use_graph else 'eager launches' + a.graph_note}", "per_gpu_batch": B, "parallelism": f"dp{world}"},
                           "whole_step_mfma_frac": round(ips / world * 1.403 / 1e3 / peak, 5), "roofline": roof, "cpu_baseline": None,
                           "final_losses": [round(x, 4) for x in tr.losses.tolist()[:3]],
                           "kernel_table": kernel_table(table) if table else None}), flush=True)
@@ -245,7 +294,9 @@ def main_sprites(a, eg, rank, world, local, dev):
         inputs = mod.DeviceInputs(synthetic_sprites(32768, dev, g), seed=1000 + rank)
         tr.inputs = inputs
     tr.step_resident()
-    use_graph = want_graph(a, world) and capture_or_eager(tr, rank, inputs=inputs)
+    use_graph = agree_on_graph(eg, a.use_graph, dev) and capture_or_exit(eg, tr, inputs=inputs)
+    if a.probe_capture:
+        probe_exit(tr)
     for _ in range(max(a.warmup - 1, 0)):
         tr.step_resident()
     eg.dp.barrier()
@@ -267,7 +318,7 @@ def main_sprites(a, eg, rank, world, local, dev):
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic" + ("" if a.resident_inputs else " (every batch drawn on the device inside the timed step)"),
                           "config": {"workload": f"EAD-GAN {'colored ' if color else ''}dSprites full train iteration (D step + joint info/affine/G step), batch {B}/GPU, "
-                                                 f"{'hipGraph replay' if use_graph else 'eager launches'}", "per_gpu_batch": B, "parallelism": f"dp{world}"},
+                                                 f"{'hipGraph replay' if use_graph else 'eager launches' + a.graph_note}", "per_gpu_batch": B, "parallelism": f"dp{world}"},
                           "whole_step_mfma_frac": round(ips / world * gf / 1e3 / peak, 5), "roofline": roof, "cpu_baseline": None,
                           "final_losses": [round(x, 4) for x in tr.losses.tolist()[:5]],
                           "kernel_table": kernel_table(table) if table else None}), flush=True)
@@ -282,7 +333,9 @@ def main_pxy(a, eg, rank, world, local, dev):
     g = torch.Generator(device=dev).manual_seed(1000 + rank)
     tr.load_inputs(synthetic_sprites(B, dev, g), torch.rand((B, 3), device=dev, generator=g) * 2 - 1)
     tr.step_resident()
-    use_graph = want_graph(a, world) and capture_or_eager(tr, rank)
+    use_graph = agree_on_graph(eg, a.use_graph, dev) and capture_or_exit(eg, tr)
+    if a.probe_capture:
+        probe_exit(tr)
     for _ in range(max(a.warmup - 1, 0)):
         tr.step_resident()
     eg.dp.barrier()
@@ -298,12 +351,14 @@ def main_pxy(a, eg, rank, world, local, dev):
                           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
                           "config": {"workload": f"dSprites/pxy.py iteration (E(img), E(warp(img)), affine regulariser, Adam), batch {B}/GPU, "
-                                                 f"{'hipGraph replay' if use_graph else 'eager launches'}", "per_gpu_batch": B, "parallelism": f"dp{world}"},
+                                                 f"{'hipGraph replay' if use_graph else 'eager launches' + a.graph_note}", "per_gpu_batch": B, "parallelism": f"dp{world}"},
                           "roofline": None, "cpu_baseline": None, "final_losses": [round(tr.losses.tolist()[0], 4)]}), flush=True)
 
 
 def main():
     a = parse()
+    # graph or eager: decided by a child process before this one loads the HIP library or initialises the GPU (decide_graph)
+    a.use_graph, a.graph_note = decide_graph(a, int(os.environ.get("WORLD_SIZE", "1")))
     eg = importlib.import_module("ead-gan_amd")
     if a.force_dist and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -343,7 +398,9 @@ def main():
         inputs = eg.celeba.DeviceInputs(torch.randint(0, 256, (16384, 3, 64, 64), device=dev, dtype=torch.uint8, generator=g), seed=1000 + rank)
         tr.inputs = inputs
     tr.step_resident()                                   # first eager iteration: loads kernels, sizes workspaces (and RCCL channels)
-    use_graph = want_graph(a, world) and capture_or_eager(tr, rank, inputs=inputs)     # RCCL collectives are captured into the same hipGraph
+    use_graph = agree_on_graph(eg, a.use_graph, dev) and capture_or_exit(eg, tr, inputs=inputs)     # RCCL collectives are captured into the same hipGraph
+    if a.probe_capture:
+        probe_exit(tr)
     for _ in range(max(a.warmup - 1, 0)):
         tr.step_resident()
     eg.dp.barrier()
@@ -373,7 +430,7 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic" + ("" if a.resident_inputs else " (every batch drawn on the device inside the timed step: uint8 gather + flip + normalise, Philox z / code / labels)"),
             "config": {"workload": f"EAD-GAN CelebA 64x64x3 full train iteration (G adv + D + info/affine, 3 Adams), batch {B}/GPU, "
-                                   f"{'hipGraph replay' if use_graph else 'eager launches'}, data-parallel x{world}",
+                                   f"{'hipGraph replay' if use_graph else 'eager launches' + a.graph_note}, data-parallel x{world}",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
             "whole_step_mfma_frac": round(ips / world * GFLOP_PER_IMG / 1e3 / peak, 4),
             "roofline": roof, "cpu_baseline": cpu,

@@ -19,7 +19,7 @@ import torch.nn as nn
 from torch.nn.utils import spectral_norm
 
 from . import ops
-from .engine import Arena, ConvRec, SideStream, Workspace, capture_step, parse_dtype
+from .engine import Arena, ConvRec, SideStream, Workspace, capture_step, check_usable, parse_dtype
 from .ops import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, EG_BF16, EG_F32, OUT_NCHW_F32)
 
 # module-level hyper-parameters, mirroring the reference's global ``opt`` (argparse defaults, :39-51)
@@ -1088,6 +1088,7 @@ class CelebATrainer:
     def step_resident(self):
         """Run one iteration on whatever is in the static input slots (or on fresh device-side draws if the trainer was captured /
         configured with a DeviceInputs); returns the device loss tensor [g,d,info,_]."""
+        check_usable(self)
         if self.graph is not None:
             self.graph.replay()
         else:

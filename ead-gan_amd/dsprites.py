@@ -15,7 +15,7 @@ from torch.nn.utils import spectral_norm
 
 from . import ops
 from .celeba import IMG_GEMM, _HipModule, _require_cuda, transformation_2D      # noqa: F401
-from .engine import Arena, ConvRec, DeviceSampler, ResidentStep, SideStream, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step, parse_dtype
+from .engine import Arena, ConvRec, DeviceSampler, ResidentStep, SideStream, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step, check_usable, parse_dtype
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, EG_F32, OUT_NCHW_F32
 from .trunk import Head, TrunkEngine
 
@@ -577,6 +577,7 @@ class PxyTrainer:
         return capture_step(self, self._step_body)
 
     def step_resident(self):
+        check_usable(self)
         if self.graph is not None:
             self.graph.replay()
         else:

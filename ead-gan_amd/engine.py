@@ -411,6 +411,7 @@ class ResidentStep:
         return capture_step(self, self._step_with_inputs)
 
     def step_resident(self):
+        check_usable(self)
         if self.graph is not None:
             self.graph.replay()
         else:
@@ -418,30 +419,46 @@ class ResidentStep:
         return self.losses
 
 
+class CaptureFailed(RuntimeError):
+    """A hipGraph capture of a training iteration failed.  THE PROCESS IS NOT USABLE FOR GPU WORK AFTERWARDS: on ROCm 7.2 every stream
+    that was forked into the capture (weight-gradient lanes, optimizer / preparation lanes, a second chain, the input sampler's and a
+    collective's internal streams) stays attached to the invalidated capture, and launching on them, destroying them or merely letting
+    them be garbage-collected crashes the runtime a little later (observed: SIGSEGV three seconds after an `in-process recovery' that
+    restored the stream, drained the sticky error and replaced the lanes -- gpurun_out/r02_z_dp2.err).  There is no in-process
+    recovery; the contract is: report the reason and end the process (``engine.exit_after_capture_failure``).  Callers that want an
+    eager fallback decide graph-vs-eager BEFORE they touch the GPU, by probing the capture in a child process (bench.py does)."""
+
+
+def exit_after_capture_failure(exc, code=3):
+    """Print the reason and end the process at once (os._exit: no destructors run over streams that still belong to the invalidated
+    capture -- that is where the crash comes from)."""
+    import sys
+    print(f"[ead-gan_amd] hipGraph capture failed: {exc}\n[ead-gan_amd] this process cannot use the GPU any more; exiting with code {code} "
+          f"(launch eagerly instead: a trainer without capture(), bench.py --no-graph)", file=sys.stderr, flush=True)
+    os._exit(code)
+
+
 def capture_step(trainer, body):
-    """Capture ``body()`` (one whole training iteration) into a hipGraph and store it as ``trainer.graph``.  If the capture fails
-    (e.g. a collective that cannot be captured) the trainer stays usable for eager launches: torch.cuda.graph's exit raises
-    inside capture_end, i.e. before it restores the stream, so that is done here, HIP's sticky error is drained, and side lanes
-    that were forked into the invalidated capture are replaced; the exception is re-raised for the caller to report."""
+    """Capture ``body()`` (one whole training iteration) into a hipGraph and store it as ``trainer.graph``.  A capture that fails
+    raises :class:`CaptureFailed` and marks the trainer unusable (``step_resident`` refuses to launch): see the exception's text for
+    why no eager fallback is offered inside the same process."""
     torch.cuda.synchronize()
     graph = torch.cuda.CUDAGraph()
-    before = torch.cuda.current_stream()
     try:
         with torch.cuda.graph(graph):
             body()
-    except Exception:
+    except Exception as exc:
         trainer.graph = None
-        torch.cuda.set_stream(before)
-        try:
-            torch.cuda.synchronize()
-        except Exception:
-            pass
-        ops.clear_errors()
-        if getattr(trainer, "side", None) is not None:
-            trainer.side = SideStream(trainer.dev, Workspace.get(trainer.dev))
-        raise
+        trainer.capture_failed = f"{type(exc).__name__}: {exc}"
+        raise CaptureFailed(trainer.capture_failed) from exc
     trainer.graph = graph
     return trainer
+
+
+def check_usable(trainer):
+    why = getattr(trainer, "capture_failed", None)
+    if why is not None:
+        raise CaptureFailed(f"this trainer's hipGraph capture failed earlier ({why}); the process must not launch GPU work any more")
 
 
 class ConvRec:

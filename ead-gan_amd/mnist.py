@@ -15,7 +15,7 @@ from torch.nn.utils import spectral_norm
 
 from . import ops
 from .celeba import _HipModule, _require_cuda, transformation_2D      # noqa: F401  (same STN warp in both scripts)
-from .engine import (Arena, ConvRec, DeviceSampler, ResidentStep, SideStream, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step,
+from .engine import (Arena, ConvRec, DeviceSampler, ResidentStep, SideStream, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step, check_usable,
                      parse_dtype)
 from .ops import ACT_LRELU, ACT_NONE, ACT_TANH, EG_F32, OUT_NCHW_F32
 from .trunk import Head, TrunkEngine
@@ -657,6 +657,7 @@ class ApproximatorTrainer:
         return capture_step(self, self._step_body)
 
     def step_resident(self):
+        check_usable(self)
         if self.graph is not None:
             self.graph.replay()
         else:

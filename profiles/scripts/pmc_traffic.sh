@@ -7,7 +7,7 @@ TAG=${1:-r02}
 shift
 # further arguments go to bench.py (e.g. --workload mnist --dtype f32 --batch 256); output name: <tag>_pmc_traffic.json
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 420 rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/pmct_${TAG}_$c -o p -- python3 $R/bench.py --steps 3 --warmup 2 --no-graph --no-overlap --no-cpu-baseline --no-roofline "$@" > $R/gpurun_out/pmct_${TAG}_$c.log 2>&1 || { echo "pass $c failed"; tail -3 $R/gpurun_out/pmct_${TAG}_$c.log; exit 1; }
+  timeout -k 10 420 rocprofv3 --pmc $c --kernel-trace -d $R/gpurun_out/pmct_${TAG}_$c -o p -- python3 $R/bench.py --no-probe --steps 3 --warmup 2 --no-graph --no-overlap --no-cpu-baseline --no-roofline "$@" > $R/gpurun_out/pmct_${TAG}_$c.log 2>&1 || { echo "pass $c failed"; tail -3 $R/gpurun_out/pmct_${TAG}_$c.log; exit 1; }
   echo "pass $c done"
 done
 python3 $R/profiles/scripts/pmc_traffic_json.py $(find $R/gpurun_out/pmct_${TAG}_FETCH_SIZE -name "*.db" | head -1) $(find $R/gpurun_out/pmct_${TAG}_WRITE_SIZE -name "*.db" | head -1) $R/gpurun_out/${TAG}_pmc_traffic.json

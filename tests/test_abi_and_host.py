@@ -111,3 +111,36 @@ def test_data_parallel_gradient_average_two_gloo_ranks(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0, out.decode()
+
+
+def test_bench_decides_graph_or_eager_from_the_probe_child(monkeypatch):
+    """bench.decide_graph: the capture is probed in a child process before the measuring process touches the GPU; a probe that exits
+    non-zero (engine.exit_after_capture_failure: code 3; a runtime crash: a negative code) selects eager launches and says so."""
+    import argparse
+    import bench
+    calls = []
+
+    class R:
+        returncode = 0
+
+    def fake_run(cmd, **kw):
+        calls.append((cmd, kw.get("env", {}).get("MASTER_PORT")))
+        return R()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setenv("MASTER_PORT", "29500")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "3"])
+    a = argparse.Namespace(no_graph=False, graph_dist=False, no_probe=False, probe_capture=False)
+    assert bench.decide_graph(a, 1) == (True, "")
+    assert calls and "--probe-capture" in calls[0][0] and "--steps" in calls[0][0] and calls[0][1] == "29501"    # the children rendezvous on their own port
+    R.returncode = 3
+    use, note = bench.decide_graph(a, 1)
+    assert use is False and "rc 3" in note
+    R.returncode = -11
+    assert bench.decide_graph(a, 1)[0] is False
+    n = len(calls)
+    assert bench.decide_graph(a, 2) == (False, "")                                 # N > 1 defaults to eager: no probe
+    assert bench.decide_graph(argparse.Namespace(no_graph=True, graph_dist=False, no_probe=False, probe_capture=False), 1) == (False, "")
+    assert bench.decide_graph(argparse.Namespace(no_graph=False, graph_dist=False, no_probe=True, probe_capture=False), 1) == (True, "")
+    assert bench.decide_graph(argparse.Namespace(no_graph=False, graph_dist=False, no_probe=False, probe_capture=True), 1) == (True, "")   # the child itself
+    assert len(calls) == n

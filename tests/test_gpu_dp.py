@@ -67,7 +67,7 @@ def test_sync_batchnorm_two_ranks_equal_one_rank_at_the_same_global_batch():
 
 @pytest.mark.parametrize("family,port", [("mnist", 29551), ("dsprites", 29552)])
 def test_small_network_generators_sync_batchnorm_two_ranks(family, port):
-    """MNIST (mnist/EAD-GAN_MNIST.py:90-112) and dSprites (dSprites/rp.py:176-206) generators, three BatchNorm layers each: two ranks x 4
+    """MNIST (MNIST/EAD-GAN_rpqmnxy.py:71-98) and dSprites (dSprites/rp.py:123-157) generators, three BatchNorm layers each: two ranks x 4
     images with dp.SyncBN give the images of one rank x 8 images; the rank gradient shares sum to the whole-batch gradient; the running
     statistics are those of the global batch on both ranks."""
     B = 8
@@ -91,7 +91,7 @@ def test_rccl_allreduce_inside_the_captured_step_child_process():
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_PORT=str(29600 + os.getpid() % 200))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--no-cpu-baseline", "--no-roofline", "--steps", "3", "--warmup", "2"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--no-probe", "--no-cpu-baseline", "--no-roofline", "--steps", "3", "--warmup", "2"],
                        capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert r.returncode == 0, (r.returncode, r.stderr[-2000:])
     line = json.loads(r.stdout.strip().splitlines()[-1])
