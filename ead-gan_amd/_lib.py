@@ -20,6 +20,8 @@ ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = range(5)
 OUT_NHWC, OUT_NCHW_F32 = 0, 1
 # eg_epilogue.nt_variant (include/eadgan_hip.h: EG_NT_*)
 NT_AUTO, NT_REG, NT_BUF128, NT_PERS, NT_S8, NT_S8P = range(6)
+# eg_epilogue.stat_mode (EG_STAT_*): column statistics of the stored tile, fused into the convolution's epilogue
+STAT_NONE, STAT_MOMENTS, STAT_BN_BWD, STAT_SN_BIAS = range(4)
 
 
 class EgConv(ctypes.Structure):
@@ -31,7 +33,10 @@ class EgEpilogue(ctypes.Structure):
                 ("act", ctypes.c_int), ("slope", ctypes.c_float), ("mask", ctypes.c_void_p),
                 ("mask_act", ctypes.c_int), ("mask_slope", ctypes.c_float), ("out_mode", ctypes.c_int), ("sigma_rows", ctypes.c_int),
                 ("splitk_ws", ctypes.c_void_p), ("splitk_ws_bytes", ctypes.c_size_t),
-                ("nt_variant", ctypes.c_int), ("nt_splitk", ctypes.c_int)]
+                ("nt_variant", ctypes.c_int), ("nt_splitk", ctypes.c_int),
+                ("stat_mode", ctypes.c_int), ("stat_out", ctypes.c_void_p), ("stat_aux", ctypes.c_void_p),
+                ("stat_p0", ctypes.c_void_p), ("stat_p1", ctypes.c_void_p), ("stat_p2", ctypes.c_void_p), ("stat_p3", ctypes.c_void_p),
+                ("stat_act", ctypes.c_int), ("stat_slope", ctypes.c_float)]
 
 
 class EgSnLayer(ctypes.Structure):

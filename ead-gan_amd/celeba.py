@@ -29,6 +29,10 @@ opt = argparse.Namespace(n_epochs=50, batch_size=16, lr=0.0002, b1=0.5, b2=0.999
 # image-side transposed convolutions (128 -> C) as one GEMM + col2im gather (1) or as the 4-phase implicit GEMM (0)
 IMG_GEMM = os.environ.get("EG_IMG_GEMM", "1") == "1"
 
+# column statistics (BatchNorm batch statistics / backward sums, bias gradient + spectral-norm coefficient) taken from the epilogue of the
+# convolution that produces the tensor (eg_epilogue.stat_mode) instead of by kernels that re-read it; 0: the stand-alone kernels (A/B runs)
+FUSE_STATS = os.environ.get("EG_FUSE_STATS", "1") != "0"
+
 G_WIDTHS = (1024, 512, 256, 128)
 D_WIDTHS = (128, 256, 512, 1024)
 LRELU_SLOPE = 0.1
@@ -96,10 +100,19 @@ class _GenEngine:
             ws.need_small(ops.bn_ws_floats(self.z[i].numel() // W[i + 1], W[i + 1]))
         ws.need_small(ops.bias_grad_ws_floats(B * 16, W[0]))
         ws.need_sums(2 * max(W))
+        self._stat = {}                                                # (kind, layer) -> (row blocks, buffer) of the fused column statistics
         self.repack()
 
     def _p(self, idx, kind):
         return getattr(self.gen.conv_blocks[idx], kind)
+
+    def _stat_buf(self, key, c, bwd, ep, C):
+        """(nrb, buffer) if the launch described by (c, bwd, ep) can take its column statistics in the epilogue, else (0, None).  Asked
+        once per layer with the very epilogue the launch uses (same hints, same split-K scratch)."""
+        if key not in self._stat:
+            nrb = ops.conv_stat_blocks(c, self.dtype, bwd, ep) if FUSE_STATS else 0
+            self._stat[key] = (nrb, torch.empty(2 * C * nrb, device=self.inp.device, dtype=torch.float32) if nrb else None)
+        return self._stat[key]
 
     # gradient buckets in the order the backward pass completes them: (tag of the lane chain that writes it last, parameter names)
     BUCKETS = (("G4", ("conv_blocks.10.weight", "conv_blocks.10.bias")),
@@ -136,9 +149,17 @@ class _GenEngine:
         x = self.h0
         for i, idx in enumerate((1, 4, 7)):
             r = self.mid[i]
-            ops.conv_bwd_data(r.c, dt, x, r.wp_bwd, self.z[i], ops.epilogue(bias=self._p(idx, "bias")))
             bn = self.gen.conv_blocks[idx + 1]
             M = self.z[i].numel() // W[i + 1]
+            nrb, stat = self._stat_buf(("fwd", i), r.c, True, ops.epilogue(bias=self._p(idx, "bias")), W[i + 1]) if (training and sync is None) else (0, None)
+            if nrb:
+                # BatchNorm batch statistics from the transposed convolution's epilogue: z is read once (apply) instead of twice
+                ops.conv_bwd_data(r.c, dt, x, r.wp_bwd, self.z[i], ops.epilogue(bias=self._p(idx, "bias"), stat_mode=ops.STAT_MOMENTS, stat_out=stat))
+                ops.bn_fwd_train_fused(dt, self.z[i], self.a[i], M, W[i + 1], stat, nrb, 256, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean,
+                                       bn.running_var, bn.num_batches_tracked, self.mean[i], self.invstd[i], self.ws.small, ACT_RELU)
+                x = self.a[i]
+                continue
+            ops.conv_bwd_data(r.c, dt, x, r.wp_bwd, self.z[i], ops.epilogue(bias=self._p(idx, "bias")))
             if training and sync is not None:
                 ops.bn_stats_local(dt, self.z[i], M, W[i + 1], self.ws.small, self.bn_stats[i])
                 allst = sync.gather_stats(self.bn_stats[i])
@@ -184,11 +205,15 @@ class _GenEngine:
         ops.conv_fwd(self.l4p.c, dt, self.patches, self.l4p.wp_fwd, self.da[2], None)
         flush()
         # L3..L1
+        fused = (0, None)                               # (row blocks, sums) if da[i] came with its BatchNorm backward sums (then it holds dy)
         for i, idx in ((2, 7), (1, 4), (0, 1)):
             r = self.mid[i]
             bn = gen.conv_blocks[idx + 1]
             M = self.z[i].numel() // W[i + 1]
-            if sync is not None:
+            if fused[0]:
+                ops.bn_bwd_fused(dt, self.z[i], self.da[i], self.dz[i], M, W[i + 1], fused[1], fused[0], bn.weight, bn.bias, self.mean[i], self.invstd[i],
+                                 gof(f"conv_blocks.{idx + 1}.weight"), gof(f"conv_blocks.{idx + 1}.bias"), ws.sums, ws.small)
+            elif sync is not None:
                 ops.bn_bwd_sums_local(dt, self.z[i], self.da[i], M, W[i + 1], bn.weight, bn.bias, self.mean[i], self.invstd[i], ACT_RELU, 0.0,
                                       gof(f"conv_blocks.{idx + 1}.weight"), gof(f"conv_blocks.{idx + 1}.bias"), self.bn_sums[i], ws.small)
                 sync.reduce_sums(self.bn_sums[i])
@@ -204,7 +229,17 @@ class _GenEngine:
                 ops.wgrad_reduce(wsw.slab, ns, r.Cout, r.Cout, r.Cin, 16, gof(f"conv_blocks.{idx}.weight"))
                 ops.bias_grad(dt, self.dz[i], M, W[i + 1], wsw.small, gof(f"conv_blocks.{idx}.bias"))
             wgrad_side(mid_wgrad, i + 1, f"G{i + 1}")
-            ops.conv_fwd(r.c, dt, self.dz[i], r.wp_fwd, self.da[i - 1] if i > 0 else self.dh0, None)
+            fused = (0, None)
+            if i > 0 and sync is None:
+                # the launch that produces d(a[i-1]) also forms dy = da * relu'(bn(z)) and the two sums of that layer's BatchNorm backward
+                fused = self._stat_buf(("bwd", i - 1), r.c, False, ops.epilogue(), W[i])
+            if fused[0]:
+                bnl = gen.conv_blocks[(1, 4, 7)[i - 1] + 1]
+                ops.conv_fwd(r.c, dt, self.dz[i], r.wp_fwd, self.da[i - 1],
+                             ops.epilogue(stat_mode=ops.STAT_BN_BWD, stat_out=fused[1], stat_aux=self.z[i - 1],
+                                          stat_p=(self.mean[i - 1], self.invstd[i - 1], bnl.weight, bnl.bias), stat_act=ACT_RELU))
+            else:
+                ops.conv_fwd(r.c, dt, self.dz[i], r.wp_fwd, self.da[i - 1] if i > 0 else self.dh0, None)
             flush()
 
         # L0
@@ -377,6 +412,7 @@ class _DiscEngine:
         self.v = [torch.zeros(NT, kd[i], device=dev, dtype=torch.float32) for i in range(4)]
         self.coef = [torch.zeros(4, device=dev, dtype=torch.float32) for _ in range(4)]
         self.imgs = [None] * NT
+        self._stat = {}                                 # (layer, T) -> (row blocks, buffer) of the fused bias-gradient / coefficient sums
         self._sn_arrays = None
         self._sn(0)
         self.repack()
@@ -416,6 +452,17 @@ class _DiscEngine:
     def rows(self, i):
         """lattice rows of one tape at the output of layer i"""
         return self.B * self.hw[i] ** 2
+
+    def _stat_buf(self, i, T, c, ep):
+        """fused sums of layer i's bias gradient / spectral-norm coefficient in the backward-data launch that produces dzs_i (T tapes):
+        (row blocks, buffer), (0, None) where that launch cannot take them (see _GenEngine._stat_buf)"""
+        key = (i, T)
+        if key not in self._stat:
+            ok = FUSE_STATS and self.rows(i + 1) % 256 == 0
+            nrb = ops.conv_stat_blocks(c, self.dtype, True, ep) if ok else 0
+            N = D_WIDTHS[i]
+            self._stat[key] = (nrb, torch.empty(N * nrb + nrb * (N // 128), device=self.out.device, dtype=torch.float32) if nrb else None)
+        return self._stat[key]
 
     def _sn_tape(self, t, training=True):
         ops.sn_power_iter_multi(self._sn(t), self.sn_scratch, training, SN_EPS)
@@ -489,14 +536,19 @@ class _DiscEngine:
         ops.dense_small_bwd(dt, dout, self.head.wp_fwd, sl(self.a[3]), sl(self.dz[3]), T * B, K, self.head.Kpad_fwd, self.nout, ACT_LRELU, LRELU_SLOPE,
                             self.sigma[3][t0:], B)
         flush()
+        fused = (0, None)                               # (row blocks, sums) if dzs_i came with its column sums
         for i in (3, 2, 1, 0):
             m = self._m(i)
             geo = g["mid"][i - 1] if i > 0 else g["l1p"]
             x_in = sl(self.a[i - 1]) if i > 0 else sl(self.patches)
             if need_wgrad:
-                def layer_wgrad(wsw, i=i, m=m, geo=geo, x_in=x_in):
-                    ops.bias_grad_sn(dt, sl(self.dz[i]), sl(self.a[i]), m.bias, T * self.rows(i), W[i], self.rows(i), self.sigma[i][t0:], LRELU_SLOPE,
-                                     wsw.small, gof(f"main.{2 * i}.bias"), self.coef[i])
+                def layer_wgrad(wsw, i=i, m=m, geo=geo, x_in=x_in, fused=fused):
+                    if fused[0]:
+                        ops.bias_grad_sn_fused(fused[1], fused[0], W[i], T * self.rows(i + 1) // 256, self.rows(i + 1) // 256, T, self.sigma[i][t0:],
+                                               gof(f"main.{2 * i}.bias"), self.coef[i])
+                    else:
+                        ops.bias_grad_sn(dt, sl(self.dz[i]), sl(self.a[i]), m.bias, T * self.rows(i), W[i], self.rows(i), self.sigma[i][t0:], LRELU_SLOPE,
+                                         wsw.small, gof(f"main.{2 * i}.bias"), self.coef[i])
                     ns = ops.conv_wgrad(geo, dt, x_in, sl(self.dz[i]), wsw.slab, wsw.wgs_target)
                     taps = 16 if i > 0 else 1
                     ops.wgrad_reduce_rank1(wsw.slab, ns, W[i], W[i], self.cin[i], taps, gof(f"main.{2 * i}.weight_orig"), T, self.coef[i],
@@ -504,9 +556,12 @@ class _DiscEngine:
                 wgrad_side(layer_wgrad, i + 1, f"D{i}")
             if i > 0:
                 # dzs_{i-1} = conv^T(dzs_i, W_i) * lrelu'(a_{i-1}) / sigma_{i-1}[tape]
-                ops.conv_bwd_data(geo, dt, sl(self.dz[i]), self.mid[i - 1].wp_bwd, sl(self.dz[i - 1]),
-                                  ops.epilogue(sigma=self.sigma[i - 1][t0:], sigma_rows=self.rows(i), mask=sl(self.a[i - 1]), mask_act=ACT_LRELU,
-                                               mask_slope=LRELU_SLOPE))
+                kw = dict(sigma=self.sigma[i - 1][t0:], sigma_rows=self.rows(i), mask=sl(self.a[i - 1]), mask_act=ACT_LRELU, mask_slope=LRELU_SLOPE)
+                # ... and, from the same tile, layer i-1's bias-gradient column sums and spectral-norm coefficient
+                fused = self._stat_buf(i - 1, T, geo, ops.epilogue(**kw)) if need_wgrad else (0, None)
+                if fused[0]:
+                    kw.update(stat_mode=ops.STAT_SN_BIAS, stat_out=fused[1], stat_p=(self._m(i - 1).bias,), stat_slope=LRELU_SLOPE)
+                ops.conv_bwd_data(geo, dt, sl(self.dz[i]), self.mid[i - 1].wp_bwd, sl(self.dz[i - 1]), ops.epilogue(**kw))
                 flush()
         if need_dimg:
             if IMG_GEMM:

@@ -842,20 +842,26 @@ static void launch_splitk_epilogue(const NtParams& q, int nphase, int Mpad, hipS
     hipLaunchKernelGGL((nt_splitk_epilogue_kernel<T>), dim3(blocks, nphase), dim3(256), 0, st, q, nphase, Mpad, lvpr);
 }
 
+static bool nt_split_inkernel();
+static int nt_stat_blocks(const NtParams& p, int nphase, const NtPlan& plan, bool half);
+
 template <typename T>
 static int launch_nt(const NtParams& p, int nphase, int variant, int splitk, hipStream_t st) {
     // the tail of the scratch is kept for igemm_nt8s's arrival counters: no variant's partial tiles may reach it
     const NtPlan plan = nt_plan(p, nphase, Elt<T>::VEC, sizeof(T), (p.part && p.part_bytes > EG_SPLIT_CNT_BYTES) ? p.part_bytes - EG_SPLIT_CNT_BYTES : 0, variant, splitk);
     EG_REQUIRE(plan.kind > 0, "eg_epilogue.nt_variant %d cannot run this problem (M=%d N=%d C=%d)", variant, p.M, p.N, p.C);
+    const int stat_nrb = nt_stat_blocks(p, nphase, plan, sizeof(T) == 2);
+    EG_REQUIRE(p.stat_mode == EG_STAT_NONE || stat_nrb > 0, "eg_epilogue.stat_mode is set but this launch cannot fuse column statistics (eg_conv_stat_blocks() == 0: M=%d N=%d C=%d)", p.M, p.N, p.C);
     static const int xcd = [] { const char* e = getenv("EG_XCD_REMAP"); return e ? atoi(e) : 1; }();   // default on (7: + diagnostic piece skipping in PROF builds)
     if (plan.kind == EG_NT_S8 || plan.kind == EG_NT_S8P) {
         NtParams q = p;
         q.nsplit = plan.ns;
         q.xcd_remap = xcd;
+        q.stat_nrb = stat_nrb;
         Nt8pGeom g;
         memset(&g, 0, sizeof(g));
         if (plan.kind == EG_NT_S8P) EG_REQUIRE(eg_nt8p_geometry(p, nphase, g), "patch geometry");
-        static const bool inkernel = [] { const char* e = getenv("EG_NT_SPLIT_INKERNEL"); return !(e && atoi(e) == 0); }();
+        const bool inkernel = nt_split_inkernel();
         q.split_cnt = (plan.ns > 1 && inkernel) ? reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.part) + p.part_bytes - EG_SPLIT_CNT_BYTES) : nullptr;
         eg_launch_nt8s<T>(q, g, plan.kind == EG_NT_S8P, nphase, plan.ns, st);      // K splits are reduced inside the launch (last-arriving workgroup)
         if (plan.ns > 1 && !inkernel) launch_splitk_epilogue<T>(q, nphase, cdiv(p.M, 256) * 256, st);
@@ -965,6 +971,34 @@ static void fill_epilogue(NtParams& p, const eg_epilogue* ep) {
     p.sigma_rows = ep ? ep->sigma_rows : 0;
     p.part = ep ? reinterpret_cast<float*>(ep->splitk_ws) : nullptr;
     p.part_bytes = ep ? ep->splitk_ws_bytes : 0;
+    p.stat_mode = ep ? ep->stat_mode : EG_STAT_NONE;
+    p.stat_out = ep ? ep->stat_out : nullptr;
+    p.stat_aux = ep ? ep->stat_aux : nullptr;
+    p.stat_p[0] = ep ? ep->stat_p0 : nullptr; p.stat_p[1] = ep ? ep->stat_p1 : nullptr;
+    p.stat_p[2] = ep ? ep->stat_p2 : nullptr; p.stat_p[3] = ep ? ep->stat_p3 : nullptr;
+    p.stat_act = ep ? ep->stat_act : EG_ACT_NONE;
+    p.stat_slope = ep ? ep->stat_slope : 0.f;
+}
+
+// row blocks of the fused column statistics if this plan can produce them (the 8-wave kernel on whole 256-row tiles, K splits reduced
+// inside the launch), else 0
+static bool nt_split_inkernel() {
+    static const bool inkernel = [] { const char* e = getenv("EG_NT_SPLIT_INKERNEL"); return !(e && atoi(e) == 0); }();
+    return inkernel;
+}
+static int nt_stat_blocks(const NtParams& p, int nphase, const NtPlan& plan, bool half) {
+    if (plan.kind != EG_NT_S8 || !half || (p.M % 256) != 0 || p.out_mode != EG_OUT_NHWC) return 0;
+    if (plan.ns > 1 && !nt_split_inkernel()) return 0;
+    return nphase * (p.M / 256);
+}
+static int check_stat(const NtParams& p) {
+    if (p.stat_mode == EG_STAT_NONE) return 0;
+    EG_REQUIRE(p.stat_mode >= EG_STAT_MOMENTS && p.stat_mode <= EG_STAT_SN_BIAS && p.stat_out, "eg_epilogue.stat_mode %d: bad mode or no stat_out", p.stat_mode);
+    if (p.stat_mode == EG_STAT_BN_BWD)
+        EG_REQUIRE(p.stat_aux && p.stat_p[0] && p.stat_p[1] && p.stat_p[2] && p.stat_p[3] && !p.mask, "EG_STAT_BN_BWD needs stat_aux (z), stat_p0..p3 (mean, invstd, gamma, beta) and no mask");
+    if (p.stat_mode == EG_STAT_SN_BIAS)
+        EG_REQUIRE(p.mask && p.mask_act == EG_ACT_LRELU && p.mask_slope > 0.f && p.stat_p[0] && p.stat_slope == p.mask_slope, "EG_STAT_SN_BIAS needs the LeakyReLU mask, stat_p0 (bias) and stat_slope == mask_slope");
+    return 0;
 }
 
 extern "C" int eg_conv_fwd(const eg_conv* c, int dtype, const void* X, const void* wp_fwd, void* Y,
@@ -976,6 +1010,7 @@ extern "C" int eg_conv_fwd(const eg_conv* c, int dtype, const void* X, const voi
     geom_fwd(c, dtype, p);
     p.src = X; p.wp = wp_fwd; p.dst = Y;
     fill_epilogue(p, ep);
+    if (int e = check_stat(p)) return e;
     const int variant = ep ? ep->nt_variant : EG_NT_AUTO, splitk = ep ? ep->nt_splitk : 0;
     int rc;
     if (dtype == EG_F32) rc = launch_nt<float>(p, 1, variant, splitk, (hipStream_t)s);
@@ -996,6 +1031,7 @@ extern "C" int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, con
     if (int e = geom_bwd(c, dtype, p, &nphase)) return e;
     p.src = dY; p.wp = wp_bwd; p.dst = dX;
     fill_epilogue(p, ep);
+    if (int e = check_stat(p)) return e;
     const int variant = ep ? ep->nt_variant : EG_NT_AUTO, splitk = ep ? ep->nt_splitk : 0;
     int rc;
     if (dtype == EG_F32) rc = launch_nt<float>(p, nphase, variant, splitk, (hipStream_t)s);
@@ -1004,6 +1040,21 @@ extern "C" int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, con
     if (rc) return rc;
     EG_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int eg_conv_stat_blocks(const eg_conv* c, int dtype, int bwd, const eg_epilogue* ep) {
+    if (!c || check_conv(c, dtype, bwd ? NEED_COUT : NEED_CIN)) return 0;
+    NtParams p;
+    memset(&p, 0, sizeof(p));
+    int nphase = 1;
+    if (bwd) { if (geom_bwd(c, dtype, p, &nphase)) return 0; }
+    else geom_fwd(c, dtype, p);
+    fill_epilogue(p, ep);
+    // the planner exactly as launch_nt runs it for this call: same hints, same scratch
+    const size_t ws = (p.part && p.part_bytes > EG_SPLIT_CNT_BYTES) ? p.part_bytes - EG_SPLIT_CNT_BYTES : 0;
+    const NtPlan plan = nt_plan(p, nphase, vec_of(dtype), dtype == EG_F32 ? 4 : 2, ws, ep ? ep->nt_variant : EG_NT_AUTO, ep ? ep->nt_splitk : 0);
+    if (plan.kind < 0) return 0;
+    return nt_stat_blocks(p, nphase, plan, dtype != EG_F32);
 }
 
 extern "C" size_t eg_conv_splitk_ws_bytes(const eg_conv* c, int dtype, int bwd) {
@@ -1908,6 +1959,41 @@ extern "C" int eg_bias_grad_sn(int dtype, const void* dzs, const void* a, const 
     else if (dtype == EG_F16) hipLaunchKernelGGL(colsum_sn_partial_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)s, (const f16_t*)dzs, (const f16_t*)a, bias, N, rows_per_tape, bpt, rpb, 1.f / slope, partials, dots);
     else hipLaunchKernelGGL(colsum_sn_partial_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, (const bf16_t*)dzs, (const bf16_t*)a, bias, N, rows_per_tape, bpt, rpb, 1.f / slope, partials, dots);
     hipLaunchKernelGGL(colsum_sn_final_kernel, dim3(cdiv(N + ntapes, 4)), dim3(256), 0, (hipStream_t)s, partials, dots, nrb, N, bpt, gx, ntapes, sigma, gb, coef);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- the same sums from the epilogue of the convolution that produced dzs (eg_epilogue.stat_mode = EG_STAT_SN_BIAS) -----------------
+// stat: [N][nrb] column sums, then [nrb][tiles_n] tile dots.  gb[n] += sum_rb sigma[tape(rb)] * stat[n][rb] (one wave per n, contiguous
+// reads); coef[t] = sum of the dots of tape t's row blocks (waves N .. N + ntapes - 1).  tape(rb) = (rb % tiles_m) / tiles_per_tape.
+__global__ void colsum_sn_final_t_kernel(const float* __restrict__ stat, int nrb, int N, int tiles_m, int tiles_per_tape, int tiles_n, int ntapes,
+                                         const float* __restrict__ sigma, float* __restrict__ gb, float* __restrict__ coef) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (j < N) {
+        const float* __restrict__ a = stat + (size_t)j * nrb;
+        float acc = 0.f;
+        for (int r = lane; r < nrb; r += 64) acc += a[r] * sigma[(r % tiles_m) / tiles_per_tape];
+        acc = wave_sum(acc);
+        if (lane == 0) gb[j] += acc;
+    } else if (j < N + ntapes) {
+        const int t = j - N;
+        const float* __restrict__ dots = stat + (size_t)N * nrb;
+        float acc = 0.f;
+        for (int r = lane; r < nrb; r += 64)
+            if ((r % tiles_m) / tiles_per_tape == t)
+                for (int q = 0; q < tiles_n; ++q) acc += dots[(size_t)r * tiles_n + q];
+        acc = wave_sum(acc);
+        if (lane == 0) coef[t] = acc;
+    }
+}
+
+extern "C" int eg_bias_grad_sn_fused(const float* stat, int nrb, int N, int tiles_m, int tiles_per_tape, int ntapes, const float* sigma, float* gb,
+                                     float* coef, eg_stream_t s) {
+    EG_REQUIRE(stat && sigma && gb && coef && nrb > 0 && N > 0 && (N % 128) == 0 && tiles_m > 0 && (nrb % tiles_m) == 0 && tiles_per_tape > 0 &&
+               ntapes > 0 && ntapes <= 4 && tiles_per_tape * ntapes == tiles_m, "eg_bias_grad_sn_fused: bad argument");
+    hipLaunchKernelGGL(colsum_sn_final_t_kernel, dim3(cdiv(N + ntapes, 4)), dim3(256), 0, (hipStream_t)s, stat, nrb, N, tiles_m, tiles_per_tape, N / 128, ntapes,
+                       sigma, gb, coef);
     EG_LAUNCH_CHECK();
     return 0;
 }

@@ -41,6 +41,13 @@ struct NtParams {
     size_t part_bytes;
     int nsplit;
     unsigned* split_cnt;   // igemm_nt8s with K splits: arrival counters, one per output tile (tail of the caller's split-K scratch; zero between launches)
+    // column statistics of the stored tile (eg_epilogue.stat_*; igemm_nt8s only)
+    int stat_mode, stat_nrb;
+    float* stat_out;
+    const void* stat_aux;
+    const float* stat_p[4];
+    int stat_act;
+    float stat_slope;
     NtPhase ph[4];
 };
 // the last EG_SPLIT_CNT_BYTES of the caller-lent split-K scratch hold the arrival counters of igemm_nt8s's in-kernel reduction (at most 224
@@ -194,7 +201,7 @@ template <typename T, int TM, int TN, int PF>
 struct NtEpiPre {
     float inv_sigma[TM];
     float bias[TN][4];
-    uint4 mask[PF];
+    uint4 mask[PF > 0 ? PF : 1];
 };
 
 template <typename T, int BM, int BNW, int TM, int TN, int NT, int PF>
@@ -232,6 +239,36 @@ __device__ __forceinline__ void nt_epi_prefetch(NtEpiPre<T, TM, TN, PF>& e, cons
 }
 
 // nt_epilogue_lds with the operands of NtEpiPre (same arithmetic, same results)
+// first half of nt_epilogue_lds_pre: the accumulators with 1/sigma, bias and activation applied go to the fp32 tile in LDS
+template <typename T, int BNW, int TM, int TN, int PF>
+__device__ __forceinline__ void nt_epilogue_stage_pre(const NtEpiPre<T, TM, TN, PF>& e, const NtParams& p, f32x4 (&acc)[TM][TN], char* smem, int nw0,
+                                                      int row0, int col0, int frow, int fq) {
+    constexpr int SW = BNW / 4 < 32 ? BNW / 4 - 1 : 31;     // 16-byte fp32 chunks per tile row - 1
+    float* ct = reinterpret_cast<float*>(smem);
+    const EgActFast af = eg_act_fast(p.act, p.slope);
+    eg_if_fast(af.special, [&](auto fast) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = row0 + i * 16 + frow;
+            const float inv_sigma = p.sigma ? 1.f / e.inv_sigma[i] : 1.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nl = col0 + j * 16 + fq * 4;
+                float4 v;
+                float* ve = reinterpret_cast<float*>(&v);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float x = __fmul_rn(acc[i][j][r], inv_sigma);
+                    if (p.bias && nw0 + nl + r < p.N) x = __fadd_rn(x, e.bias[j][r]);
+                    if constexpr (decltype(fast)::value) ve[r] = eg_act_apply(x, af);
+                    else ve[r] = eg_act(x, p.act, p.slope);
+                }
+                *reinterpret_cast<float4*>(ct + row * BNW + (((nl >> 2) ^ (row & SW)) << 2)) = v;
+            }
+        }
+    });
+}
+
 template <typename T, int BM, int BNW, int TM, int TN, int NT, int PF>
 __device__ __forceinline__ void nt_epilogue_lds_pre(const NtEpiPre<T, TM, TN, PF>& e, const NtParams& p, const NtPhase& ph, f32x4 (&acc)[TM][TN],
                                                     char* smem, int m0, int nw0, int row0, int col0, int tid, int frow, int fq) {
@@ -303,6 +340,148 @@ __device__ __forceinline__ void nt_epilogue_lds_pre(const NtEpiPre<T, TM, TN, PF
             for (int q = 0; q < VEC; ++q) Elt<T>::st(oe + q, f[q]);
             *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.dst) + o) = ov;
         }
+    }
+}
+
+// nt_epilogue_lds_pre + column statistics of the stored tile (NtParams.stat_*, eg_epilogue.stat_mode in the ABI header): the same staging,
+// the same stored values (EG_STAT_BN_BWD stores dy = da * act'(bn(z)) instead of da), plus two sums per column over the tile's BM rows,
+// taken from the values as they are stored (rounded to T).  Order of the sums: a thread adds its NIT rows top down, then the RPP row
+// lanes of a column are added in lane order -> deterministic.  Whole tiles only (the planner guarantees m0 + BM <= M); 16-bit types.
+// rb = phase * tiles_m + m_tile: row block of the tile in stat_out; n_tile / tiles_n: for the per-tile dot of EG_STAT_SN_BIAS.
+template <typename T, int BM, int BNW, int TM, int TN, int NT, int PF>
+__device__ __forceinline__ void nt_epilogue_lds_stat(const NtEpiPre<T, TM, TN, PF>& e, const NtParams& p, const NtPhase& ph, f32x4 (&acc)[TM][TN],
+                                                     char* smem, int m0, int nw0, int row0, int col0, int tid, int frow, int fq, int rb, int n_tile,
+                                                     int tiles_n) {
+    constexpr int VEC = Elt<T>::VEC;
+    static_assert(VEC == 8, "16-bit element types");
+    const int OWm = (1 << p.lOW) - 1, OHm = (1 << p.lOH) - 1;
+    constexpr int SW = BNW / 4 < 32 ? BNW / 4 - 1 : 31;
+    float* ct = reinterpret_cast<float*>(smem);
+    const EgGradFast gf = eg_grad_fast(p.mask_act, p.mask_slope);
+    nt_epilogue_stage_pre<T, BNW, TM, TN, PF>(e, p, acc, smem, nw0, row0, col0, frow, fq);
+    __syncthreads();
+    constexpr int VPR = BNW / VEC, RPP = NT / VPR, NIT = BM / RPP;
+    const int vc = tid % VPR, vr = tid / VPR;
+    const T* __restrict__ mask = reinterpret_cast<const T*>(p.mask);
+    const T* __restrict__ aux = reinterpret_cast<const T*>(p.stat_aux);
+    const int n = nw0 + vc * VEC;
+    const int mode = p.stat_mode;
+    auto round_t = [](float v) { T t; Elt<T>::st(&t, v); return Elt<T>::ld(&t); };
+    float s1[VEC], s2[VEC], k0[VEC], k1[VEC], k2[VEC], k3[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) { s1[q] = 0.f; s2[q] = 0.f; k0[q] = 0.f; k1[q] = 0.f; k2[q] = 0.f; k3[q] = 0.f; }
+    if (mode == EG_STAT_MOMENTS) {
+        // pivot = the column's value in the tile's first row (any pivot is exact; this one keeps the sums small)
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) k0[q] = round_t(ct[vc * VEC + q]);
+    } else if (mode == EG_STAT_BN_BWD) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            const float mu = p.stat_p[0][n + q], is = p.stat_p[1][n + q], g = p.stat_p[2][n + q], b = p.stat_p[3][n + q];
+            k0[q] = mu; k1[q] = is; k2[q] = __fmul_rn(g, is); k3[q] = __fsub_rn(b, __fmul_rn(mu, k2[q]));
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) k0[q] = p.stat_p[0][n + q];
+    }
+    const EgGradFast sgf = eg_grad_fast(p.stat_act, p.stat_slope);
+    const float inv_slope = p.stat_slope != 0.f ? 1.f / p.stat_slope : 1.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int row = vr + it * RPP;
+        const int m = m0 + row;
+        const int b = m >> (p.lOW + p.lOH);
+        const int y = ((m >> p.lOW) & OHm) * p.osy + ph.ooy;
+        const int x = (m & OWm) * p.osx + ph.oox;
+        const size_t o = (((size_t)b * p.DH + y) * p.DW + x) * p.N + n;
+        float f[VEC];
+#pragma unroll
+        for (int q = 0; q < VEC / 4; ++q) {
+            const int chunk = (vc * (VEC / 4) + q) ^ (row & SW);
+            const float4 v = *reinterpret_cast<const float4*>(ct + row * BNW + (chunk << 2));
+            f[q * 4 + 0] = v.x; f[q * 4 + 1] = v.y; f[q * 4 + 2] = v.z; f[q * 4 + 3] = v.w;
+        }
+        uint4 mv = make_uint4(0, 0, 0, 0);
+        if (mask) {
+            mv = it < PF ? e.mask[it < PF ? it : 0] : *reinterpret_cast<const uint4*>(mask + o);
+            const T* me = reinterpret_cast<const T*>(&mv);
+            if (!gf.special) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) f[q] *= eg_grad_apply(Elt<T>::ld(me + q), gf);
+            } else {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) f[q] *= eg_act_grad_from_out(Elt<T>::ld(me + q), p.mask_act, p.mask_slope);
+            }
+        }
+        uint4 ov;
+        T* oe = reinterpret_cast<T*>(&ov);
+        if (mode == EG_STAT_MOMENTS) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                Elt<T>::st(oe + q, f[q]);
+                const float d = Elt<T>::ld(oe + q) - k0[q];
+                s1[q] += d;
+                s2[q] = fmaf(d, d, s2[q]);
+            }
+        } else if (mode == EG_STAT_BN_BWD) {
+            const uint4 zv = *reinterpret_cast<const uint4*>(aux + o);
+            const T* ze = reinterpret_cast<const T*>(&zv);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const float z = Elt<T>::ld(ze + q);
+                const float xh = (z - k0[q]) * k1[q];
+                const float dy = round_t(f[q]) * eg_grad_apply(fmaf(z, k2[q], k3[q]), sgf);      // the forward's activation input: z * (g * is) + (b - mu * g * is)
+                Elt<T>::st(oe + q, dy);
+                s1[q] += dy;
+                s2[q] = fmaf(dy, xh, s2[q]);
+            }
+        } else {
+            const T* me = reinterpret_cast<const T*>(&mv);
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                Elt<T>::st(oe + q, f[q]);
+                const float g = Elt<T>::ld(oe + q);
+                float a = Elt<T>::ld(me + q);
+                a = a > 0.f ? a : a * inv_slope;
+                s1[q] += g;
+                s2[q] = fmaf(g, a - k0[q], s2[q]);
+            }
+        }
+        *reinterpret_cast<uint4*>(reinterpret_cast<T*>(p.dst) + o) = ov;
+    }
+    __syncthreads();                                   // every row of the tile has been read: rows 1.. become the reduction scratch
+    float* red = ct + BNW;                             // [2][RPP][BNW]; row 0 of the tile (the pivots) stays
+#pragma unroll
+    for (int q = 0; q < VEC / 4; ++q) {
+        *reinterpret_cast<float4*>(red + (size_t)vr * BNW + vc * VEC + q * 4) = make_float4(s1[q * 4], s1[q * 4 + 1], s1[q * 4 + 2], s1[q * 4 + 3]);
+        *reinterpret_cast<float4*>(red + (size_t)(RPP + vr) * BNW + vc * VEC + q * 4) = make_float4(s2[q * 4], s2[q * 4 + 1], s2[q * 4 + 2], s2[q * 4 + 3]);
+    }
+    __syncthreads();
+    float t2 = 0.f;
+    if (tid < BNW) {
+        float t1 = 0.f;
+#pragma unroll 8
+        for (int l = 0; l < RPP; ++l) { t1 += red[l * BNW + tid]; t2 += red[(RPP + l) * BNW + tid]; }
+        const size_t nrb = (size_t)p.stat_nrb;
+        float* o1 = p.stat_out + (size_t)(nw0 + tid) * nrb + rb;
+        if (mode == EG_STAT_MOMENTS) {
+            const float pv = round_t(ct[tid]), cnt = (float)BM;
+            o1[0] = pv + t1 / cnt;
+            o1[(size_t)p.N * nrb] = fmaxf(t2 - t1 * t1 / cnt, 0.f);
+        } else if (mode == EG_STAT_BN_BWD) {
+            o1[0] = t1;
+            o1[(size_t)p.N * nrb] = t2;
+        } else {
+            o1[0] = t1;
+        }
+    }
+    if (mode == EG_STAT_SN_BIAS && tid < BNW) {        // waves 0 and 1 (BNW = 128): the tile's dot, added in wave order
+        const float w = wave_sum(t2);
+        if ((tid & 63) == 0) red[2 * RPP * BNW + (tid >> 6)] = w;
+    }
+    if (mode == EG_STAT_SN_BIAS) {
+        __syncthreads();
+        if (tid == 0) p.stat_out[(size_t)p.N * p.stat_nrb + (size_t)rb * tiles_n + n_tile] = red[2 * RPP * BNW] + red[2 * RPP * BNW + 1];
     }
 }
 

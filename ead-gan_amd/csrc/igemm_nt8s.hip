@@ -54,7 +54,9 @@ __device__ __forceinline__ void eg_wait_vm_dyn_lgkm0(int n) {      // wave-unifo
 
 // PROF (diagnostic instantiation, EG_NT8_PROF=1): wave 0 of every workgroup stamps s_memtime (shader clock) and s_memrealtime (100 MHz)
 // at kernel entry, after the prologue, after the K loop and at the end: where a workgroup's time goes and at which clock it ran.
-template <typename T, bool PATCH, bool SPLITK, bool PROF = false>
+// STAT: its own instantiation for launches with eg_epilogue.stat_mode set (column statistics of the stored tile in the epilogue): the
+// plain kernels keep their register allocation (230 VGPRs, no scratch; with the statistics epilogue inlined behind a branch they spilled)
+template <typename T, bool PATCH, bool SPLITK, bool PROF = false, bool STAT = false>
 __global__ __launch_bounds__(512) void igemm_nt8s_kernel(const NtParams p, const Nt8pGeom g, int tiles_m, int tiles_n, unsigned long long* prof = nullptr) {
     unsigned long long pt[4] = {0, 0, 0, 0}, pr[4] = {0, 0, 0, 0}, pe[2] = {0, 0};
     unsigned long long lp[3] = {0, 0, 0};              // PROF: K loop split into groups (reads + DMA issue + MFMA) | counted wait | barrier
@@ -500,6 +502,14 @@ __global__ __launch_bounds__(512) void igemm_nt8s_kernel(const NtParams p, const
             for (int j = 0; j < TN; ++j) acc[i][j] = sum[i][j];
         __syncthreads();                               // the flag word is read; the epilogue stages through the same LDS
     }
+    if constexpr (STAT) {
+        // column statistics of the stored tile (eg_epilogue.stat_mode); masks are not prefetched here (32 registers the sums need)
+        NtEpiPre<T, TM, TN, 0> epi0;
+        nt_epi_prefetch<T, BM, 128, TM, TN, 512, 0>(epi0, p, ph, m0, n0, wm * TM * 16, wn * 64, tid, frow, fq);
+        nt_epilogue_lds_stat<T, BM, 128, TM, TN, 512, 0>(epi0, p, ph, acc, smem, m0, n0, wm * TM * 16, wn * 64, tid, frow, fq, phase * tiles_m + m_tile,
+                                                         n_tile, tiles_n);
+        return;
+    }
     constexpr int PF = 8;
     NtEpiPre<T, TM, TN, PF> epi;
     nt_epi_prefetch<T, BM, 128, TM, TN, 512, PF>(epi, p, ph, m0, n0, wm * TM * 16, wn * 64, tid, frow, fq);
@@ -606,6 +616,17 @@ static void launch_s(const NtParams& p, const Nt8pGeom& g, int nphase, int ns, h
             fprintf(stderr, "[nt8s_prof] patch %d wgs %zu nk %d | median ticks: prologue %.0f  K loop %.0f (%.0f per K tile: wave 0 groups %.0f, counted wait %.0f, barrier %.0f; wave 7 %.0f / %.0f / %.0f)  epilogue %.0f (operand fetch %.0f, staging + store issue %.0f, store drain %.0f) | clock %.0f MHz | "
                     "first->last wave-0 stamp %.1f us, median WG start %.1f us, median end %.1f us, last end %.1f us\n",
                     (int)PATCH, nwg, nk, med(pro), med(loop), med(loop) / nk, med(l_g) / nk, med(l_w) / nk, med(l_b) / nk, med(l7_g) / nk, med(l7_w) / nk, med(l7_b) / nk, med(epi), med(e_pf), med(e_st), med(e_dr), med(clk), (double)(r1 - r0) / 100.0, med(start), med(endt), mx(endt));
+            return;
+        }
+    }
+    if constexpr (!PATCH && !std::is_same<T, float>::value) {
+        if (p.stat_mode != EG_STAT_NONE) {
+            static bool attr_stat = false;
+            if (!attr_stat) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_nt8s_kernel<T, PATCH, SPLITK, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_stat = true;
+            }
+            hipLaunchKernelGGL((igemm_nt8s_kernel<T, PATCH, SPLITK, false, true>), dim3(tm * tn, 1, nphase * ns), dim3(512), lds, st, p, g, tm, tn, (unsigned long long*)nullptr);
             return;
         }
     }

@@ -167,6 +167,67 @@ extern "C" int eg_bn_fwd_train(int dtype, const void* x, void* y, int M, int C, 
     return 0;
 }
 
+// ---- statistics from the producing convolution's epilogue (eg_epilogue.stat_mode = EG_STAT_MOMENTS) -----------------------------
+// stat = [2][C][nrb]: (mean, M2) of nrb row blocks of `cnt` rows each.  One wave per channel, contiguous reads.  Equal counts make
+// Chan's combination a plain two-pass form without divisions in the loops: mean = avg(mean_b), M2 = sum M2_b + cnt * sum (mean_b - mean)^2;
+// fp64, lanes in a fixed order.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ void bn_stats_final_eq_kernel(const float* __restrict__ stat, int nrb, int C, int cnt, int M, float eps, float momentum,
+                                         float* running_mean, float* running_var, long long* nbt, float* save_mean, float* save_invstd,
+                                         const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ coef) {
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
+    if (c >= C) return;
+    const float* __restrict__ mb = stat + (size_t)c * nrb;
+    const float* __restrict__ qb = stat + ((size_t)C + c) * nrb;
+    double sm = 0.0;
+    for (int r = lane; r < nrb; r += 64) sm += (double)mb[r];
+    const double mean = wave_sum_f64(sm) / (double)nrb;
+    double m2 = 0.0;
+    for (int r = lane; r < nrb; r += 64) {
+        const double d = (double)mb[r] - mean;
+        m2 += (double)qb[r] + (double)cnt * d * d;
+    }
+    m2 = wave_sum_f64(m2);
+    if (lane != 0) return;
+    const double var = m2 / (double)M;
+    save_mean[c] = (float)mean;
+    const float istd = (float)(1.0 / sqrt(var + (double)eps));
+    save_invstd[c] = istd;
+    coef[c] = gamma[c] * istd;
+    coef[C + c] = beta[c] - (float)mean * gamma[c] * istd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+    if (running_var) {
+        const double unb = M > 1 ? m2 / (double)(M - 1) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+}
+
+extern "C" int eg_bn_fwd_train_fused(int dtype, const void* x, void* y, int M, int C, const float* stat, int nrb, int rows_per_block,
+                                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                     long long* num_batches_tracked, float* save_mean, float* save_invstd, float* ws, int act, float slope,
+                                     eg_stream_t s) {
+    EG_REQUIRE(x && y && stat && gamma && beta && save_mean && save_invstd && ws && M > 0 && C > 0 && nrb > 0, "eg_bn_fwd_train_fused: bad argument");
+    EG_REQUIRE((long long)nrb * rows_per_block == M, "eg_bn_fwd_train_fused: nrb * rows_per_block must be M (whole row blocks of equal size)");
+    EG_REQUIRE(C % (dtype == EG_F32 ? 4 : 8) == 0, "eg_bn_fwd_train_fused: C must be a multiple of the 16-byte vector width");
+    hipStream_t st = (hipStream_t)s;
+    float* coef = ws;                                   // 2*C floats
+    hipLaunchKernelGGL(bn_stats_final_eq_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, stat, nrb, C, rows_per_block, M, eps, momentum, running_mean,
+                       running_var, num_batches_tracked, save_mean, save_invstd, gamma, beta, coef);
+    const int cpr = C / (dtype == EG_F32 ? 4 : 8);
+    const int blocks = bn_apply_blocks((size_t)M, cpr);
+    if (dtype == EG_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, (size_t)M, C, coef, act, slope);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(bn_apply_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, (const f16_t*)x, (f16_t*)y, (size_t)M, C, coef, act, slope);
+    else hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, (size_t)M, C, coef, act, slope);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
 // ---- synchronised BatchNorm (data parallel: statistics over the GLOBAL batch) ---------------------------------------
 // forward:  eg_bn_stats_local -> (n, mean, M2) per channel of this rank's rows; the host layer gathers the 3*C floats of every rank
 //           (slot-wise all-reduce); eg_bn_fwd_from_stats combines them with Chan's formula (same kernel as the single-rank path, the
@@ -454,6 +515,50 @@ extern "C" int eg_bn_bwd_from_sums(int dtype, const void* z, const void* da, voi
     if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)z, (const float*)da, (float*)dz, (size_t)M_local, C, coef, act, slope, EG_ACT_NONE, 0.f, (const float*)nullptr);
     else if (dtype == EG_F16) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, (const f16_t*)z, (const f16_t*)da, (f16_t*)dz, (size_t)M_local, C, coef, act, slope, EG_ACT_NONE, 0.f, (const float*)nullptr);
     else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)da, (bf16_t*)dz, (size_t)M_local, C, coef, act, slope, EG_ACT_NONE, 0.f, (const float*)nullptr);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// the two sums from the epilogue of the convolution that produced dy (EG_STAT_BN_BWD), stat = [2][C][nrb]: one wave per channel
+__global__ void bn_bwd_final_t_kernel(const float* __restrict__ stat, int nrb, int C, float* sums, float* dgamma, float* dbeta,
+                                      const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+                                      const float* __restrict__ invstd, int M, float* __restrict__ coef) {
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    const float* __restrict__ a = stat + (size_t)c * nrb;
+    const float* __restrict__ b = stat + ((size_t)C + c) * nrb;
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = lane; r < nrb; r += 64) { s1 += a[r]; s2 += b[r]; }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane != 0) return;
+    sums[c] = s1;
+    sums[C + c] = s2;
+    if (dbeta) dbeta[c] += s1;
+    if (dgamma) dgamma[c] += s2;
+    const float g = gamma[c], is = invstd[c], mu = mean[c], invM = 1.f / (float)M;
+    coef[c] = g * is;
+    coef[C + c] = g * is * is * s2 * invM;
+    coef[2 * C + c] = g * is * (s1 * invM - mu * is * s2 * invM);
+    coef[3 * C + c] = g * is;
+    coef[4 * C + c] = beta[c] - mu * g * is;
+}
+
+extern "C" int eg_bn_bwd_fused(int dtype, const void* z, const void* dy, void* dz, int M, int C, const float* stat, int nrb,
+                               const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                               float* sums, float* ws, eg_stream_t s) {
+    EG_REQUIRE(z && dy && dz && stat && gamma && beta && save_mean && save_invstd && sums && ws && M > 0 && C > 0 && nrb > 0, "eg_bn_bwd_fused: bad argument");
+    EG_REQUIRE(C % (dtype == EG_F32 ? 4 : 8) == 0, "eg_bn_bwd_fused: C must be a multiple of the 16-byte vector width");
+    hipStream_t st = (hipStream_t)s;
+    float* coef = ws;                                   // 5*C floats
+    hipLaunchKernelGGL(bn_bwd_final_t_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, stat, nrb, C, sums, dgamma, dbeta, gamma, beta, save_mean, save_invstd, M, coef);
+    const int cpr = C / (dtype == EG_F32 ? 4 : 8);
+    const int blocks = bn_apply_blocks((size_t)M, cpr);
+    // dy already carries the activation gradient (act = NONE here)
+    if (dtype == EG_F32) hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)z, (const float*)dy, (float*)dz, (size_t)M, C, coef, EG_ACT_NONE, 0.f, EG_ACT_NONE, 0.f, (const float*)nullptr);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(bn_bwd_apply_kernel<f16_t>, dim3(blocks), dim3(256), 0, st, (const f16_t*)z, (const f16_t*)dy, (f16_t*)dz, (size_t)M, C, coef, EG_ACT_NONE, 0.f, EG_ACT_NONE, 0.f, (const float*)nullptr);
+    else hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)z, (const bf16_t*)dy, (bf16_t*)dz, (size_t)M, C, coef, EG_ACT_NONE, 0.f, EG_ACT_NONE, 0.f, (const float*)nullptr);
     EG_LAUNCH_CHECK();
     return 0;
 }

@@ -11,7 +11,8 @@ import os
 import torch
 
 from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, EG_BF16, EG_F16, EG_F32, NT_AUTO, NT_BUF128,
-                   NT_PERS, NT_REG, NT_S8, NT_S8P, OUT_NCHW_F32, OUT_NHWC, EgConv, EgEpilogue, EgSnLayer, lib)
+                   NT_PERS, NT_REG, NT_S8, NT_S8P, OUT_NCHW_F32, OUT_NHWC, STAT_BN_BWD, STAT_MOMENTS, STAT_NONE, STAT_SN_BIAS, EgConv, EgEpilogue,
+                   EgSnLayer, lib)
 
 __all__ = ["EG_F32", "EG_BF16", "EG_F16", "ACT_NONE", "ACT_LRELU", "ACT_RELU", "ACT_TANH", "ACT_SIGMOID", "OUT_NHWC",
            "OUT_NCHW_F32"]
@@ -64,14 +65,25 @@ _ENV_SPLITK = int(os.environ.get("EG_NT_SPLITK", "0"))
 
 
 def epilogue(bias=None, bias_mod=0, sigma=None, act=ACT_NONE, slope=0.0, mask=None, mask_act=ACT_NONE,
-             mask_slope=0.0, out_mode=OUT_NHWC, sigma_rows=0, nt_variant=_ENV_VARIANT, nt_splitk=_ENV_SPLITK, splitk_ws="default") -> EgEpilogue:
+             mask_slope=0.0, out_mode=OUT_NHWC, sigma_rows=0, nt_variant=_ENV_VARIANT, nt_splitk=_ENV_SPLITK, splitk_ws="default",
+             stat_mode=STAT_NONE, stat_out=None, stat_aux=None, stat_p=(), stat_act=ACT_NONE, stat_slope=0.0) -> EgEpilogue:
     """``nt_variant`` / ``nt_splitk``: per-call kernel hints (NT_* in _lib.py; 0 = the planner decides).  ``splitk_ws``: scratch
-    tensor lent for K splits (default: the device's registered workspace; None = never split)."""
+    tensor lent for K splits (default: the device's registered workspace; None = never split).  ``stat_*``: column statistics of
+    the stored tile fused into the epilogue (eg_epilogue in the header; only where ``conv_stat_blocks`` answers > 0)."""
     ws = splitk_ws
     if isinstance(ws, str):
         ws = SPLITK_OVERRIDE if SPLITK_OVERRIDE is not None else (SPLITK_WS.get(torch.cuda.current_device()) if SPLITK_WS else None)
+    sp = [_p(t) for t in stat_p] + [None] * (4 - len(stat_p))
     return EgEpilogue(_p(bias), bias_mod, _p(sigma), act, slope, _p(mask), mask_act, mask_slope, out_mode, sigma_rows,
-                      _p(ws), ws.numel() * ws.element_size() if ws is not None else 0, nt_variant, nt_splitk)
+                      _p(ws), ws.numel() * ws.element_size() if ws is not None else 0, nt_variant, nt_splitk,
+                      stat_mode, _p(stat_out), _p(stat_aux), sp[0], sp[1], sp[2], sp[3], stat_act, stat_slope)
+
+
+def conv_stat_blocks(c, dtype, bwd, ep=None) -> int:
+    """row blocks of the fused column statistics this exact call (geometry, hints, scratch of ``ep``) would write; 0 = it cannot fuse them"""
+    if ep is None:
+        ep = epilogue()
+    return lib().query("eg_conv_stat_blocks", ctypes.byref(c), dtype, int(bwd), ctypes.byref(ep))
 
 
 # ---- implicit-GEMM family ------------------------------------------------------------------------
@@ -217,6 +229,10 @@ def bias_grad_sn(dtype, dzs, a, bias, rows, N, rows_per_tape, sigma, slope, ws, 
     lib().call("eg_bias_grad_sn", dtype, _p(dzs), _p(a), _p(bias), rows, N, rows_per_tape, _p(sigma), slope, _p(ws), _p(gb), _p(coef), _stream())
 
 
+def bias_grad_sn_fused(stat, nrb, N, tiles_m, tiles_per_tape, ntapes, sigma, gb, coef):
+    lib().call("eg_bias_grad_sn_fused", _p(stat), nrb, N, tiles_m, tiles_per_tape, ntapes, _p(sigma), _p(gb), _p(coef), _stream())
+
+
 def wgrad_reduce_rank1(slab, nsplit, n_slab, n_rows, C, T, grad, ntapes, coef, u, v, c_row=0):
     lib().call("eg_wgrad_reduce_rank1", _p(slab), nsplit, n_slab, n_rows, C, T, _p(grad), ntapes, _p(coef), _p(u), _p(v), c_row, _stream())
 
@@ -319,6 +335,17 @@ def bn_bwd_from_sums(dtype, z, da, dz, M_local, C, sums_global, M_global, gamma,
 def bn_fwd_train(dtype, x, y, M, C, gamma, beta, eps, momentum, rmean, rvar, nbt, save_mean, save_invstd, ws, act=ACT_NONE, slope=0.0):
     lib().call("eg_bn_fwd_train", dtype, _p(x), _p(y), M, C, _p(gamma), _p(beta), eps, momentum, _p(rmean), _p(rvar), _p(nbt),
                _p(save_mean), _p(save_invstd), _p(ws), act, slope, _stream())
+
+
+def bn_fwd_train_fused(dtype, x, y, M, C, stat, nrb, rows_per_block, gamma, beta, eps, momentum, rmean, rvar, nbt, save_mean, save_invstd, ws,
+                       act=ACT_NONE, slope=0.0):
+    lib().call("eg_bn_fwd_train_fused", dtype, _p(x), _p(y), M, C, _p(stat), nrb, rows_per_block, _p(gamma), _p(beta), eps, momentum, _p(rmean), _p(rvar),
+               _p(nbt), _p(save_mean), _p(save_invstd), _p(ws), act, slope, _stream())
+
+
+def bn_bwd_fused(dtype, z, dy, dz, M, C, stat, nrb, gamma, beta, save_mean, save_invstd, dgamma, dbeta, sums, ws):
+    lib().call("eg_bn_bwd_fused", dtype, _p(z), _p(dy), _p(dz), M, C, _p(stat), nrb, _p(gamma), _p(beta), _p(save_mean), _p(save_invstd),
+               _p(dgamma), _p(dbeta), _p(sums), _p(ws), _stream())
 
 
 def bn_bwd(dtype, z, da, dz, M, C, gamma, beta, save_mean, save_invstd, act, slope, dgamma, dbeta, sums, ws):

@@ -65,7 +65,32 @@ typedef struct eg_epilogue {
                               /* every launch leaves at zero.  One scratch must not be lent to two launches that may run concurrently. */
     int nt_variant;           /* EG_NT_AUTO (0): the planner picks the kernel; otherwise force one (the call fails if it cannot run the problem) */
     int nt_splitk;            /* 0: the planner picks the K split; n >= 1: at most n splits (1 = never) */
+    /* Column statistics of the stored tile, fused into the epilogue (EG_STAT_*; 0 = none): the reductions that follow a convolution in the
+     * reference's graph -- BatchNorm batch statistics (celebA/EAD-GAN_celebA.py:79,83,87), the two sums of the BatchNorm backward, the bias
+     * gradient + spectral-norm coefficient of a spectrally normalised layer (:110-122) -- taken from the tile while it is in LDS instead of
+     * by a kernel that re-reads the whole tensor.  Only launches that eg_conv_stat_blocks() answers > 0 for may set it (the 8-wave kernel
+     * on whole 256-row tiles); such a launch fails otherwise.  Per row block rb = phase * tiles_m + m_tile (256 lattice rows) and column n:
+     *   stat_out[(0 * N + n) * nrb + rb], stat_out[(1 * N + n) * nrb + rb]     (nrb = eg_conv_stat_blocks())
+     * deterministic (fixed order inside a tile; the consumers eg_bn_fwd_train_fused / eg_bn_bwd_fused / eg_bias_grad_sn_fused sum the row
+     * blocks in a fixed order).
+     *   EG_STAT_MOMENTS : (mean, M2) of the 256 stored values of the column
+     *   EG_STAT_BN_BWD  : the launch computes da = the gradient w.r.t. a BatchNorm layer's activation output.  stat_aux = z (the BatchNorm
+     *                     input, layout of dst), stat_p0..p3 = save_mean, save_invstd, gamma, beta, stat_act / stat_slope = the activation
+     *                     behind the BatchNorm.  STORES dy = da * act'(bn(z)) instead of da; sums (sum dy, sum dy * xhat)
+     *   EG_STAT_SN_BIAS : the launch computes dzs = dz / sigma of a spectrally normalised LeakyReLU layer (mask = its activation output a,
+     *                     mask_act = EG_ACT_LRELU); stat_p0 = the layer's bias.  Sums (sum dzs, sum dzs * (lrelu^-1(a) - bias)); the second
+     *                     sum is further reduced over the tile's 128 columns: stat_out[N * nrb + rb * (N / 128) + n_tile] */
+    int stat_mode;
+    float* stat_out;
+    const void* stat_aux;
+    const float* stat_p0;
+    const float* stat_p1;
+    const float* stat_p2;
+    const float* stat_p3;
+    int stat_act;
+    float stat_slope;
 } eg_epilogue;
+enum { EG_STAT_NONE = 0, EG_STAT_MOMENTS = 1, EG_STAT_BN_BWD = 2, EG_STAT_SN_BIAS = 3 };
 
 /* kernels behind eg_conv_fwd / eg_conv_bwd_data.  The choice is a pure function of the problem and of these two per-call fields:
  * the library holds no tuning state.  All variants accumulate K in the same order: without a K split they are bit-identical. */
@@ -99,6 +124,10 @@ int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, const void* wp
  * buffer-descriptor kernel (plain / split-K), 135 = persistent pipeline, 147 / 148 = igemm_nt8s (plain / split-K), 149 / 150 =
  * igemm_nt8s with the input patch; -1 = the forced variant cannot run the problem.  Profiling labels and tests. */
 int eg_igemm_nt_tile(const eg_conv* c, int dtype, int bwd, int variant, int splitk);
+/* row blocks (nrb) of the column statistics that THIS call -- eg_conv_fwd (bwd = 0) / eg_conv_bwd_data (bwd = 1) with this epilogue, its
+ * kernel hints and its split-K scratch -- would write if stat_mode were set; 0 = the launch cannot fuse them (another kernel than the
+ * 8-wave one, ragged row tiles, splits reduced by a second launch): the caller then runs the stand-alone reduction kernels. */
+int eg_conv_stat_blocks(const eg_conv* c, int dtype, int bwd, const eg_epilogue* ep);
 /* bytes of eg_epilogue.splitk_ws that let eg_conv_fwd (bwd = 0) / eg_conv_bwd_data (bwd = 1) split as far as the policy wants */
 size_t eg_conv_splitk_ws_bytes(const eg_conv* c, int dtype, int bwd);
 /* dW partial slabs: slab[split][Cout][k*k][Cin] fp32.  Returns the split count through *nsplit.  16-bit 4x4 / stride-2 / pad-1 layers
@@ -144,6 +173,10 @@ int eg_bias_grad(int dtype, const void* dY, int rows, int N, int bias_mod, float
 size_t eg_bias_grad_sn_ws_floats(int rows, int N, int rows_per_tape);
 int eg_bias_grad_sn(int dtype, const void* dzs, const void* a, const float* bias, int rows, int N, int rows_per_tape,
                     const float* sigma, float slope, float* ws, float* gb, float* coef, eg_stream_t s);
+/* eg_bias_grad_sn with the per-tile sums taken from the epilogue of the convolution that produced dzs (EG_STAT_SN_BIAS): stat = its
+ * stat_out (nrb = nphase * tiles_m row blocks of 256 lattice rows; tape of a row block = (rb % tiles_m) / tiles_per_tape) */
+int eg_bias_grad_sn_fused(const float* stat, int nrb, int N, int tiles_m, int tiles_per_tape, int ntapes, const float* sigma, float* gb,
+                          float* coef, eg_stream_t s);
 /* grad[n][c][t] += sum_split slab[split][n][t][c] - sum_tape coef[tape] * u[tape][n] * v[tape][c*T + t]
  * (u: [ntapes][n_rows], v: [ntapes][c_row*T]); single pass, deterministic.  c_row: destination row length in channels
  * (0 = C; < C when the gathered operand was zero padded, e.g. 9 of 16 im2col columns). */
@@ -215,6 +248,18 @@ size_t eg_bn_ws_floats(int M, int C);
 int eg_bn_fwd_train(int dtype, const void* x, void* y, int M, int C, const float* gamma, const float* beta, float eps,
                     float momentum, float* running_mean, float* running_var, long long* num_batches_tracked,
                     float* save_mean, float* save_invstd, float* ws, int act, float slope, eg_stream_t s);
+/* the same with the batch statistics taken from the producing convolution's epilogue (eg_epilogue.stat_mode = EG_STAT_MOMENTS):
+ * stat = its stat_out, nrb row blocks of rows_per_block rows each.  Two launches (statistics + running stats, apply) instead of three,
+ * and x is read once instead of twice.  ws: 2*C floats. */
+int eg_bn_fwd_train_fused(int dtype, const void* x, void* y, int M, int C, const float* stat, int nrb, int rows_per_block,
+                          const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                          long long* num_batches_tracked, float* save_mean, float* save_invstd, float* ws, int act, float slope,
+                          eg_stream_t s);
+/* backward with the two sums taken from the epilogue of the convolution that produced dy (EG_STAT_BN_BWD: dy already carries the
+ * activation gradient): dz = gamma * invstd * (dy - sum(dy)/M - xhat * sum(dy*xhat)/M); dgamma / dbeta accumulate.  ws: 5*C floats. */
+int eg_bn_bwd_fused(int dtype, const void* z, const void* dy, void* dz, int M, int C, const float* stat, int nrb,
+                    const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                    float* sums, float* ws, eg_stream_t s);
 /* synchronised BatchNorm for data parallel runs (statistics over the global batch: N ranks x B/N images == 1 rank x B images).
  * Forward: eg_bn_stats_local writes this rank's (count, mean, M2) per channel to stats[3*C]; the host gathers every rank's block
  * (stats_all[nranks][3*C]); eg_bn_fwd_from_stats combines them (Chan, fp64), updates the running statistics with the GLOBAL
