@@ -33,6 +33,32 @@ IMG_GEMM = os.environ.get("EG_IMG_GEMM", "1") == "1"
 # convolution that produces the tensor (eg_epilogue.stat_mode) instead of by kernels that re-read it; 0: the stand-alone kernels (A/B runs)
 FUSE_STATS = os.environ.get("EG_FUSE_STATS", "1") != "0"
 
+# optimizer.step() of a convolution weight and the refresh of its packed panels as ONE launch per layer (ops.adam_pack_conv / adam_pack_rows);
+# 0: one Adam launch over the arena (or bucket) followed by the re-packing launches (A/B runs; same bits either way)
+FUSE_ADAM = os.environ.get("EG_FUSE_ADAM", "1") != "0"
+# ... per optimizer update of the pipelined step (g1, d2, d3, g3 as in EG_BUCKET_OPT; "all")
+FUSE_ADAM_AT = os.environ.get("EG_FUSE_ADAM_AT", "g3")
+
+
+def adam_bucket(eng, arena, tag, lo, hi, m, v, lr, betas, step, zero, fuse=True):
+    """optimizer.step() (+ zero_grad) on one gradient bucket [lo, hi) of ``arena`` and the refresh of the packed panels of its layers.  The
+    bucket's big convolution weight (``eng.fused_weight(tag)``) is updated AND re-packed by one launch; the remaining parameters of the
+    bucket (biases, BatchNorm affine) by plain Adam launches on their slices.  The step counter has been ticked by the caller."""
+    b1, b2 = betas
+    fw = eng.fused_weight(tag) if (FUSE_ADAM and fuse) else None
+    if fw is None:
+        ops.adam_step_zero(arena.flat[lo:hi], arena.grad[lo:hi], m[lo:hi], v[lo:hi], hi - lo, lr, b1, b2, 1e-8, step, False, zero)
+        eng.repack_bucket(tag)
+        return
+    name, launch = fw
+    off, k = arena.slices[name]
+    assert lo <= off and off + k <= hi
+    launch(arena.flat[off:off + k], arena.grad[off:off + k], m[off:off + k], v[off:off + k], lr, b1, b2, step, zero)
+    for a, b in ((lo, off), (off + k, hi)):
+        if b > a:
+            ops.adam_step_zero(arena.flat[a:b], arena.grad[a:b], m[a:b], v[a:b], b - a, lr, b1, b2, 1e-8, step, False, zero)
+
+
 G_WIDTHS = (1024, 512, 256, 128)
 D_WIDTHS = (128, 256, 512, 1024)
 LRELU_SLOPE = 0.1
@@ -125,6 +151,20 @@ class _GenEngine:
         for tag, _ in self.BUCKETS:
             self.repack_bucket(tag)
 
+    def fused_weight(self, tag):
+        """(parameter name, launcher) of the bucket's convolution weight if Adam + re-packing of it run as one launch, else None"""
+        dt = self.dtype
+        if tag == "G0":
+            # [cin][1024][4][4] seen as [cin][16384]: panel row (t, co) = column co * 16 + t
+            return ("conv_blocks.0.weight", lambda p, g, m, v, lr, b1, b2, step, zero: ops.adam_pack_rows(
+                dt, p, g, m, v, self.l0.wp_fwd, self.cin, 16 * G_WIDTHS[0], self.l0.Kpad_fwd, 16, G_WIDTHS[0], lr, b1, b2, 1e-8, step, zero))
+        if tag in ("G1", "G2", "G3"):
+            r = self.mid[int(tag[1]) - 1]
+            if ops.adam_pack_conv_ok(r.c, dt, True, True):
+                return (f"conv_blocks.{(1, 4, 7)[int(tag[1]) - 1]}.weight", lambda p, g, m, v, lr, b1, b2, step, zero: ops.adam_pack_conv(
+                    r.c, dt, p, g, m, v, lr, b1, b2, 1e-8, step, zero, r.wp_fwd, r.wp_bwd))
+        return None
+
     def repack_bucket(self, tag):
         """re-pack the panels of one gradient bucket's layers (the optimizer lane updates bucket by bucket)"""
         g, dt = self.gen, self.dtype
@@ -140,10 +180,12 @@ class _GenEngine:
             # wp[t*C + c][ci] = W[ci][c][t]   (master [128][C][4][4])
             ops.pack_strided(dt, self._p(10, "weight"), self.l4g.wp_fwd, self.kp, G_WIDTHS[3], self.l4g.Kpad_fwd, g.channels, 1, 16, self.kp)
 
-    def forward(self, noise, labels, code, training=True, sync=None):
+    def forward(self, noise, labels, code, training=True, sync=None, ws=None):
         """``training=False``: BatchNorm with the running statistics, nothing updated (module.eval()).  ``sync`` (a dp.SyncBN):
-        batch statistics over all ranks (synchronised BatchNorm)."""
+        batch statistics over all ranks (synchronised BatchNorm).  ``ws``: scratch to use instead of the engine's (a forward that runs
+        on its own stream beside other main-stream work; the caller also activates that workspace's split-K scratch)."""
         dt, B, W = self.dtype, self.B, G_WIDTHS
+        small = (ws or self.ws).small
         ops.concat_cast(dt, noise, labels, code, self.inp, B, self.cpad)
         ops.conv_fwd(self.l0.c, dt, self.inp, self.l0.wp_fwd, self.h0, ops.epilogue(bias=self._p(0, "bias"), bias_mod=W[0]))
         x = self.h0
@@ -156,20 +198,20 @@ class _GenEngine:
                 # BatchNorm batch statistics from the transposed convolution's epilogue: z is read once (apply) instead of twice
                 ops.conv_bwd_data(r.c, dt, x, r.wp_bwd, self.z[i], ops.epilogue(bias=self._p(idx, "bias"), stat_mode=ops.STAT_MOMENTS, stat_out=stat))
                 ops.bn_fwd_train_fused(dt, self.z[i], self.a[i], M, W[i + 1], stat, nrb, 256, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean,
-                                       bn.running_var, bn.num_batches_tracked, self.mean[i], self.invstd[i], self.ws.small, ACT_RELU)
+                                       bn.running_var, bn.num_batches_tracked, self.mean[i], self.invstd[i], small, ACT_RELU)
                 x = self.a[i]
                 continue
             ops.conv_bwd_data(r.c, dt, x, r.wp_bwd, self.z[i], ops.epilogue(bias=self._p(idx, "bias")))
             if training and sync is not None:
-                ops.bn_stats_local(dt, self.z[i], M, W[i + 1], self.ws.small, self.bn_stats[i])
+                ops.bn_stats_local(dt, self.z[i], M, W[i + 1], small, self.bn_stats[i])
                 allst = sync.gather_stats(self.bn_stats[i])
                 ops.bn_fwd_from_stats(dt, self.z[i], self.a[i], M, W[i + 1], allst, sync.world, M * sync.world, bn.weight, bn.bias, bn.eps, bn.momentum,
-                                      bn.running_mean, bn.running_var, bn.num_batches_tracked, self.mean[i], self.invstd[i], self.ws.small, ACT_RELU)
+                                      bn.running_mean, bn.running_var, bn.num_batches_tracked, self.mean[i], self.invstd[i], small, ACT_RELU)
             elif training:
                 ops.bn_fwd_train(dt, self.z[i], self.a[i], M, W[i + 1], bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean,
-                                 bn.running_var, bn.num_batches_tracked, self.mean[i], self.invstd[i], self.ws.small, ACT_RELU)
+                                 bn.running_var, bn.num_batches_tracked, self.mean[i], self.invstd[i], small, ACT_RELU)
             else:
-                ops.bn_fwd_eval(dt, self.z[i], self.a[i], M, W[i + 1], bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, self.ws.small, ACT_RELU)
+                ops.bn_fwd_eval(dt, self.z[i], self.a[i], M, W[i + 1], bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, small, ACT_RELU)
             x = self.a[i]
         if IMG_GEMM:
             ops.conv_fwd(self.l4g.c, dt, x, self.l4g.wp_fwd, self.cols4, None)
@@ -435,6 +477,16 @@ class _DiscEngine:
     def repack(self):
         for tag, _ in self.BUCKETS:
             self.repack_bucket(tag)
+
+    def fused_weight(self, tag):
+        """see _GenEngine.fused_weight"""
+        if tag in ("D1", "D2", "D3"):
+            i = int(tag[1])
+            r = self.mid[i - 1]
+            if ops.adam_pack_conv_ok(r.c, self.dtype, True, True):
+                return (f"main.{2 * i}.weight_orig", lambda p, g, m, v, lr, b1, b2, step, zero: ops.adam_pack_conv(
+                    r.c, self.dtype, p, g, m, v, lr, b1, b2, 1e-8, step, zero, r.wp_fwd, r.wp_bwd))
+        return None
 
     def repack_bucket(self, tag):
         """re-pack the panels of one gradient bucket's layer (see _GenEngine.repack_bucket)"""
@@ -811,7 +863,10 @@ class DeviceInputs:
 # the switch on), but SLOWER in the overlapped step, 4.75 -> 4.94 ms (profiles/r02_x_ab_batch_d12.txt): the discriminator step's forward
 # no longer runs beside the generator's weight-gradient lanes and update.  Default 0: two forwards (T = 1, T = 2).
 BATCH_D12 = os.environ.get("EG_BATCH_D12", "0") != "0"
-BUCKET_OPT = os.environ.get("EG_BUCKET_OPT", "g3")     # "0" never, "1" every update, "3" the info step's two updates, "g3" only its last (G)
+# optimizer updates bucket by bucket (each bucket behind its own weight-gradient chain) instead of one update behind all chains: "0" never,
+# "1" every update, "3" the info step's two, or a comma list of g1 (generator step), d2 (discriminator step), d3, g3 (info step: D, then G)
+BUCKET_OPT = os.environ.get("EG_BUCKET_OPT", "g3")
+BUCKET_SET = {"0": set(), "1": {"g1", "d2", "d3", "g3"}, "3": {"d3", "g3"}}.get(BUCKET_OPT, set(BUCKET_OPT.split(",")))
 
 
 class CelebATrainer:
@@ -862,6 +917,13 @@ class CelebATrainer:
         # weight-gradient chains and re-packing run on a second stream beside the backward-data chain (same arithmetic, same order
         # inside every chain -> bit-identical results with and without)
         self.side = SideStream(dev, Workspace.get(dev), lanes=int(os.environ.get("EG_LANES", "4"))) if overlap else None
+        # experiment (EG_G3_EARLY=1): the info step's generator forward on a stream of its own, as soon as the generator's first update is
+        # done, beside the discriminator step -- it needs nothing the discriminator step produces
+        self.g3_early = overlap and os.environ.get("EG_G3_EARLY", "0") != "0" and sync_bn is None
+        if self.g3_early:
+            self.g3_stream = torch.cuda.Stream(dev)
+            self.g3_ws = Workspace(dev, register=False)
+            self.g3_ws._grow("small", Workspace.get(dev).small.numel())
 
     # -- the hot path ---------------------------------------------------------------------------------
     def _buckets(self, arena):
@@ -878,7 +940,16 @@ class CelebATrainer:
         return out
 
     def _adam(self, arena, m, v, lr, slot, tick):
-        ops.adam_step(arena.flat, arena.grad, m, v, arena.numel, lr, self.betas[0], self.betas[1], 1e-8, self.steps[slot:slot + 1], tick)
+        """optimizer.step() of one network + refresh of its packed panels (serial body)"""
+        eng = self.ge if arena is self.G.arena else self.de
+        if not FUSE_ADAM:
+            ops.adam_step(arena.flat, arena.grad, m, v, arena.numel, lr, self.betas[0], self.betas[1], 1e-8, self.steps[slot:slot + 1], tick)
+            eng.repack()
+            return
+        if tick:
+            ops.adam_tick(self.steps[slot:slot + 1])
+        for tag, lo, hi in self._buckets(arena):
+            adam_bucket(eng, arena, tag, lo, hi, m, v, lr, self.betas, self.steps[slot:slot + 1], False)
 
     def _step_body(self):
         if self.side is not None:
@@ -935,7 +1006,6 @@ class CelebATrainer:
         ge.backward(dimg, ga.grad, None, sync=self.sync_bn)
         self._reduce(ga.grad)
         self._adam(ga, self.mG, self.vG, self.lr[0], 0, True)
-        ge.repack()
         # ---- 2) discriminator step (:353-366); gen is the (detached) output of step 1; D(scaled) then D(gen), batched ----
         ops.fill_f32(da.grad)
         out = out12 if BATCH_D12 else de.forward([self.scaled, gen], 0)
@@ -944,7 +1014,6 @@ class CelebATrainer:
         de.backward(0, 2, self.dout[:2 * B], da.grad)
         self._reduce(da.grad)
         self._adam(da, self.mD, self.vD, self.lr[1], 1, True)
-        de.repack()
         ops.fill_f32(da.grad)
         # ---- 3) info + affine step (:375-401): D(gen), D(scaled), D(real) batched as tapes 0,1,2 ----
         ops.fill_f32(ga.grad)
@@ -960,8 +1029,6 @@ class CelebATrainer:
         self._reduce(ga.grad)
         self._adam(da, self.miD, self.viD, self.lr[2], 2, True)     # optimizer_info's step counter is shared by both arenas
         self._adam(ga, self.miG, self.viG, self.lr[2], 2, False)
-        de.repack()
-        ge.repack()
 
     def _step_body_pipelined(self):
         """The same iteration on five streams.  Main stream: the forward / backward-data chain of the three sub-steps, back to back.
@@ -990,8 +1057,10 @@ class CelebATrainer:
             ever wait for the capture's origin stream: a lane that RCCL waited for and that later waits for RCCL is the stream-level back
             edge hipStreamEndCapture crashes on), and FINISHED on the optimizer lane, so the main stream waits neither for the
             collective nor for Adam / re-packing."""
-            side.flush()
+            if side.deferred != "1":
+                side.flush()
             side.close_tags()
+            fuse = FUSE_ADAM and (FUSE_ADAM_AT == "all" or where in FUSE_ADAM_AT.split(","))
             buckets = self._buckets(arena)
             hs = {}
             if ar is not None:
@@ -1002,15 +1071,23 @@ class CelebATrainer:
                     else:
                         ar(arena.grad[lo:hi])
             last = buckets[-1][0]
-            if not (BUCKET_OPT == "1" or (BUCKET_OPT == "3" and where in ("d3", "g3")) or BUCKET_OPT == where):     # A/B switch: the whole arena in one update behind ALL chains (round-1 schedule)
+            if where not in BUCKET_SET:                 # the whole arena in one update behind ALL chains
                 def whole(_ws):
                     for tag in hs:
                         ar.finish(hs[tag])
-                    ops.adam_step_zero(arena.flat, arena.grad, m, v, arena.numel, lr, self.betas[0], self.betas[1], 1e-8, self.steps[slot:slot + 1],
-                                       tick, zero)
-                    if key_w:
-                        evs[key_w] = side.mark()
-                    eng.repack()
+                    if fuse:
+                        if tick:
+                            ops.adam_tick(self.steps[slot:slot + 1])
+                        for tag, lo, hi in buckets:
+                            adam_bucket(eng, arena, tag, lo, hi, m, v, lr, self.betas, self.steps[slot:slot + 1], zero)
+                        if key_w:
+                            evs[key_w] = side.mark()
+                    else:
+                        ops.adam_step_zero(arena.flat, arena.grad, m, v, arena.numel, lr, self.betas[0], self.betas[1], 1e-8, self.steps[slot:slot + 1],
+                                           tick, zero)
+                        if key_w:
+                            evs[key_w] = side.mark()
+                        eng.repack()
                     if key:
                         evs[key] = side.mark()
                 side.done.clear()
@@ -1021,11 +1098,18 @@ class CelebATrainer:
                 def fn(_ws, tag=tag, lo=lo, hi=hi, first=(k == 0)):
                     if tag in hs:
                         ar.finish(hs[tag])
-                    ops.adam_step_zero(arena.flat[lo:hi], arena.grad[lo:hi], m[lo:hi], v[lo:hi], hi - lo, lr, self.betas[0], self.betas[1], 1e-8,
-                                       self.steps[slot:slot + 1], tick and first, zero)
-                    if key_w and tag == last:
-                        evs[key_w] = side.mark()        # master weights are new
-                    eng.repack_bucket(tag)
+                    if fuse:
+                        if tick and first:
+                            ops.adam_tick(self.steps[slot:slot + 1])
+                        adam_bucket(eng, arena, tag, lo, hi, m, v, lr, self.betas, self.steps[slot:slot + 1], zero)
+                        if key_w and tag == last:
+                            evs[key_w] = side.mark()    # master weights are new
+                    else:
+                        ops.adam_step_zero(arena.flat[lo:hi], arena.grad[lo:hi], m[lo:hi], v[lo:hi], hi - lo, lr, self.betas[0], self.betas[1], 1e-8,
+                                           self.steps[slot:slot + 1], tick and first, zero)
+                        if key_w and tag == last:
+                            evs[key_w] = side.mark()    # master weights are new
+                        eng.repack_bucket(tag)
                     if key and tag == last:
                         evs[key] = side.mark()          # panels are new, gradients zeroed
                 side.defer_opt_after((tag,), fn)
@@ -1058,7 +1142,15 @@ class CelebATrainer:
         side.flush()
         dimg = de.backward(2, 1, self.dout[2 * B:], da.grad, need_wgrad=False, need_dimg=True)
         ge.backward(dimg, ga.grad, side, sync=self.sync_bn)
-        update(ga, self.mG, self.vG, self.lr[0], 0, True, True, ge, key="g")                            # beside the whole of step 2
+        update(ga, self.mG, self.vG, self.lr[0], 0, True, True, ge, key="g", where="g1")                # beside the whole of step 2
+        if self.g3_early:
+            side.flush()
+            self.g3_stream.wait_event(evs["g"])         # new panels, gradients zeroed
+            if not BATCH_D12:
+                self.g3_stream.wait_event(evs["prep2"])     # step 2's patch rows of the step-1 image exist: the image buffer may be rewritten
+            with torch.cuda.stream(self.g3_stream), self.g3_ws.active():
+                ge.forward(self.z, self.onehot, self.code, ws=self.g3_ws)
+                evs["g3fwd"] = side.mark()
         # ---- 2) discriminator step (:353-366); gen is the (detached) output of step 1; D(scaled) then D(gen), batched ----
         ops.fill_f32(da.grad)
         side.flush()
@@ -1070,15 +1162,24 @@ class CelebATrainer:
         ops.loss_bce_sigmoid(out[:B], 19, 0, B, 1.0, 0.5, self.losses[1:2], self.dout[:B])
         ops.loss_bce_sigmoid(out[B:], 19, 0, B, 0.0, 0.5, self.losses[1:2], self.dout[B:2 * B])
         de.backward(0, 2, self.dout[:2 * B], da.grad, side=side)
-        update(da, self.mD, self.vD, self.lr[1], 1, True, True, de, key_w="dw")                         # beside step 3's generator forward
+        g3_first = os.environ.get("EG_G3_FIRST", "0") != "0"
+        keep = side.deferred
+        if g3_first:
+            side.deferred = "1"                         # layer 0's chain, D's update and step 3's preparation are CAPTURED behind the generator forward's launches
+        update(da, self.mD, self.vD, self.lr[1], 1, True, True, de, key_w="dw", where="d2")             # beside step 3's generator forward
 
         def prep3(_ws):                                 # step 3's three power iterations (new weights), patch rows of scaled / real
             side.wait(evs["dw"])
             de.prepare(0, [None, self.scaled, self.real])
         side.defer_prep(prep3)
         # ---- 3) info + affine step (:375-401): D(gen), D(scaled), D(real) batched as tapes 0,1,2 ----
-        side.wait(evs["g"])                             # G's panels and zeroed gradients (optimizer lane, step 1)
-        gen = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
+        if self.g3_early:
+            side.wait(evs["g3fwd"])
+            gen = ge.img
+        else:
+            side.wait(evs["g"])                         # G's panels and zeroed gradients (optimizer lane, step 1)
+            gen = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
+        side.deferred = keep
         side.join()                                     # D's panels, power iterations, patch rows
         out = de.forward([gen, self.scaled, self.real], 0, prepared=(False, True, True))
         o_gen, o_trans, o_real = out[:B], out[B:2 * B], out[2 * B:]

@@ -14,6 +14,7 @@
 
 #include "eg_common.h"
 #include "igemm_nt.h"
+#include "adam.h"
 
 // This file is compiled with -ffp-contract=off (Makefile): every NT variant must round the epilogue (acc / sigma + bias) alike -- the
 // variants are tested bit for bit against each other -- and clang contracts `a * b + c` depending on where the operands come from.
@@ -1224,14 +1225,12 @@ __global__ __launch_bounds__(256) void pack_conv_tile_kernel(const PackTileParam
     }
 }
 
-extern "C" int eg_pack_conv(const eg_conv* c, int dtype, const float* w, void* wp_fwd, void* wp_bwd, eg_stream_t s) {
-    EG_REQUIRE(c && w && (wp_fwd || wp_bwd), "eg_pack_conv: null pointer");
-    EG_REQUIRE(dtype == EG_F32 || dtype == EG_BF16 || dtype == EG_F16, "dtype must be EG_F32, EG_BF16 or EG_F16");
+// tile-kernel parameters of a layer, or false where only the per-element gather kernels can pack it (ragged channel counts, K padding)
+static bool pack_tile_params(const eg_conv* c, int dtype, void* wp_fwd, void* wp_bwd, PackTileParams& p) {
     const int T = c->k * c->k, bk = bk_of(dtype);
     bool fast = (c->Cout % 16) == 0 && (c->Cin % 32) == 0 && T <= 16 && (!wp_bwd || c->stride <= 2);
-    PackTileParams p;
     memset(&p, 0, sizeof(p));
-    p.w = w; p.wp_fwd = wp_fwd; p.wp_bwd = wp_bwd; p.Cout = c->Cout; p.Cin = c->Cin; p.T = T;
+    p.wp_fwd = wp_fwd; p.wp_bwd = wp_bwd; p.Cout = c->Cout; p.Cin = c->Cin; p.T = T;
     if (fast && wp_fwd && (T * c->Cin) % bk != 0) fast = false;          // K padding: the gather kernel zero-fills
     if (fast && wp_bwd) {
         long long off = 0;
@@ -1252,6 +1251,16 @@ extern "C" int eg_pack_conv(const eg_conv* c, int dtype, const float* w, void* w
                 off += (long long)c->Cin * Kpad;
             }
     }
+    return fast;
+}
+
+extern "C" int eg_pack_conv(const eg_conv* c, int dtype, const float* w, void* wp_fwd, void* wp_bwd, eg_stream_t s) {
+    EG_REQUIRE(c && w && (wp_fwd || wp_bwd), "eg_pack_conv: null pointer");
+    EG_REQUIRE(dtype == EG_F32 || dtype == EG_BF16 || dtype == EG_F16, "dtype must be EG_F32, EG_BF16 or EG_F16");
+    const int T = c->k * c->k;
+    PackTileParams p;
+    const bool fast = pack_tile_params(c, dtype, wp_fwd, wp_bwd, p);
+    p.w = w;
     if (!fast) {
         if (wp_fwd) if (int e = eg_pack_fwd(c, dtype, w, wp_fwd, s)) return e;
         if (wp_bwd) if (int e = eg_pack_bwd(c, dtype, w, wp_bwd, s)) return e;
@@ -1265,6 +1274,207 @@ extern "C" int eg_pack_conv(const eg_conv* c, int dtype, const float* w, void* w
     else if (dtype == EG_F16) EG_PACK_TILE(f16_t);
     else EG_PACK_TILE(bf16_t);
 #undef EG_PACK_TILE
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam + re-packing in one pass (torch.optim.Adam.step() on a convolution's weight, celebA/EAD-GAN_celebA.py:344,365,400, followed by
+// the panel refresh every consumer of the weight needs): the pack_conv_tile tiling with the optimizer update applied while the master
+// tile is on its way into LDS -- p, g, m, v are read once, p, m, v (and the cleared g) written once, both panels written from the tile.
+// Same element update as adam_kernel (adam.h), same panel bytes as eg_pack_conv of the updated master.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int TTC, bool ZERO, bool V4, int TC>
+__global__ __launch_bounds__(256) void adam_pack_conv_tile_kernel(const PackTileParams p, float* __restrict__ w, float* __restrict__ g,
+                                                                  float* __restrict__ m, float* __restrict__ v, float lr, float b1, float b2,
+                                                                  float eps, const int* __restrict__ step) {
+    constexpr int VEC = Elt<T>::VEC;
+    constexpr int TN = 16;
+    extern __shared__ float tile[];                 // [TN][TC][T + 1]
+    const int TT = TTC ? TTC : p.T, TP = TT + 1;
+    const int n0 = blockIdx.x * TN, c0 = blockIdx.y * TC;
+    const int tid = threadIdx.x;
+    const AdamCoef ac = adam_coef(lr, b1, b2, eps, step);
+    if (V4) {
+        // 16-byte loads and stores (the four slices are 16-byte aligned and TT is a multiple of 4: a float4 stays inside one (n, c) run),
+        // four vectors per thread in flight -- the scalar form below moved 1.2 TB/s, the flat-arena Adam kernel moves 5.9
+        const int total4 = TN * TC * TT / 4;
+        constexpr int U = TC >= 32 ? 4 : 2;           // vectors per thread in flight (the narrow tile keeps the kernel under 48 registers)
+#pragma unroll 1
+        for (int e0 = tid; e0 < total4; e0 += U * 256) {
+            float4 pi[U], gi[U], mi[U], vi[U];
+            size_t idx[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = (e0 + u * 256) * 4;
+                const int n = e / (TC * TT), rem = e - n * (TC * TT);
+                idx[u] = ((size_t)(n0 + n) * p.Cin + c0) * TT + rem;
+                if (e0 + u * 256 < total4) {
+                    pi[u] = *reinterpret_cast<const float4*>(w + idx[u]); gi[u] = *reinterpret_cast<const float4*>(g + idx[u]);
+                    mi[u] = *reinterpret_cast<const float4*>(m + idx[u]); vi[u] = *reinterpret_cast<const float4*>(v + idx[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (e0 + u * 256 >= total4) continue;
+                adam_elem(pi[u].x, gi[u].x, mi[u].x, vi[u].x, ac);
+                adam_elem(pi[u].y, gi[u].y, mi[u].y, vi[u].y, ac);
+                adam_elem(pi[u].z, gi[u].z, mi[u].z, vi[u].z, ac);
+                adam_elem(pi[u].w, gi[u].w, mi[u].w, vi[u].w, ac);
+                *reinterpret_cast<float4*>(w + idx[u]) = pi[u];
+                *reinterpret_cast<float4*>(m + idx[u]) = mi[u];
+                *reinterpret_cast<float4*>(v + idx[u]) = vi[u];
+                if (ZERO) *reinterpret_cast<float4*>(g + idx[u]) = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int e = (e0 + u * 256) * 4;
+                const int n = e / (TC * TT), rem = e - n * (TC * TT);
+                const int c = rem / TT, t = rem - c * TT;
+                float* tp = tile + (n * TC + c) * TP + t;
+                tp[0] = pi[u].x; tp[1] = pi[u].y; tp[2] = pi[u].z; tp[3] = pi[u].w;
+            }
+        }
+    } else
+    for (int e = tid; e < TN * TC * TT; e += 256) {
+        const int n = e / (TC * TT), rem = e - n * (TC * TT);
+        const int c = rem / TT, t = rem - c * TT;
+        const size_t i = ((size_t)(n0 + n) * p.Cin + c0) * TT + rem;
+        float pi = w[i], mi = m[i], vi = v[i];
+        adam_elem(pi, g[i], mi, vi, ac);
+        w[i] = pi; m[i] = mi; v[i] = vi;
+        if (ZERO) g[i] = 0.f;
+        tile[(n * TC + c) * TP + t] = pi;
+    }
+    __syncthreads();
+    if (p.wp_fwd) {
+        T* dst = reinterpret_cast<T*>(p.wp_fwd);
+        const size_t pitch = (size_t)TT * p.Cin;
+        for (int it = tid; it < TN * TT * (TC / VEC); it += 256) {
+            const int cg = it % (TC / VEC), r = it / (TC / VEC);
+            const int t = r % TT, n = r / TT;
+            uint4 ov;
+            T* oe = reinterpret_cast<T*>(&ov);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) Elt<T>::st(oe + j, tile[(n * TC + cg * VEC + j) * TP + t]);
+            *reinterpret_cast<uint4*>(dst + (size_t)(n0 + n) * pitch + (size_t)t * p.Cin + c0 + cg * VEC) = ov;
+        }
+    }
+    if (p.wp_bwd) {
+        T* dst = reinterpret_cast<T*>(p.wp_bwd);
+        for (int it = tid; it < TC * p.nq * (TN / VEC); it += 256) {
+            const int ng = it % (TN / VEC), r = it / (TN / VEC);
+            const int q = r % p.nq, c = r / p.nq;
+            const int t = p.t_of[q];
+            uint4 ov;
+            T* oe = reinterpret_cast<T*>(&ov);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) Elt<T>::st(oe + j, tile[((ng * VEC + j) * TC + c) * TP + t]);
+            *reinterpret_cast<uint4*>(dst + p.off[q] + (size_t)(c0 + c) * p.pitch[q] + n0 + ng * VEC) = ov;
+        }
+    }
+}
+
+extern "C" int eg_adam_pack_conv_ok(const eg_conv* c, int dtype, int has_fwd, int has_bwd) {
+    PackTileParams p;
+    if (!c || (!has_fwd && !has_bwd) || c->k * c->k > 16) return 0;
+    return pack_tile_params(c, dtype, has_fwd ? (void*)1 : nullptr, has_bwd ? (void*)1 : nullptr, p) ? 1 : 0;
+}
+
+extern "C" int eg_adam_pack_conv(const eg_conv* c, int dtype, float* w, float* g, float* m, float* v, float lr, float b1, float b2, float eps,
+                                 const int* step, int zero_grad, void* wp_fwd, void* wp_bwd, eg_stream_t s) {
+    EG_REQUIRE(c && w && g && m && v && step && (wp_fwd || wp_bwd), "eg_adam_pack_conv: null pointer");
+    EG_REQUIRE(dtype == EG_F32 || dtype == EG_BF16 || dtype == EG_F16, "dtype must be EG_F32, EG_BF16 or EG_F16");
+    const int T = c->k * c->k;
+    PackTileParams p;
+    EG_REQUIRE(pack_tile_params(c, dtype, wp_fwd, wp_bwd, p), "eg_adam_pack_conv: this layer needs the gather kernels (eg_adam_pack_conv_ok() == 0): run eg_adam_step_zero + eg_pack_conv");
+    // tile width along Cin: 32 (64-byte panel stores, 34 KiB of LDS) or 8 (16-byte stores, 8.5 KiB: fits beside a resident 147-KiB GEMM
+    // workgroup, so the update can share CUs with the main chain's convolutions like the LDS-free flat Adam kernel does)
+    static const int tc_env = [] { const char* e = getenv("EG_ADAM_PACK_TC"); return e ? atoi(e) : 8; }();
+    const int tc = tc_env == 32 ? 32 : 8;
+    const dim3 grid(c->Cout / 16, c->Cin / tc);
+    const size_t lds = (size_t)16 * tc * (T + 1) * sizeof(float);
+    const bool v4 = T == 16 && ((((uintptr_t)w | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0);
+#define EG_AP_TC(TY, Z, TCC) do { if (v4) hipLaunchKernelGGL((adam_pack_conv_tile_kernel<TY, 16, Z, true, TCC>), grid, dim3(256), lds, (hipStream_t)s, p, w, g, m, v, lr, b1, b2, eps, step); \
+                               else if (T == 16) hipLaunchKernelGGL((adam_pack_conv_tile_kernel<TY, 16, Z, false, TCC>), grid, dim3(256), lds, (hipStream_t)s, p, w, g, m, v, lr, b1, b2, eps, step); \
+                               else hipLaunchKernelGGL((adam_pack_conv_tile_kernel<TY, 0, Z, false, TCC>), grid, dim3(256), lds, (hipStream_t)s, p, w, g, m, v, lr, b1, b2, eps, step); } while (0)
+#define EG_AP_TILE(TY, Z) do { if (tc == 32) EG_AP_TC(TY, Z, 32); else EG_AP_TC(TY, Z, 8); } while (0)
+#define EG_AP_TYPE(Z) do { if (dtype == EG_F32) EG_AP_TILE(float, Z); else if (dtype == EG_F16) EG_AP_TILE(f16_t, Z); else EG_AP_TILE(bf16_t, Z); } while (0)
+    if (zero_grad) EG_AP_TYPE(true);
+    else EG_AP_TYPE(false);
+#undef EG_AP_TC
+#undef EG_AP_TYPE
+#undef EG_AP_TILE
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// Adam + re-packing of a weight whose panel is a row-permuted transpose of the master: master w[K][N] (N contiguous; ConvTranspose2d on
+// a 1x1 input, celebA/EAD-GAN_celebA.py:76: K = input channels, N = Cout * 16), panel wp[n'][Kpad] with n' = (n % n_mod) * n_mul + n / n_mod
+// and k < K (the K padding keeps the zeros of the first eg_pack_strided).  A workgroup takes 32 master rows x 256 columns: coalesced
+// reads along N, the update, 16-byte panel stores along K.
+template <typename T, bool ZERO>
+__global__ __launch_bounds__(256) void adam_pack_rows_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                             T* __restrict__ wp, int K, int N, int Kpad, int n_mod, int n_mul, float lr, float b1,
+                                                             float b2, float eps, const int* __restrict__ step) {
+    constexpr int VEC = Elt<T>::VEC;
+    constexpr int TK = 8, TNN = 256;                   // 8 KiB of LDS: fits beside a resident GEMM workgroup
+    __shared__ float tile[TK][TNN + 1];
+    const int k0 = blockIdx.y * TK, n0 = blockIdx.x * TNN;
+    const int tid = threadIdx.x;
+    const AdamCoef ac = adam_coef(lr, b1, b2, eps, step);
+    const int n = n0 + tid;
+#pragma unroll 1
+    for (int kk = 0; kk < TK; kk += 4) {                 // four rows' loads in flight per thread
+        float pi[4], gi[4], mi[4], vi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + kk + u;
+            pi[u] = 0.f; gi[u] = 0.f; mi[u] = 0.f; vi[u] = 0.f;
+            if (k < K && n < N) {
+                const size_t i = (size_t)k * N + n;
+                pi[u] = w[i]; gi[u] = g[i]; mi[u] = m[i]; vi[u] = v[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + kk + u;
+            if (k < K && n < N) {
+                const size_t i = (size_t)k * N + n;
+                adam_elem(pi[u], gi[u], mi[u], vi[u], ac);
+                w[i] = pi[u]; m[i] = mi[u]; v[i] = vi[u];
+                if (ZERO) g[i] = 0.f;
+            }
+            tile[kk + u][tid] = pi[u];
+        }
+    }
+    __syncthreads();
+    // panel rows n' of this tile's columns, TK / VEC 16-byte vectors each
+    for (int it = tid; it < TNN * (TK / VEC); it += 256) {
+        const int kg = it % (TK / VEC), nl = it / (TK / VEC);
+        const int n = n0 + nl, kb = k0 + kg * VEC;
+        if (n >= N || kb >= K) continue;
+        const int np = (n % n_mod) * n_mul + n / n_mod;
+        T* dst = wp + (size_t)np * Kpad + kb;
+        if (kb + VEC <= K) {
+            uint4 ov;
+            T* oe = reinterpret_cast<T*>(&ov);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) Elt<T>::st(oe + j, tile[kg * VEC + j][nl]);
+            *reinterpret_cast<uint4*>(dst) = ov;
+        } else {
+            for (int j = 0; kb + j < K; ++j) Elt<T>::st(dst + j, tile[kg * VEC + j][nl]);
+        }
+    }
+}
+
+extern "C" int eg_adam_pack_rows(int dtype, float* w, float* g, float* m, float* v, void* wp, int K, int N, int Kpad, int n_mod, int n_mul,
+                                 float lr, float b1, float b2, float eps, const int* step, int zero_grad, eg_stream_t s) {
+    EG_REQUIRE(w && g && m && v && wp && step && K > 0 && N > 0 && Kpad >= K && n_mod > 0 && n_mul > 0 && (N % n_mod) == 0, "eg_adam_pack_rows: bad argument");
+    EG_REQUIRE(dtype == EG_F32 || dtype == EG_BF16 || dtype == EG_F16, "dtype must be EG_F32, EG_BF16 or EG_F16");
+    EG_REQUIRE((Kpad % vec_of(dtype)) == 0, "eg_adam_pack_rows: Kpad must be a multiple of the 16-byte vector width");
+    const dim3 grid(cdiv(N, 256), cdiv(K, 8));
+#define EG_APR(TY, Z) hipLaunchKernelGGL((adam_pack_rows_kernel<TY, Z>), grid, dim3(256), 0, (hipStream_t)s, w, g, m, v, (TY*)wp, K, N, Kpad, n_mod, n_mul, lr, b1, b2, eps, step)
+    if (zero_grad) { if (dtype == EG_F32) EG_APR(float, true); else if (dtype == EG_F16) EG_APR(f16_t, true); else EG_APR(bf16_t, true); }
+    else { if (dtype == EG_F32) EG_APR(float, false); else if (dtype == EG_F16) EG_APR(f16_t, false); else EG_APR(bf16_t, false); }
+#undef EG_APR
     EG_LAUNCH_CHECK();
     return 0;
 }

@@ -224,23 +224,7 @@ extern "C" int eg_sn_power_iter_multi(const eg_sn_layer* layers, int nlayers, fl
 // ---- Adam -----------------------------------------------------------------------------------------
 __global__ void adam_tick_kernel(int* step) { step[0] += 1; }
 
-struct AdamCoef { float step_size, bc2_sqrt, w, b2, eps; };
-
-__device__ __forceinline__ AdamCoef adam_coef(float lr, float b1, float b2, float eps, const int* __restrict__ step) {
-    const int t = step[0];
-    const double bc1 = 1.0 - pow((double)b1, (double)t);
-    const double bc2 = 1.0 - pow((double)b2, (double)t);
-    return {(float)((double)lr / bc1), (float)sqrt(bc2), 1.f - b1, b2, eps};
-}
-
-__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamCoef& c) {
-#pragma clang fp contract(off)      // the float4 and the scalar paths must round alike (slice-wise == whole-arena, bit for bit)
-    // exp_avg.lerp_(grad, 1-beta1) with ATen's two-sided formula
-    m = (c.w < 0.5f) ? m + c.w * (g - m) : g - (g - m) * (1.f - c.w);
-    v = v * c.b2 + (1.f - c.b2) * g * g;
-    const float denom = sqrtf(v) / c.bc2_sqrt + c.eps;
-    p = p - c.step_size * (m / denom);
-}
+#include "adam.h"
 
 // elements [0, head) and [head + 4*nvec, n) one per thread (the unaligned ends of an arena slice), the middle as float4; the four arrays
 // are slices of sibling arenas at the same element offset, so one `head` aligns all of them.  ZERO: the gradient is cleared in the
@@ -309,6 +293,13 @@ extern "C" int eg_adam_step_zero(float* p, float* g, float* m, float* v, size_t 
     EG_REQUIRE(p && g && m && v && step, "eg_adam_step_zero: null pointer");
     if (n == 0) return 0;
     launch_adam(p, g, m, v, n, lr, b1, b2, eps, step, tick, zero_grad != 0, (hipStream_t)s);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int eg_adam_tick(int* step, eg_stream_t s) {
+    EG_REQUIRE(step, "eg_adam_tick: null pointer");
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, step);
     EG_LAUNCH_CHECK();
     return 0;
 }

@@ -391,6 +391,24 @@ def adam_step_zero(p, g, m, v, n, lr, b1, b2, eps, step, tick=True, zero_grad=Fa
     lib().call("eg_adam_step_zero", _p(p), _p(g), _p(m), _p(v), n, lr, b1, b2, eps, _p(step), int(tick), int(zero_grad), _stream())
 
 
+def adam_tick(step):
+    lib().call("eg_adam_tick", _p(step), _stream())
+
+
+def adam_pack_conv_ok(c, dtype, has_fwd, has_bwd) -> bool:
+    return bool(lib().query("eg_adam_pack_conv_ok", ctypes.byref(c), dtype, int(has_fwd), int(has_bwd)))
+
+
+def adam_pack_conv(c, dtype, p, g, m, v, lr, b1, b2, eps, step, zero_grad, wp_fwd, wp_bwd):
+    """optimizer.step() on one convolution weight (slices of the four arenas) + refresh of its packed panels, one launch"""
+    lib().call("eg_adam_pack_conv", ctypes.byref(c), dtype, _p(p), _p(g), _p(m), _p(v), lr, b1, b2, eps, _p(step), int(zero_grad), _p(wp_fwd), _p(wp_bwd),
+               _stream())
+
+
+def adam_pack_rows(dtype, p, g, m, v, wp, K, N, Kpad, n_mod, n_mul, lr, b1, b2, eps, step, zero_grad):
+    lib().call("eg_adam_pack_rows", dtype, _p(p), _p(g), _p(m), _p(v), _p(wp), K, N, Kpad, n_mod, n_mul, lr, b1, b2, eps, _p(step), int(zero_grad), _stream())
+
+
 def clear_errors():
     return lib().query("eg_clear_errors")
 

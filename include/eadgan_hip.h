@@ -316,6 +316,19 @@ int eg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float l
  * (optimizer.step() + optimizer.zero_grad(), celebA/EAD-GAN_celebA.py:344-345,365-366,400-401) */
 int eg_adam_step_zero(float* p, float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,
                       int* step, int tick, int zero_grad, eg_stream_t s);
+/* optimizer.step() on ONE convolution weight (conv view master [Cout][Cin][k][k]) fused with the refresh of its packed panels: the update
+ * of eg_adam_step_zero (same bits) applied on the way through the tile transpose of eg_pack_conv (same panel bytes); p / g / m / v are
+ * the parameter's slices of the four arenas; `step` is the optimizer's device step counter, already ticked (eg_adam_tick).  Only layers
+ * eg_adam_pack_conv_ok() accepts (channel counts in multiples of 16 / 32, no K padding); either panel may be NULL. */
+int eg_adam_pack_conv_ok(const eg_conv* c, int dtype, int has_fwd, int has_bwd);
+int eg_adam_pack_conv(const eg_conv* c, int dtype, float* p, float* g, float* m, float* v, float lr, float b1, float b2, float eps,
+                      const int* step, int zero_grad, void* wp_fwd, void* wp_bwd, eg_stream_t s);
+/* the same for a weight whose panel is a row-permuted transpose of the master: master p[K][N] (N contiguous; the ConvTranspose2d on a
+ * 1x1 input, celebA/EAD-GAN_celebA.py:76), panel wp[n'][Kpad], n' = (n % n_mod) * n_mul + n / n_mod, columns k < K (the padding keeps
+ * the zeros eg_pack_strided wrote once) */
+int eg_adam_pack_rows(int dtype, float* p, float* g, float* m, float* v, void* wp, int K, int N, int Kpad, int n_mod, int n_mul,
+                      float lr, float b1, float b2, float eps, const int* step, int zero_grad, eg_stream_t s);
+int eg_adam_tick(int* step, eg_stream_t s);            /* step[0] += 1 (once per optimizer.step(), before its slice-wise updates) */
 int eg_fill_f32(float* p, size_t n, float val, eg_stream_t s);
 
 /* --- utility: generator input concat+cast, elementwise activation gradient, layout conversion -------------- */

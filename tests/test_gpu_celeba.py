@@ -376,6 +376,35 @@ def test_side_stream_overlap_is_bit_identical(monkeypatch):
         assert float((a - b).norm() / b.norm()) < 2e-2
 
 
+@pytest.mark.parametrize("overlap", [False, True])
+def test_fused_adam_and_repacking_is_bit_identical(overlap, monkeypatch):
+    """optimizer.step() of a convolution weight + refresh of its packed panels as one launch per layer (ops.adam_pack_conv /
+    adam_pack_rows) against the Adam launch over the arena followed by the re-packing launches: the same element update, the same
+    panel bytes -> identical losses, masters, moments and panels after 3 steps (celebA/EAD-GAN_celebA.py:344,365,400)."""
+    B = 8
+
+    def run(fuse):
+        monkeypatch.setattr(eg.celeba, "FUSE_ADAM", fuse)
+        orc, G, D = build_pair(12, "bf16")
+        tr = eg.celeba.CelebATrainer(G, D, B, dtype="bf16", overlap=overlap)
+        rng = np.random.RandomState(3)
+        real = co.synthetic_real(B, seed=7).to(DEV)
+        out = []
+        for i in range(3):
+            z, code, labels = co.draw_step_inputs(rng, B)
+            tr.load_inputs(real, z.to(DEV), code.to(DEV), labels.to(DEV))
+            out.append(tr.step_resident().clone())
+        torch.cuda.synchronize()
+        panels = [t.clone() for r in tr.ge.mid + tr.de.mid for t in (r.wp_fwd, r.wp_bwd)] + [tr.ge.l0.wp_fwd.clone(), tr.de.head.wp_fwd.clone()]
+        state = [G.arena.flat, D.arena.flat, tr.mG, tr.vG, tr.mD, tr.vD, tr.miG, tr.viG, tr.miD, tr.viD, tr.steps]
+        return torch.stack(out).cpu(), [t.clone() for t in state], panels
+
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]), (a[0], b[0])
+    for x, y in zip(a[1] + a[2], b[1] + b[2]):
+        assert torch.equal(x, y)
+
+
 def test_generator_eval_mode_uses_running_statistics():
     """generate_image.py / gen_imgs.py of the reference sample from G.eval(): BatchNorm with the running statistics, nothing
     updated.  Two training forwards move the running statistics, then eval forwards (fp32, bf16) are compared with torch."""
