@@ -29,6 +29,10 @@ opt = argparse.Namespace(n_epochs=50, batch_size=16, lr=0.0002, b1=0.5, b2=0.999
 # image-side transposed convolutions (128 -> C) as one GEMM + col2im gather (1) or as the 4-phase implicit GEMM (0)
 IMG_GEMM = os.environ.get("EG_IMG_GEMM", "1") == "1"
 
+# image-side convolutions (first D layer forward, input gradient of G's last layer) straight from the fp32 images on the MFMA units
+# (ops.conv_img_mfma) instead of patch rows in HBM + a K = 64 GEMM; the patch rows remain for the weight gradients, off the main chain
+IMG_DIRECT = os.environ.get("EG_IMG_DIRECT", "1") != "0"
+
 # column statistics (BatchNorm batch statistics / backward sums, bias gradient + spectral-norm coefficient) taken from the epilogue of the
 # convolution that produces the tensor (eg_epilogue.stat_mode) instead of by kernels that re-read it; 0: the stand-alone kernels (A/B runs)
 FUSE_STATS = os.environ.get("EG_FUSE_STATS", "1") != "0"
@@ -235,16 +239,25 @@ class _GenEngine:
                 side.defer(lane, fn, tag)
         flush = side.flush if side is not None else (lambda: None)
 
-        # tanh backward fused with the bias gradient of the last ConvTranspose2d
-        ops.act_grad_mul_bias_nchw(dimg, self.img, self.dimg_z, B, C, S * S, ACT_TANH, 0.0, ws.small, gof("conv_blocks.10.bias"))
-        # L4 = ConvTranspose2d(128 -> C): weight / input gradients as 1x1-conv GEMMs over im2col patches of d(img)
-        ops.im2col_img(dt, self.dimg_z, self.patches, B, C, S, S, 4, 2, 1, self.kp)
+        direct = IMG_DIRECT and ops.conv_img_mfma_ok(dt, C, S, S, W[3], 4, 2, 1)
+        if not direct:
+            # tanh backward fused with the bias gradient of the last ConvTranspose2d
+            ops.act_grad_mul_bias_nchw(dimg, self.img, self.dimg_z, B, C, S * S, ACT_TANH, 0.0, ws.small, gof("conv_blocks.10.bias"))
+            # L4 = ConvTranspose2d(128 -> C): weight / input gradients as 1x1-conv GEMMs over im2col patches of d(img)
+            ops.im2col_img(dt, self.dimg_z, self.patches, B, C, S, S, 4, 2, 1, self.kp)
 
         def l4_wgrad(wsw):
+            if direct:                                  # the patch rows only feed the weight gradient: built here, beside the main chain
+                ops.act_grad_mul_bias_nchw(dimg, self.img, self.dimg_z, B, C, S * S, ACT_TANH, 0.0, wsw.small, gof("conv_blocks.10.bias"))
+                ops.im2col_img(dt, self.dimg_z, self.patches, B, C, S, S, 4, 2, 1, self.kp)
             ns = ops.conv_wgrad(self.l4p.c, dt, self.patches, self.a[2], wsw.slab, wsw.wgs_target)
             ops.wgrad_reduce(wsw.slab, ns, W[3], W[3], self.kp, 1, gof("conv_blocks.10.weight"))
         wgrad_side(l4_wgrad, 0, "G4")
-        ops.conv_fwd(self.l4p.c, dt, self.patches, self.l4p.wp_fwd, self.da[2], None)
+        if direct:
+            # d(a) = Conv2d(C -> 128, 4, 2, 1) of d(img) * tanh'(img): straight from the two fp32 images, no patch rows
+            ops.conv_img_mfma(dt, [dimg], self.l4p.wp_fwd, self.da[2], B, C, S, S, None, gates=[self.img], gate_act=ACT_TANH)
+        else:
+            ops.conv_fwd(self.l4p.c, dt, self.patches, self.l4p.wp_fwd, self.da[2], None)
         flush()
         # L3..L1
         fused = (0, None)                               # (row blocks, sums) if da[i] came with its BatchNorm backward sums (then it holds dy)
@@ -454,6 +467,8 @@ class _DiscEngine:
         self.v = [torch.zeros(NT, kd[i], device=dev, dtype=torch.float32) for i in range(4)]
         self.coef = [torch.zeros(4, device=dev, dtype=torch.float32) for _ in range(4)]
         self.imgs = [None] * NT
+        self.patch_ok = [False] * NT                    # tape has its patch rows (the weight gradient of layer 0 reads them)
+        self.img_direct = IMG_DIRECT and ops.conv_img_mfma_ok(dtype, C, S, S, W[0], 4, 2, 1)
         self._stat = {}                                 # (layer, T) -> (row blocks, buffer) of the fused bias-gradient / coefficient sums
         self._sn_arrays = None
         self._sn(0)
@@ -526,6 +541,7 @@ class _DiscEngine:
     def _im2col_tape(self, t, img):
         npix = self.B * (self.S // 2) ** 2
         ops.im2col_img(self.dtype, img, self.patches[t * npix:(t + 1) * npix], self.B, self.C, self.S, self.S, 4, 2, 1, self.kp)
+        self.patch_ok[t] = True
 
     def prepare(self, t0, imgs, training=True):
         """Image-independent head start of ``forward(imgs, t0, prepared=...)``: the tapes' power iterations (in list order, like
@@ -549,11 +565,18 @@ class _DiscEngine:
             if prepared is None:
                 self._sn_tape(t, training)
             if prepared is None or not prepared[k]:
-                self._im2col_tape(t, img)
+                if self.img_direct:
+                    self.patch_ok[t] = False            # built by the weight-gradient chain if a backward pass wants them (backward)
+                else:
+                    self._im2col_tape(t, img)
         g = self.geo[T]
         sl = lambda buf, i: buf[t0 * (buf.shape[0] // self.NT):]
         ep = lambda i: ops.epilogue(bias=self._m(i).bias, sigma=self.sigma[i][t0:], sigma_rows=self.rows(i), act=ACT_LRELU, slope=LRELU_SLOPE)
-        ops.conv_fwd(g["l1p"], dt, sl(self.patches, 0), self.l1p.wp_fwd, sl(self.a[0], 0), ep(0))
+        if self.img_direct:
+            # first layer straight from the fp32 images of the T tapes (one launch, 1/sigma per tape): no patch rows on the main chain
+            ops.conv_img_mfma(dt, [im.contiguous() for im in imgs], self.l1p.wp_fwd, sl(self.a[0], 0), B, self.C, self.S, self.S, ep(0))
+        else:
+            ops.conv_fwd(g["l1p"], dt, sl(self.patches, 0), self.l1p.wp_fwd, sl(self.a[0], 0), ep(0))
         for i in range(3):
             ops.conv_fwd(g["mid"][i], dt, sl(self.a[i], i), self.mid[i].wp_fwd, sl(self.a[i + 1], i + 1), ep(i + 1))
         K = 16 * W[3]
@@ -601,6 +624,10 @@ class _DiscEngine:
                     else:
                         ops.bias_grad_sn(dt, sl(self.dz[i]), sl(self.a[i]), m.bias, T * self.rows(i), W[i], self.rows(i), self.sigma[i][t0:], LRELU_SLOPE,
                                          wsw.small, gof(f"main.{2 * i}.bias"), self.coef[i])
+                    if i == 0:
+                        for t in range(t0, t0 + T):     # patch rows of tapes whose forward ran straight from the image
+                            if not self.patch_ok[t]:
+                                self._im2col_tape(t, self.imgs[t])
                     ns = ops.conv_wgrad(geo, dt, x_in, sl(self.dz[i]), wsw.slab, wsw.wgs_target)
                     taps = 16 if i > 0 else 1
                     ops.wgrad_reduce_rank1(wsw.slab, ns, W[i], W[i], self.cin[i], taps, gof(f"main.{2 * i}.weight_orig"), T, self.coef[i],

@@ -78,7 +78,7 @@ __device__ __forceinline__ float eg_act_grad_from_out(float a, int act, float sl
     switch (act) {
         case EG_ACT_LRELU: return a > 0.f ? 1.f : slope;
         case EG_ACT_RELU: return a > 0.f ? 1.f : 0.f;
-        case EG_ACT_TANH: return 1.f - a * a;
+        case EG_ACT_TANH: return fmaf(-a, a, 1.f);      // explicit: the same bits in translation units built with and without fp contraction
         case EG_ACT_SIGMOID: return a * (1.f - a);
         default: return 1.f;
     }

@@ -1,0 +1,183 @@
+// Image-side layers of the CelebA networks on the MFMA units WITHOUT patch rows in HBM (16-bit types, gfx950):
+//
+//   conv_img_mfma : Conv2d(C <= 4 -> 128, 4, 2, 1) over fp32 NCHW images -> 16-bit NHWC activations
+//                   * the first Discriminator layer, forward (celebA/EAD-GAN_celebA.py:110; spectral norm: 1/sigma per tape, bias, LeakyReLU)
+//                   * the input gradient of the Generator's last ConvTranspose2d (:90-91), whose backward is this very convolution of
+//                     d(img) * tanh'(img) with the same weights
+//
+// Before, these ran as eg_im2col_img (fp32 image -> 16-bit patch rows [B*OH*OW][64] in HBM) + a K = 64 GEMM reading them back: 50 MB of
+// traffic per 128 images for 6 MB of input and 34 MB of output, 38 us (one tape) to 95 us (three) on the step's critical chain.  Here a
+// workgroup stages the six fp32 image rows that two output rows need in LDS (as 16-bit values), every lane builds its two K = 32
+// fragments from them (fragment chunk = one channel, two filter rows, four columns: 2 x 8 bytes of LDS), the 128 x 64 weight panel
+// lives in registers, 16 MFMAs per 16 pixels, and the tile leaves through LDS as whole 256-byte pixel rows.
+// Same operands in the same MFMA slots as the patch-row GEMM (K order = master weight order (c, ky, kx), zero padded to 64; k halves in
+// order) and the same epilogue arithmetic -> bit-identical outputs (tests/test_gpu_img_conv.py).
+#include <stdlib.h>
+
+#include "eg_common.h"
+#include "igemm_nt.h"
+
+#ifndef EG_IMG_CONV_OCC
+#define EG_IMG_CONV_OCC 3          // workgroups (of 4 waves) per CU the register allocation aims for
+#endif
+
+struct ImgMfmaParams {
+    const float* img[4];      // per tape: [B][C][H][W] fp32
+    const float* gate[4];     // per tape or null: input = img * act'(gate) (gate = the activation OUTPUT the image gradient passes through)
+    const void* wp;           // [128][64] panel, dtype T: wp[n][c*16 + ky*4 + kx], columns C*16 .. 63 zero
+    void* out;                // [ntapes*B][H/2][W/2][128] dtype T
+    const float* bias;        // [128] or null
+    const float* sigma;       // [ntapes] or null: out = acc / sigma[tape] + bias
+    int B, C, H, W;
+    int act;
+    float slope;
+    int gate_act;
+    float gate_slope;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, EG_IMG_CONV_OCC) void conv_img_mfma_kernel(const ImgMfmaParams p, int ntiles) {
+    constexpr int N = 128, XS = 72, OS = N + 8;          // LDS row pitches in elements: 66 used columns (x = -1 .. 64); 16-byte aligned pixel rows
+    __shared__ __attribute__((aligned(16))) unsigned short s_in[4][6][XS];
+    __shared__ __attribute__((aligned(16))) unsigned short s_out[4][16][OS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int OH = p.H >> 1, OW = p.W >> 1;
+    const int gxn = OW >> 5, tpi = (OH >> 1) * gxn;       // 32-column groups per row; tiles (2 output rows x 32 columns) per image
+    const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp);
+
+    // weight fragments, loaded once per workgroup: column tile j, k half s -> panel rows j*16 + frow, columns s*32 + fq*8 .. +7
+    uint4 bf[2][8];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bf[s][j] = *reinterpret_cast<const uint4*>(wp + (size_t)(j * 16 + frow) * 64 + s * 32 + fq * 8);
+    __shared__ __attribute__((aligned(16))) float s_bias[N];
+    if (tid < N) s_bias[tid] = p.bias ? p.bias[tid] : 0.f;      // (published by the loop's first barrier)
+    const EgActFast af = eg_act_fast(p.act, p.slope);
+
+    // staging slots of this thread: elements e = tid and tid + 256 of the 4 x 6 x 16 float4 grid (channel, image row, 4-column group)
+    struct Slot { float4 v; float lo, hi; };
+    auto fetch = [&](int tile, int e, Slot& sl) {
+        sl.v = make_float4(0.f, 0.f, 0.f, 0.f); sl.lo = 0.f; sl.hi = 0.f;
+        if (e >= 4 * 6 * 16 || tile >= ntiles) return;
+        const int ib = tile / tpi, rem_t = tile - ib * tpi;
+        const int tape = ib / p.B, b = ib - tape * p.B;
+        const int gx = rem_t % gxn, oy0 = (rem_t / gxn) * 2;
+        const int c = e / 96, rem = e - c * 96, r = rem >> 4, x4 = rem & 15;
+        const int iy = 2 * oy0 - 1 + r, x0 = gx * 64;
+        if (c >= p.C || iy < 0 || iy >= p.H) return;
+        const size_t o = (((size_t)b * p.C + c) * p.H + iy) * p.W + x0 + x4 * 4;
+        const float* __restrict__ img = p.img[tape];
+        const float* __restrict__ gate = p.gate[tape];
+        sl.v = *reinterpret_cast<const float4*>(img + o);
+        if (x4 == 0 && x0 > 0) sl.lo = img[o - 1];
+        if (x4 == 15 && x0 + 64 < p.W) sl.hi = img[o + 4];
+        if (gate) {
+            const float4 g = *reinterpret_cast<const float4*>(gate + o);
+            sl.v.x *= eg_act_grad_from_out(g.x, p.gate_act, p.gate_slope); sl.v.y *= eg_act_grad_from_out(g.y, p.gate_act, p.gate_slope);
+            sl.v.z *= eg_act_grad_from_out(g.z, p.gate_act, p.gate_slope); sl.v.w *= eg_act_grad_from_out(g.w, p.gate_act, p.gate_slope);
+            if (x4 == 0 && x0 > 0) sl.lo *= eg_act_grad_from_out(gate[o - 1], p.gate_act, p.gate_slope);
+            if (x4 == 15 && x0 + 64 < p.W) sl.hi *= eg_act_grad_from_out(gate[o + 4], p.gate_act, p.gate_slope);
+        }
+    };
+    auto stage = [&](int e, const Slot& sl) {           // 16-bit values into LDS; image column x sits at x + 1
+        if (e >= 4 * 6 * 16) return;
+        const int c = e / 96, rem = e - c * 96, r = rem >> 4, x4 = rem & 15;
+        T h[4];
+        Elt<T>::st(h + 0, sl.v.x); Elt<T>::st(h + 1, sl.v.y); Elt<T>::st(h + 2, sl.v.z); Elt<T>::st(h + 3, sl.v.w);
+        unsigned short* row = &s_in[c][r][0];
+        const unsigned short* hb = reinterpret_cast<const unsigned short*>(h);
+        row[1 + x4 * 4] = hb[0];
+        *reinterpret_cast<unsigned*>(row + 2 + x4 * 4) = (unsigned)hb[1] | ((unsigned)hb[2] << 16);
+        row[4 + x4 * 4] = hb[3];
+        if (x4 == 0) { T t; Elt<T>::st(&t, sl.lo); row[0] = *reinterpret_cast<const unsigned short*>(&t); }
+        if (x4 == 15) { T t; Elt<T>::st(&t, sl.hi); row[65] = *reinterpret_cast<const unsigned short*>(&t); }
+    };
+
+    // this wave inside a tile: output row (wave >> 1), columns 16 * (wave & 1) + frow
+    const int ry = wave >> 1, oxl = (wave & 1) * 16 + frow;
+    // K chunk fq of k half 0: channel fq >> 1, filter rows 2*(fq & 1) and +1, four columns; k half 1: channel 2 + (fq >> 1)
+    const int r0 = 2 * ry + (fq & 1) * 2;
+    auto ld8 = [&](int c, int r) {
+        const unsigned* q = reinterpret_cast<const unsigned*>(&s_in[c][r][2 * oxl]);     // image column 2*ox - 1 + kx sits at 2*ox + kx
+        return make_uint2(q[0], q[1]);
+    };
+    T* __restrict__ out = reinterpret_cast<T*>(p.out);
+
+    Slot s0, s1;
+    int tile = blockIdx.x;
+    fetch(tile, tid, s0); fetch(tile, tid + 256, s1);
+    for (; tile < ntiles; tile += gridDim.x) {
+        stage(tid, s0); stage(tid + 256, s1);
+        __syncthreads();                                 // the tile's image rows are in LDS (and the previous tile's output rows have been read)
+        fetch(tile + gridDim.x, tid, s0); fetch(tile + gridDim.x, tid + 256, s1);      // next tile's loads fly under this tile's work
+        const uint2 a00 = ld8(fq >> 1, r0), a01 = ld8(fq >> 1, r0 + 1);
+        const uint2 a10 = ld8(2 + (fq >> 1), r0), a11 = ld8(2 + (fq >> 1), r0 + 1);
+        const uint4 a0 = make_uint4(a00.x, a00.y, a01.x, a01.y), a1 = make_uint4(a10.x, a10.y, a11.x, a11.y);
+        f32x4 acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mfma_step<T>(a0, bf[0][j], acc[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mfma_step<T>(a1, bf[1][j], acc[j]);
+        // epilogue: acc[j][r] = C[pixel frow][channel j*16 + fq*4 + r]; the arithmetic of the NT kernels' epilogue
+        const int ib = tile / tpi, rem_t = tile - ib * tpi;
+        const int tape = ib / p.B;
+        const int gx = rem_t % gxn, oy0 = (rem_t / gxn) * 2;
+        const float inv_sigma = p.sigma ? 1.f / p.sigma[tape] : 1.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            T h[4];
+            const float4 bv = *reinterpret_cast<const float4*>(&s_bias[j * 16 + fq * 4]);
+            const float bj[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = __fmul_rn(acc[j][r], inv_sigma);
+                if (p.bias) x = __fadd_rn(x, bj[r]);
+                x = af.special ? eg_act(x, p.act, p.slope) : eg_act_apply(x, af);
+                Elt<T>::st(h + r, x);
+            }
+            *reinterpret_cast<uint2*>(&s_out[wave][frow][j * 16 + fq * 4]) = *reinterpret_cast<const uint2*>(h);
+        }
+        __syncthreads();                                 // output rows complete; every wave is done reading the image rows
+        const size_t pix0 = ((size_t)ib * OH + oy0 + ry) * OW + gx * 32 + (wave & 1) * 16;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 4 + (lane >> 4), chunk = lane & 15;
+            const uint4 v = *reinterpret_cast<const uint4*>(&s_out[wave][row][chunk * 8]);
+            *reinterpret_cast<uint4*>(out + (pix0 + row) * N + chunk * 8) = v;
+        }
+    }
+}
+
+extern "C" int eg_conv_img_mfma_ok(int dtype, int C, int H, int W, int N, int k, int stride, int pad) {
+    return dtype != EG_F32 && C >= 1 && C <= 4 && N == 128 && k == 4 && stride == 2 && pad == 1 && H >= 4 && (H % 4) == 0 && (W % 64) == 0;
+}
+
+extern "C" int eg_conv_img_mfma(int dtype, const float* img0, const float* img1, const float* img2, const float* gate0, const float* gate1,
+                                const float* gate2, int ntapes, const void* wp, void* out, int B, int C, int H, int W, const eg_epilogue* ep,
+                                int gate_act, float gate_slope, eg_stream_t s) {
+    EG_REQUIRE(img0 && wp && out && ntapes >= 1 && ntapes <= 3 && B > 0, "eg_conv_img_mfma: bad argument");
+    EG_REQUIRE(eg_conv_img_mfma_ok(dtype, C, H, W, 128, 4, 2, 1), "eg_conv_img_mfma: 16-bit types, C <= 4, H %% 4 == 0, W %% 64 == 0 only (use eg_im2col_img + eg_conv_fwd)");
+    EG_REQUIRE((ntapes < 2 || img1) && (ntapes < 3 || img2), "eg_conv_img_mfma: one image pointer per tape");
+    EG_REQUIRE(!ep || (!ep->mask && ep->out_mode == EG_OUT_NHWC && ep->stat_mode == EG_STAT_NONE && ep->bias_mod == 0), "eg_conv_img_mfma: unsupported epilogue field");
+    ImgMfmaParams p;
+    memset(&p, 0, sizeof(p));
+    p.img[0] = img0; p.img[1] = img1; p.img[2] = img2;
+    p.gate[0] = gate0; p.gate[1] = gate1; p.gate[2] = gate2;
+    p.wp = wp; p.out = out; p.B = B; p.C = C; p.H = H; p.W = W;
+    p.bias = ep ? ep->bias : nullptr;
+    p.sigma = ep ? ep->sigma : nullptr;
+    p.act = ep ? ep->act : EG_ACT_NONE;
+    p.slope = ep ? ep->slope : 0.f;
+    p.gate_act = gate_act; p.gate_slope = gate_slope;
+    const int ntiles = (H / 4) * (W / 64) * B * ntapes;  // 2 output rows x 32 columns each
+    static const int wgs = [] { const char* e = getenv("EG_IMG_CONV_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256 * EG_IMG_CONV_OCC; }();
+    const dim3 grid(ntiles < wgs ? ntiles : wgs);         // persistent: two workgroups per CU (181 registers) walk the tiles with the weight panel in registers
+    if (dtype == EG_F16) hipLaunchKernelGGL(conv_img_mfma_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)s, p, ntiles);
+    else hipLaunchKernelGGL(conv_img_mfma_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, p, ntiles);
+    EG_LAUNCH_CHECK();
+    return 0;
+}

@@ -255,6 +255,18 @@ def im2col_img(dtype, img, out, B, CI, H, W, k, stride, pad, Kp):
     lib().call("eg_im2col_img", dtype, _p(img), _p(out), B, CI, H, W, k, stride, pad, Kp, _stream())
 
 
+def conv_img_mfma_ok(dtype, C, H, W, N, k, stride, pad) -> bool:
+    return bool(lib().query("eg_conv_img_mfma_ok", dtype, C, H, W, N, k, stride, pad))
+
+
+def conv_img_mfma(dtype, imgs, wp, out, B, C, H, W, ep=None, gates=None, gate_act=ACT_NONE, gate_slope=0.0):
+    """Conv2d(C -> 128, 4, 2, 1) of up to three fp32 NCHW image tensors (tapes) straight on the MFMA units, no patch rows in HBM"""
+    im = [_p(t) for t in imgs] + [None] * (3 - len(imgs))
+    ga = [_p(t) for t in (gates or [])] + [None] * (3 - len(gates or []))
+    lib().call("eg_conv_img_mfma", dtype, im[0], im[1], im[2], ga[0], ga[1], ga[2], len(imgs), _p(wp), _p(out), B, C, H, W,
+               ctypes.byref(ep) if ep is not None else None, gate_act, gate_slope, _stream())
+
+
 def cast_pad(dtype, src, dst, rows, n, npad):
     lib().call("eg_cast_pad", dtype, _p(src), _p(dst), rows, n, npad, _stream())
 

@@ -203,6 +203,15 @@ int eg_conv_img_wgrad(int dtype, const void* dz, const float* img, float* slab, 
  * run on the MFMA kernels as 1x1 convolutions over Kp channels */
 int eg_im2col_img(int dtype, const float* img, void* out, int B, int CI, int H, int W, int k, int stride, int pad, int Kp,
                   eg_stream_t s);
+/* the same convolution WITHOUT patch rows in HBM, 16-bit types: Conv2d(C <= 4 -> 128, 4, 2, 1) of up to three fp32 NCHW image tensors
+ * ("tapes": independent forwards batched into one launch, each with its own spectral-norm sigma -- ep->sigma[tape]) straight on the MFMA
+ * units; out [ntapes*B][H/2][W/2][128] dtype T.  wp: the [128][64] panel of eg_pack_strided (K order = master weight order).  gate_t != NULL:
+ * the convolution's input is img_t * act'(gate_t) (the input gradient of the Generator's last ConvTranspose2d + Tanh, celebA.py:90-91: img =
+ * d(loss)/d(image), gate = the image).  ep: bias, sigma, act / slope only.  Bit-identical to eg_im2col_img + eg_conv_fwd on the patch rows. */
+int eg_conv_img_mfma_ok(int dtype, int C, int H, int W, int N, int k, int stride, int pad);
+int eg_conv_img_mfma(int dtype, const float* img0, const float* img1, const float* img2, const float* gate0, const float* gate1,
+                     const float* gate2, int ntapes, const void* wp, void* out, int B, int C, int H, int W, const eg_epilogue* ep,
+                     int gate_act, float gate_slope, eg_stream_t s);
 int eg_cast_pad(int dtype, const float* src, void* dst, int rows, int n, int npad, eg_stream_t s);
 /* col2im of a transposed convolution with C = 1 or 3 output channels (ConvTranspose2d(128 -> 3, 4, 2, 1): celebA/EAD-GAN_celebA.py:90-91; the
  * backward-to-image of Conv2d(3 -> 128, 4, 2, 1): :110).  cols [B*Hin*Win][k*k*C] (dtype T; column t*C + c, t = kh*k + kw) is the output of

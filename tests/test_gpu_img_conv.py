@@ -1,0 +1,87 @@
+"""Image-side convolution without patch rows (eg_conv_img_mfma, csrc/img_conv.hip) against the path it replaces on the step's critical chain,
+eg_im2col_img + eg_conv_fwd over the patch rows: the first Discriminator layer (celebA/EAD-GAN_celebA.py:110, spectral norm per tape, bias,
+LeakyReLU(0.1)) and the input gradient of the Generator's ConvTranspose2d(128 -> 3) + Tanh (:90-91).  Same MFMA operands in the same slots,
+same epilogue arithmetic: bit-identical."""
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+eg = None
+ops = None
+
+
+def setup_module(module):
+    global eg, ops
+    eg = importlib.import_module("ead-gan_amd")
+    ops = eg.ops
+
+
+def _patch_path(dtype, imgs, wp, B, C, S, ep_kw):
+    T = len(imgs)
+    tdt = ops.torch_dtype(dtype)
+    npix = B * (S // 2) ** 2
+    patches = torch.empty(T * npix, 64, device=DEV, dtype=tdt)
+    for t, im in enumerate(imgs):
+        ops.im2col_img(dtype, im, patches[t * npix:(t + 1) * npix], B, C, S, S, 4, 2, 1, 64)
+    c = ops.make_conv(T * B, S // 2, S // 2, 64, 128, 1, 1, 0)
+    out = torch.empty(T * B, S // 2, S // 2, 128, device=DEV, dtype=tdt)
+    ops.conv_fwd(c, dtype, patches, wp, out, ops.epilogue(**ep_kw))
+    return out
+
+
+@pytest.mark.parametrize("dtype", [1, 2])
+@pytest.mark.parametrize("T,B,C", [(1, 8, 3), (3, 5, 3), (2, 4, 1), (1, 128, 3)])
+def test_first_discriminator_layer_without_patch_rows(T, B, C, dtype):
+    S = 64
+    g = torch.Generator().manual_seed(5)
+    imgs = [(torch.rand(B, C, S, S, generator=g) * 2 - 1).to(DEV) for _ in range(T)]
+    w = (torch.randn(128, C, 4, 4, generator=g) * 0.1).to(DEV)
+    bias = torch.randn(128, generator=g).to(DEV) * 0.1
+    sigma = (torch.arange(T, dtype=torch.float32) * 0.4 + 1.1).to(DEV)
+    tdt = ops.torch_dtype(dtype)
+    wp = torch.empty(128 * 64, device=DEV, dtype=tdt)
+    ops.pack_strided(dtype, w, wp, 128, C * 16, 64, 1, C * 16, 0, 1)
+    kw = dict(bias=bias, sigma=sigma, sigma_rows=B * (S // 2) ** 2, act=ops.ACT_LRELU, slope=0.1)
+    want = _patch_path(dtype, imgs, wp, B, C, S, kw)
+    assert ops.conv_img_mfma_ok(dtype, C, S, S, 128, 4, 2, 1)
+    got = torch.empty_like(want)
+    ops.conv_img_mfma(dtype, imgs, wp, got, B, C, S, S, ops.epilogue(**kw))
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    # and against torch on the rounded operands
+    rq = lambda x: x.to(tdt).float()
+    for t in range(T):
+        ref = F.leaky_relu(F.conv2d(rq(imgs[t]), rq(w), None, 2, 1) / sigma[t] + bias[None, :, None, None], 0.1).permute(0, 2, 3, 1)
+        torch.testing.assert_close(got[t * B:(t + 1) * B].float(), ref, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [1, 2])
+def test_generator_last_layer_input_gradient_without_patch_rows(dtype):
+    """d(loss)/d(a) of ConvTranspose2d(128 -> 3, 4, 2, 1) + Tanh == Conv2d(3 -> 128, 4, 2, 1) of dimg * (1 - img^2) with the layer's weights"""
+    B, C, S = 16, 3, 64
+    g = torch.Generator().manual_seed(6)
+    dimg = torch.randn(B, C, S, S, generator=g).to(DEV)
+    img = torch.tanh(torch.randn(B, C, S, S, generator=g)).to(DEV)
+    w = (torch.randn(128, C, 4, 4, generator=g) * 0.1).to(DEV)      # ConvTranspose2d master [in = 128][out = C][4][4]
+    tdt = ops.torch_dtype(dtype)
+    wp = torch.empty(128 * 64, device=DEV, dtype=tdt)
+    ops.pack_strided(dtype, w, wp, 128, C * 16, 64, 1, C * 16, 0, 1)
+    dz = torch.empty_like(dimg)
+    part = torch.empty(B * C, device=DEV)
+    gb = torch.zeros(C, device=DEV)
+    ops.act_grad_mul_bias_nchw(dimg, img, dz, B, C, S * S, ops.ACT_TANH, 0.0, part, gb)
+    want = _patch_path(dtype, [dz], wp, B, C, S, {})
+    got = torch.empty_like(want)
+    ops.conv_img_mfma(dtype, [dimg], wp, got, B, C, S, S, None, gates=[img], gate_act=ops.ACT_TANH)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+
+
+def test_other_shapes_are_refused():
+    assert not ops.conv_img_mfma_ok(0, 3, 64, 64, 128, 4, 2, 1)          # fp32
+    assert not ops.conv_img_mfma_ok(1, 3, 32, 32, 128, 4, 2, 1)          # 32-pixel rows
+    assert not ops.conv_img_mfma_ok(1, 3, 64, 64, 64, 4, 2, 1)           # 64 output channels
