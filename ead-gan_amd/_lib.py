@@ -44,6 +44,11 @@ class EgSnLayer(ctypes.Structure):
                 ("u_snap", ctypes.c_void_p), ("v_snap", ctypes.c_void_p), ("R", ctypes.c_int), ("Kd", ctypes.c_int)]
 
 
+class EgRngSeg(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int), ("out", ctypes.c_void_p), ("n", ctypes.c_size_t), ("a", ctypes.c_float), ("b", ctypes.c_float),
+                ("stream_id", ctypes.c_uint), ("onehot", ctypes.c_void_p), ("onehot_n", ctypes.c_int)]
+
+
 _SCALARS = {"int": ctypes.c_int, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
             "long long": ctypes.c_longlong, "unsigned long long": ctypes.c_ulonglong, "unsigned int": ctypes.c_uint,
             "eg_stream_t": ctypes.c_void_p}

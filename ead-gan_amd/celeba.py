@@ -29,6 +29,9 @@ opt = argparse.Namespace(n_epochs=50, batch_size=16, lr=0.0002, b1=0.5, b2=0.999
 # image-side transposed convolutions (128 -> C) as one GEMM + col2im gather (1) or as the 4-phase implicit GEMM (0)
 IMG_GEMM = os.environ.get("EG_IMG_GEMM", "1") == "1"
 
+# the iteration's head (device-side draws, gather, affine matrix + warp) as 3 launches instead of 11 (same values)
+FUSE_INPUTS = os.environ.get("EG_FUSE_INPUTS", "1") != "0"
+
 # image-side convolutions (first D layer forward, input gradient of G's last layer) straight from the fp32 images on the MFMA units
 # (ops.conv_img_mfma) instead of patch rows in HBM + a K = 64 GEMM; the patch rows remain for the weight gradients, off the main chain
 IMG_DIRECT = os.environ.get("EG_IMG_DIRECT", "1") != "0"
@@ -875,6 +878,15 @@ class DeviceInputs:
         if self.idx is None or self.idx.numel() != B:
             self.idx = torch.empty(B, device=self.data.device, dtype=torch.int64)
             self.flips = torch.empty(B, device=self.data.device, dtype=torch.uint8)
+        if FUSE_INPUTS:
+            # the five draws + the one-hot labels as one launch, the counter tick inside the gather: 3 launches instead of 8 at the head of
+            # the iteration's critical chain (the same values: a draw depends on (element, step, stream id, seed) only)
+            ops.rng_fill_multi([(ops.RNG_RANDINT, self.idx, 0, N, 1),                       # shuffle-with-replacement sampling
+                                (ops.RNG_BERNOULLI, self.flips, 0.5, 0.0, 2),               # RandomHorizontalFlip(p=0.5)
+                                (ops.RNG_NORMAL, tr.z, 0.0, 1.0, 3), (ops.RNG_UNIFORM, tr.code, -1.0, 1.0, 4),
+                                (ops.RNG_RANDINT, tr.labels, 0, tr.G.n_classes, 5, tr.onehot)], self.seed, self.step)
+            ops.gather_u8_images(self.data, self.idx, self.flips if self.flip else None, tr.real, B, C, H, W, 2.0 / 255.0, -1.0, tick=self.step)   # ToTensor + Normalize(.5,.5)
+            return
         ops.rng_fill(ops.RNG_RANDINT, self.idx, 0, N, self.seed, self.step, 1)             # shuffle-with-replacement sampling
         ops.rng_fill(ops.RNG_BERNOULLI, self.flips, 0.5, 0.0, self.seed, self.step, 2)     # RandomHorizontalFlip(p=0.5)
         ops.gather_u8_images(self.data, self.idx, self.flips if self.flip else None, tr.real, B, C, H, W, 2.0 / 255.0, -1.0)   # ToTensor + Normalize(.5,.5)
@@ -985,8 +997,11 @@ class CelebATrainer:
 
     def _inputs_head(self):
         G, B = self.G, self.B
-        ops.fill_f32(self.losses)
         # A = get_matrix(code[:, :5]); scaled = trans_2D(real, A[:, 0:2])           (:325-327)
+        if FUSE_INPUTS and (G.img_size * G.img_size) % 256 == 0:
+            ops.warp_affine_rpqxy(self.real, self.code, G.code_dim, self.theta, self.scaled, B, G.channels, G.img_size, G.img_size, zero=self.losses)
+            return
+        ops.fill_f32(self.losses)
         ops.theta_rpqxy(self.code, G.code_dim, B, self.theta)
         ops.warp_affine(self.real, self.theta, self.scaled, B, G.channels, G.img_size, G.img_size)
 

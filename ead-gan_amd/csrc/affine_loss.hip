@@ -64,6 +64,60 @@ extern "C" int eg_warp_affine(const float* img, const float* theta, float* out, 
     return 0;
 }
 
+// theta_rpqxy + warp in one launch (the head of the CelebA iteration: A = get_matrix(code[:, :5]); scaled = trans_2D(real, A[:, 0:2]),
+// celebA/EAD-GAN_celebA.py:325-327): a block's 256 pixels lie in one image (H * W a multiple of 256), its first thread forms that image's
+// matrix -- the function theta_rpqxy_kernel calls -- and the rest is warp_affine_kernel<false>'s arithmetic; `zero` (optional): zero_n floats
+// cleared by the launch's first thread (the iteration's loss accumulators)
+__global__ __launch_bounds__(256) void warp_affine_rpqxy_kernel(const float* __restrict__ img, const float* __restrict__ code, int ldc,
+                                                                float* __restrict__ theta_out, float* __restrict__ out, int B, int C, int H, int W,
+                                                                float* zero, int zero_n) {
+    __shared__ float th[6];
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = (int)(idx / ((size_t)W * H));
+    if (blockIdx.x == 0 && threadIdx.x == 0 && zero)
+        for (int i = 0; i < zero_n; ++i) zero[i] = 0.f;
+    if (threadIdx.x == 0) {
+        float c[5];
+        for (int i = 0; i < 5; ++i) c[i] = code[(size_t)b * ldc + i];
+        const Aff<float> m = matrix_rpqxy<float>(c);
+        th[0] = m.a; th[1] = m.b; th[2] = m.c; th[3] = m.d; th[4] = m.e; th[5] = m.f;
+        if (theta_out && (idx % ((size_t)W * H)) == 0) {
+            float* t = theta_out + (size_t)b * 6;
+            t[0] = m.a; t[1] = m.b; t[2] = m.c; t[3] = m.d; t[4] = m.e; t[5] = m.f;
+        }
+    }
+    __syncthreads();
+    const int x = (int)(idx % W), y = (int)((idx / W) % H);
+    const float xn = (2.f * x + 1.f) / W - 1.f, yn = (2.f * y + 1.f) / H - 1.f;
+    const float gx = th[0] * xn + th[1] * yn + th[2];
+    const float gy = th[3] * xn + th[4] * yn + th[5];
+    float ix = ((gx + 1.f) * W - 1.f) * 0.5f, iy = ((gy + 1.f) * H - 1.f) * 0.5f;
+    ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
+    iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - fx, wx0 = 1.f - wx1, wy1 = iy - fy, wy0 = 1.f - wy1;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+    for (int c = 0; c < C; ++c) {
+        const float* p = img + ((size_t)b * C + c) * H * W;
+        float v = 0.f;
+        if (vx0 && vy0) v += p[y0 * W + x0] * (wx0 * wy0);
+        if (vx1 && vy0) v += p[y0 * W + x1] * (wx1 * wy0);
+        if (vx0 && vy1) v += p[y1 * W + x0] * (wx0 * wy1);
+        if (vx1 && vy1) v += p[y1 * W + x1] * (wx1 * wy1);
+        out[((size_t)b * C + c) * H * W + (size_t)y * W + x] = v;
+    }
+}
+
+extern "C" int eg_warp_affine_rpqxy(const float* img, const float* code, int ldc, float* theta_out, float* out, int B, int C, int H, int W,
+                                    float* zero, int zero_n, eg_stream_t s) {
+    EG_REQUIRE(img && code && out && ldc >= 5 && B > 0 && ((size_t)H * W) % 256 == 0 && zero_n >= 0 && zero_n <= 64, "eg_warp_affine_rpqxy: bad argument (H * W must be a multiple of 256)");
+    const size_t total = (size_t)B * H * W;
+    hipLaunchKernelGGL(warp_affine_rpqxy_kernel, dim3((unsigned)(total / 256)), dim3(256), 0, (hipStream_t)s, img, code, ldc, theta_out, out, B, C, H, W, zero, zero_n);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int eg_warp_affine_zeros(const float* img, const float* theta, float* out, int B, int C, int H, int W, eg_stream_t s) {
     EG_REQUIRE(img && theta && out, "eg_warp_affine_zeros: null pointer");
     const size_t total = (size_t)B * H * W;

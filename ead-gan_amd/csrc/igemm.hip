@@ -1864,7 +1864,43 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     if (MODE == 2)
         for (int q = 0; q < ntapes; ++q) un[q] = coef[q] * u[(size_t)q * N + n];
     const int crow = c_row ? c_row : C;                 // row length of the destination (<= C when the slab is column padded)
-    if (cw == EG_RC && c0 + EG_RC <= crow && (C & 3) == 0) {
+    const int nv = T * (EG_RC / 4);                     // float4 elements of a full tile
+    if (cw == EG_RC && c0 + EG_RC <= crow && (C & 3) == 0 && nv <= 64 && nsplit >= 16) {
+        // few taps, many splits (the image-side layers as 1x1 convolutions: T = 1, 128 splits): the tile has only nv <= 64 vectors, so the
+        // loop below would leave most of the block idle behind a chain of nsplit loads per thread.  Here 256 / nv thread groups each take
+        // every (256 / nv)-th split, eight loads in flight, and the groups are added in group order through LDS (deterministic).
+        __shared__ float4 part[256];
+        const int G = 256 / nv, e4 = threadIdx.x % nv, sg = threadIdx.x / nv;
+        const int t = e4 / (EG_RC / 4), c = (e4 % (EG_RC / 4)) * 4;
+        const size_t si = ((size_t)n * T + t) * C + c0 + c;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (sg < G) {
+            int z = sg;
+            for (; z + 7 * G < nsplit; z += 8 * G) {
+                float4 x[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[q] = *reinterpret_cast<const float4*>(slab + (size_t)(z + q * G) * split_stride + si);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { a.x += x[q].x; a.y += x[q].y; a.z += x[q].z; a.w += x[q].w; }
+            }
+            for (; z < nsplit; z += G) {
+                const float4 x = *reinterpret_cast<const float4*>(slab + (size_t)z * split_stride + si);
+                a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
+            }
+        }
+        part[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x < nv) {
+            a = part[threadIdx.x];
+            for (int gq = 1; gq < G; ++gq) { const float4 x = part[gq * nv + threadIdx.x]; a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w; }
+            if (MODE == 2)
+                for (int q = 0; q < ntapes; ++q) {
+                    const float* vq = v + (size_t)q * crow * T + (size_t)(c0 + c) * T + t;
+                    a.x -= un[q] * vq[0]; a.y -= un[q] * vq[T]; a.z -= un[q] * vq[2 * T]; a.w -= un[q] * vq[3 * T];
+                }
+            tile[c * (T + 1) + t] = a.x; tile[(c + 1) * (T + 1) + t] = a.y; tile[(c + 2) * (T + 1) + t] = a.z; tile[(c + 3) * (T + 1) + t] = a.w;
+        }
+    } else if (cw == EG_RC && c0 + EG_RC <= crow && (C & 3) == 0) {
         // full 64-channel block: 16-byte loads along the channels (one float4 per thread and slab for k = 4), same summation order
         for (int e4 = threadIdx.x; e4 < T * (EG_RC / 4); e4 += 256) {
             const int t = e4 / (EG_RC / 4), c = (e4 % (EG_RC / 4)) * 4;

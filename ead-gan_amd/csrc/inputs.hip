@@ -5,6 +5,8 @@
 // (element, DEVICE step counter), so that a captured hipGraph draws fresh, reproducible inputs on every replay with no host work.
 // These are new draws with the reference's DISTRIBUTIONS (numpy's Mersenne-Twister stream cannot be reproduced on the device; parity
 // tests keep feeding the host draws through load_inputs).
+#include <algorithm>
+
 #include "eg_common.h"
 
 struct Philox {
@@ -26,12 +28,12 @@ struct Philox {
 
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0,1), 24 bits
 
-// kind 0: uniform [a, b) fp32; 1: normal(mean a, std b) fp32 (Box-Muller); 2: integers in [a, b) as int64; 3: Bernoulli(a) as uint8
-__global__ void rng_fill_kernel(int kind, void* __restrict__ out, size_t n, float a, float b, uint64_t seed, const int* __restrict__ step,
-                                uint32_t stream_id) {
-    const Philox ph{(uint32_t)seed, (uint32_t)(seed >> 32)};
-    const uint32_t st = step ? (uint32_t)step[0] : 0u;
-    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q * 4 < n; q += (size_t)gridDim.x * blockDim.x) {
+// kind 0: uniform [a, b) fp32; 1: normal(mean a, std b) fp32 (Box-Muller); 2: integers in [a, b) as int64; 3: Bernoulli(a) as uint8.
+// Quad q of a draw depends on (q, step, stream id, seed) only -- not on the launch shape -- so one launch over several draws
+// (rng_fill_multi_kernel) writes the very values the single launches write.  onehot (kind 2): out row i also sets onehot[i][0..onehot_n).
+__device__ __forceinline__ void rng_fill_quads(int kind, void* __restrict__ out, size_t n, float a, float b, const Philox& ph, uint32_t st,
+                                               uint32_t stream_id, size_t q0, size_t qstride, float* __restrict__ onehot, int onehot_n) {
+    for (size_t q = q0; q * 4 < n; q += qstride) {
         uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), st, stream_id};
         ph(c);
         float v[4];
@@ -60,9 +62,45 @@ __global__ void rng_fill_kernel(int kind, void* __restrict__ out, size_t n, floa
                 long long k = (long long)a + (long long)(v[e] * (b - a));
                 if (k >= (long long)b) k = (long long)b - 1;
                 reinterpret_cast<long long*>(out)[i] = k;
+                if (onehot)
+                    for (int j = 0; j < onehot_n; ++j) onehot[i * onehot_n + j] = k == j ? 1.f : 0.f;
             } else reinterpret_cast<unsigned char*>(out)[i] = v[e] < a ? 1 : 0;
         }
     }
+}
+
+__global__ void rng_fill_kernel(int kind, void* __restrict__ out, size_t n, float a, float b, uint64_t seed, const int* __restrict__ step,
+                                uint32_t stream_id) {
+    const Philox ph{(uint32_t)seed, (uint32_t)(seed >> 32)};
+    const uint32_t st = step ? (uint32_t)step[0] : 0u;
+    rng_fill_quads(kind, out, n, a, b, ph, st, stream_id, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x, nullptr, 0);
+}
+
+// several draws of one iteration in ONE launch (blockIdx.y = draw): the five draws + the one-hot labels of the CelebA loop were six
+// launches of ~4.5 us each at the head of every iteration's critical chain
+struct RngSegs { eg_rng_seg s[8]; };
+__global__ void rng_fill_multi_kernel(const RngSegs segs, uint64_t seed, const int* __restrict__ step) {
+    const Philox ph{(uint32_t)seed, (uint32_t)(seed >> 32)};
+    const uint32_t st = step ? (uint32_t)step[0] : 0u;
+    const eg_rng_seg& g = segs.s[blockIdx.y];
+    rng_fill_quads(g.kind, g.out, g.n, g.a, g.b, ph, st, g.stream_id, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x,
+                   g.onehot, g.onehot_n);
+}
+
+extern "C" int eg_rng_fill_multi(const eg_rng_seg* segs, int nseg, unsigned long long seed, const int* step, eg_stream_t s) {
+    EG_REQUIRE(segs && nseg >= 1 && nseg <= 8, "eg_rng_fill_multi: 1..8 draws");
+    RngSegs p;
+    memset(&p, 0, sizeof(p));
+    size_t maxq = 1;
+    for (int i = 0; i < nseg; ++i) {
+        EG_REQUIRE(segs[i].out && segs[i].kind >= 0 && segs[i].kind <= 3 && (!segs[i].onehot || (segs[i].kind == 2 && segs[i].onehot_n > 0)), "eg_rng_fill_multi: bad draw %d", i);
+        p.s[i] = segs[i];
+        maxq = std::max(maxq, (segs[i].n + 3) / 4);
+    }
+    const int blocks = (int)((maxq + 255) / 256 > 256 ? 256 : (maxq + 255) / 256);
+    hipLaunchKernelGGL(rng_fill_multi_kernel, dim3(blocks, nseg), dim3(256), 0, (hipStream_t)s, p, (uint64_t)seed, step);
+    EG_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int eg_rng_fill(int kind, void* out, size_t n, float a, float b, unsigned long long seed, const int* step, unsigned int stream_id,
@@ -88,7 +126,8 @@ extern "C" int eg_counter_add(int* counter, int v, eg_stream_t s) {
 
 // out[b][c][y][x] = data[idx[b]][c][y][flip[b] ? W-1-x : x] * scale + shift   (uint8 NCHW dataset resident in HBM -> fp32 NCHW batch)
 __global__ void gather_u8_images_kernel(const unsigned char* __restrict__ data, const long long* __restrict__ idx, const unsigned char* __restrict__ flip,
-                                        float* __restrict__ out, int B, int CH, int W, float scale, float shift) {
+                                        float* __restrict__ out, int B, int CH, int W, float scale, float shift, int* tick) {
+    if (tick && blockIdx.x == 0 && threadIdx.x == 0) tick[0] += 1;      // the draws of this iteration (earlier launches) have read the counter
     const size_t per = (size_t)CH * W;               // CH = C*H rows of W pixels per image
     const size_t total = (size_t)B * per;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -106,7 +145,17 @@ extern "C" int eg_gather_u8_images(const unsigned char* data, const long long* i
     EG_REQUIRE(data && idx && out && B > 0 && C > 0 && H > 0 && W > 0, "eg_gather_u8_images: bad argument");
     const size_t total = (size_t)B * C * H * W;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    hipLaunchKernelGGL(gather_u8_images_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, data, idx, flip, out, B, C * H, W, scale, shift);
+    hipLaunchKernelGGL(gather_u8_images_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, data, idx, flip, out, B, C * H, W, scale, shift, (int*)nullptr);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int eg_gather_u8_images_tick(const unsigned char* data, const long long* idx, const unsigned char* flip, float* out, int B, int C, int H,
+                                        int W, float scale, float shift, int* step_tick, eg_stream_t s) {
+    EG_REQUIRE(data && idx && out && B > 0 && C > 0 && H > 0 && W > 0, "eg_gather_u8_images_tick: bad argument");
+    const size_t total = (size_t)B * C * H * W;
+    const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(gather_u8_images_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, data, idx, flip, out, B, C * H, W, scale, shift, step_tick);
     EG_LAUNCH_CHECK();
     return 0;
 }

@@ -12,7 +12,7 @@ import torch
 
 from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, EG_BF16, EG_F16, EG_F32, NT_AUTO, NT_BUF128,
                    NT_PERS, NT_REG, NT_S8, NT_S8P, OUT_NCHW_F32, OUT_NHWC, STAT_BN_BWD, STAT_MOMENTS, STAT_NONE, STAT_SN_BIAS, EgConv, EgEpilogue,
-                   EgSnLayer, lib)
+                   EgRngSeg, EgSnLayer, lib)
 
 __all__ = ["EG_F32", "EG_BF16", "EG_F16", "ACT_NONE", "ACT_LRELU", "ACT_RELU", "ACT_TANH", "ACT_SIGMOID", "OUT_NHWC",
            "OUT_NCHW_F32"]
@@ -458,6 +458,11 @@ def warp_affine(img, theta, out, B, C, H, W):
     lib().call("eg_warp_affine", _p(img), _p(theta), _p(out), B, C, H, W, _stream())
 
 
+def warp_affine_rpqxy(img, code, ldc, theta_out, out, B, C, H, W, zero=None):
+    """theta_rpqxy + warp_affine in one launch; ``zero``: a small fp32 tensor the launch clears first"""
+    lib().call("eg_warp_affine_rpqxy", _p(img), _p(code), ldc, _p(theta_out), _p(out), B, C, H, W, _p(zero), zero.numel() if zero is not None else 0, _stream())
+
+
 def mlp_rpqmnxy_floats():
     return lib().query("eg_mlp_rpqmnxy_floats")
 
@@ -538,12 +543,26 @@ def rng_fill(kind, out, a, b, seed, step, stream_id):
     lib().call("eg_rng_fill", kind, _p(out), out.numel(), float(a), float(b), int(seed), _p(step), int(stream_id), _stream())
 
 
+def rng_fill_multi(draws, seed, step):
+    """several draws in ONE launch, the values of one rng_fill each: draws = [(kind, out, a, b, stream_id[, onehot tensor])]"""
+    arr = (EgRngSeg * len(draws))()
+    for i, d in enumerate(draws):
+        kind, out, a, b, sid = d[:5]
+        oh = d[5] if len(d) > 5 else None
+        arr[i] = EgRngSeg(kind, _p(out), out.numel(), float(a), float(b), int(sid), _p(oh), oh.shape[1] if oh is not None else 0)
+    lib().call("eg_rng_fill_multi", arr, len(draws), int(seed), _p(step), _stream())
+
+
 def counter_add(counter, v=1):
     lib().call("eg_counter_add", _p(counter), int(v), _stream())
 
 
-def gather_u8_images(data, idx, flip, out, B, C, H, W, scale, shift):
-    lib().call("eg_gather_u8_images", _p(data), _p(idx), _p(flip), _p(out), B, C, H, W, float(scale), float(shift), _stream())
+def gather_u8_images(data, idx, flip, out, B, C, H, W, scale, shift, tick=None):
+    """``tick``: device step counter incremented by this launch (the iteration's draws, earlier on the stream, have read it)"""
+    if tick is None:
+        lib().call("eg_gather_u8_images", _p(data), _p(idx), _p(flip), _p(out), B, C, H, W, float(scale), float(shift), _stream())
+    else:
+        lib().call("eg_gather_u8_images_tick", _p(data), _p(idx), _p(flip), _p(out), B, C, H, W, float(scale), float(shift), _p(tick), _stream())
 
 
 def resample_u8(src, dst, planes, in_h, in_w, axis, bounds, kk, ksize, o0, on, c0, cn):

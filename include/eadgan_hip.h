@@ -352,6 +352,10 @@ int eg_nhwc_to_nchw(int dtype, const void* x, float* y, int B, int C, int HW, in
  * celebA/EAD-GAN_celebA.py:146-152 ;  losses : celebA/EAD-GAN_celebA.py:161-169,342,355-362,383-395 */
 int eg_theta_rpqxy(const float* code, int ldc, int B, float* theta, eg_stream_t s);
 int eg_warp_affine(const float* img, const float* theta, float* out, int B, int C, int H, int W, eg_stream_t s);
+/* eg_theta_rpqxy + eg_warp_affine in one launch (same arithmetic; H * W a multiple of 256); theta_out optional; zero / zero_n: floats the
+ * launch clears first (the iteration's loss accumulators) */
+int eg_warp_affine_rpqxy(const float* img, const float* code, int ldc, float* theta_out, float* out, int B, int C, int H, int W,
+                         float* zero, int zero_n, eg_stream_t s);
 int eg_loss_bce_sigmoid(const float* o, int ld, int col, int B, float target, float scale, float* loss, float* dout,
                         int zero_rows, eg_stream_t s);
 int eg_loss_mse(const float* o, int ld, int col0, int n, int B, const float* tgt, int ldt, float tconst, float scale,
@@ -426,10 +430,25 @@ int eg_quantize_u8(const float* x, int C, int H, int W, const float* range, unsi
  * kind 0: uniform [a,b) fp32; 1: normal(a, b) fp32; 2: integers in [a,b) as int64; 3: Bernoulli(a) as uint8 */
 int eg_rng_fill(int kind, void* out, size_t n, float a, float b, unsigned long long seed, const int* step, unsigned int stream_id,
                 eg_stream_t s);
+/* several draws in ONE launch (the same values as one eg_rng_fill per draw).  onehot != NULL (kind 2 only): row i of onehot[n][onehot_n] is
+ * the one-hot code of draw i (to_categorical fused). */
+typedef struct eg_rng_seg {
+    int kind;
+    void* out;
+    size_t n;
+    float a, b;
+    unsigned int stream_id;
+    float* onehot;
+    int onehot_n;
+} eg_rng_seg;
+int eg_rng_fill_multi(const eg_rng_seg* segs, int nseg, unsigned long long seed, const int* step, eg_stream_t s);
 int eg_counter_add(int* counter, int v, eg_stream_t s);
 /* out[b] = data[idx[b]] (uint8 NCHW dataset in HBM), mirrored along x where flip[b], * scale + shift  -> fp32 NCHW */
 int eg_gather_u8_images(const unsigned char* data, const long long* idx, const unsigned char* flip, float* out, int B, int C, int H,
                         int W, float scale, float shift, eg_stream_t s);
+/* the same, and step_tick[0] += 1 afterwards (NULL: no tick): the iteration's draws -- earlier launches on the stream -- have read the counter */
+int eg_gather_u8_images_tick(const unsigned char* data, const long long* idx, const unsigned char* flip, float* out, int B, int C, int H,
+                             int W, float scale, float shift, int* step_tick, eg_stream_t s);
 int eg_onehot(const long long* labels, float* out, int B, int n, eg_stream_t s);          /* to_categorical (celebA.py:59-64) */
 /* transforms.Resize (PIL bilinear, antialiased) + CenterCrop of the uint8 dataset on its way into HBM (celebA.py:194-196): ONE separable
  * pass along y (axis 0) or x (axis 1) of `planes` planar uint8 images [in_h][in_w] with PIL's 8-bit fixed-point coefficient tables

@@ -100,6 +100,34 @@ def test_trainer_feeds_itself_from_the_captured_graph():
     assert all(torch.equal(a, b) for a, b in zip(runs[0][1], runs[1][1]))
 
 
+def test_fused_iteration_head_draws_the_same_batches(monkeypatch):
+    """The head of the CelebA iteration as 3 launches (all draws + one-hot in one, counter tick inside the gather, affine matrix + warp + loss
+    clearing in one) against the 11 separate launches: identical real / z / code / labels / one-hot / theta / warped batch and losses."""
+    B = 8
+    data = (co.synthetic_real(64, seed=9) * 127.5 + 127.5).clamp(0, 255).to(torch.uint8).to(DEV)
+    runs = []
+    for fuse in (False, True):
+        monkeypatch.setattr(eg.celeba, "FUSE_INPUTS", fuse)
+        orc = co.CelebAOracle(seed=2)
+        G = eg.celeba.Generator(dtype="bf16").to(DEV)
+        D = eg.celeba.Discriminator(dtype="bf16").to(DEV)
+        G.load_state_dict({k: v.detach() for k, v in orc.G.items()})
+        D.load_state_dict({k: v.detach() for k, v in orc.D.items()})
+        tr = eg.celeba.CelebATrainer(G, D, B, dtype="bf16")
+        inp = eg.celeba.DeviceInputs(data, seed=5)
+        tr.inputs = inp
+        seen = []
+        for i in range(3):
+            loss = tr.step_resident().clone()
+            seen.append([t.clone() for t in (tr.real, tr.z, tr.code, tr.labels, tr.onehot, tr.theta, tr.scaled, loss)])
+        torch.cuda.synchronize()
+        assert int(inp.step.item()) == 3
+        runs.append(seen)
+    for a, b in zip(runs[0], runs[1]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
 def _run_small(family, capture, steps=4, B=8):
     """one of the small-network trainers feeding itself from a DeviceInputs; returns (losses per step, label draws, sampler, trainer)"""
     torch.manual_seed(0)
