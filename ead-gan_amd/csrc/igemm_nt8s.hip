@@ -503,10 +503,10 @@ __global__ __launch_bounds__(512) void igemm_nt8s_kernel(const NtParams p, const
         __syncthreads();                               // the flag word is read; the epilogue stages through the same LDS
     }
     if constexpr (STAT) {
-        // column statistics of the stored tile (eg_epilogue.stat_mode); masks are not prefetched here (32 registers the sums need)
-        NtEpiPre<T, TM, TN, 0> epi0;
-        nt_epi_prefetch<T, BM, 128, TM, TN, 512, 0>(epi0, p, ph, m0, n0, wm * TM * 16, wn * 64, tid, frow, fq);
-        nt_epilogue_lds_stat<T, BM, 128, TM, TN, 512, 0>(epi0, p, ph, acc, smem, m0, n0, wm * TM * 16, wn * 64, tid, frow, fq, phase * tiles_m + m_tile,
+        // column statistics of the stored tile (eg_epilogue.stat_mode)
+        NtEpiPre<T, TM, TN, 8> epi0;
+        nt_epi_prefetch<T, BM, 128, TM, TN, 512, 8>(epi0, p, ph, m0, n0, wm * TM * 16, wn * 64, tid, frow, fq);
+        nt_epilogue_lds_stat<T, BM, 128, TM, TN, 512, 8>(epi0, p, ph, acc, smem, m0, n0, wm * TM * 16, wn * 64, tid, frow, fq, phase * tiles_m + m_tile,
                                                          n_tile, tiles_n);
         return;
     }

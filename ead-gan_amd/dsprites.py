@@ -649,6 +649,15 @@ class DspritesTrainer(ResidentStep):
     def _adam(self, arena, m, v, lr, slot, tick):
         ops.adam_step(arena.flat, arena.grad, m, v, arena.numel, lr, self.betas[0], self.betas[1], 1e-8, self.steps[slot:slot + 1], tick)
 
+    def import_adam_state(self, opt_D, opt_info):
+        """moments and step counts of the two ``torch.optim.Adam`` the reference steps (dSprites/rp.py:270-279: D | G + E parameters,
+        ``.parameters()`` order) -- teacher-forced comparisons against the oracle"""
+        from .engine import import_adam_moments
+        n = lambda mod: len(list(mod.parameters()))
+        s0 = import_adam_moments(opt_D, [(n(self.D), self.mD, self.vD)])
+        s1 = import_adam_moments(opt_info, [(n(self.G), self.miG, self.viG), (n(self.E), self.miE, self.viE)])
+        self.steps.copy_(torch.tensor([s0, s1], dtype=torch.int32))
+
     def _step_body(self):
         """One iteration as TWO chains.  These networks are small (0.5 GFLOP per image): the step is a chain of ~200 launches of a few
         microseconds each, bound by launch latency, not by the chip -- so independent parts run side by side:

@@ -484,3 +484,26 @@ class ConvRec:
     def pack(self, w_master):
         if self.wp_fwd is not None or self.wp_bwd is not None:
             ops.pack_conv(self.c, self.dtype, w_master, self.wp_fwd, self.wp_bwd)
+
+
+def import_adam_moments(opt, arenas):
+    """exp_avg / exp_avg_sq of a ``torch.optim.Adam`` built over the parameters of one or more modules in ``.parameters()`` order (the
+    reference's optimizers: celebA/EAD-GAN_celebA.py:211-217, MNIST/EAD-GAN_rpqmnxy.py:206-217, dSprites/rp.py:270-279) into the flat
+    moment tensors of a fused trainer.  ``arenas``: [(number of parameters of the module, m, v)] in the optimizer's parameter order.
+    Returns the optimizer's step count (0 if it has not stepped yet)."""
+    params = opt.param_groups[0]["params"]
+    step, i = 0, 0
+    for count, m, v in arenas:
+        off = 0
+        for p in params[i:i + count]:
+            st = opt.state.get(p, {})
+            n = p.numel()
+            if st:
+                m[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                step = int(st["step"])
+            off += n
+        assert off == m.numel(), "optimizer parameters do not tile the arena"
+        i += count
+    assert i == len(params)
+    return step

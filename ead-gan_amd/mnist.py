@@ -480,6 +480,16 @@ class MnistTrainer(ResidentStep):
     def _adam(self, arena, m, v, lr, slot, tick):
         ops.adam_step(arena.flat, arena.grad, m, v, arena.numel, lr, self.betas[0], self.betas[1], 1e-8, self.steps[slot:slot + 1], tick)
 
+    def import_adam_state(self, opt_G, opt_D, opt_info):
+        """moments and step counts of three ``torch.optim.Adam`` built like the reference's (MNIST/EAD-GAN_rpqmnxy.py:206-217: G | D | G + E
+        parameters, ``.parameters()`` order) -- teacher-forced comparisons against the oracle"""
+        from .engine import import_adam_moments
+        n = lambda mod: len(list(mod.parameters()))
+        s0 = import_adam_moments(opt_G, [(n(self.G), self.mG, self.vG)])
+        s1 = import_adam_moments(opt_D, [(n(self.D), self.mD, self.vD)])
+        s2 = import_adam_moments(opt_info, [(n(self.G), self.miG, self.viG), (n(self.E), self.miE, self.viE)])
+        self.steps.copy_(torch.tensor([s0, s1, s2], dtype=torch.int32))
+
     def _step_body(self):
         G, D, E, ge, de, ee, B = self.G, self.D, self.E, self.ge, self.de, self.ee, self.B
         ga, da, ea = G.arena, D.arena, E.arena

@@ -265,10 +265,11 @@ def teacher_forced_curve(steps, B=4, seed=11, progress=None):
     return dev
 
 
-def test_teacher_forced_loss_curve_200_steps_fp32():
-    """200 consecutive iterations, each from the oracle's state: every g / d / info loss within 1e-3 of the oracle's
-    (profiles/scripts/teacher_forced_curve.py runs the same function for 1000 iterations; its table is committed under profiles/)."""
-    dev = teacher_forced_curve(200)
+def test_teacher_forced_loss_curve_100_steps_fp32():
+    """100 consecutive iterations, each from the oracle's state: every g / d / info loss within 1e-3 of the oracle's
+    (profiles/scripts/teacher_forced_curve.py runs the same function for 1000 iterations; its table is committed under profiles/;
+    the MNIST / dSprites / colored-dSprites loops have the same test in their files)."""
+    dev = teacher_forced_curve(100)
     assert dev.max() < 1e-3, (dev.max(axis=0), np.argmax(dev, axis=0))
     assert np.median(dev[:, :2]) < 5e-5          # g / d losses are functions of the synchronised state alone
 

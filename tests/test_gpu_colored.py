@@ -107,3 +107,11 @@ def test_train_step_fp16_tracks_oracle():
     for i in range(2):
         for k in NAMES:
             assert abs(got[i][k] - want[i][k]) < 5e-2 * max(1.0, abs(want[i][k])), (i, k, got[i][k], want[i][k])
+
+
+def test_teacher_forced_loss_curve_100_steps_fp32():
+    """100 consecutive iterations of the loop body (colored_dSprites/rp_color.py:363-516), each started from the oracle's state (parameters, buffers, Adam moments and
+    step counts): every loss within 1e-3 of the oracle's (tests/teacher_forced.py; profiles/scripts/teacher_forced_curve.py runs 1000)."""
+    import teacher_forced
+    dev, names = teacher_forced.curve("colored", 100)
+    assert dev.max() < 1e-3, (names, dev.max(axis=0), np.argmax(dev, axis=0))

@@ -194,3 +194,11 @@ def test_graph_replay_equals_eager():
     for r in res[1:]:
         for a, b in zip(r, res[0]):
             assert torch.equal(a, b)
+
+
+def test_teacher_forced_loss_curve_100_steps_fp32():
+    """100 consecutive iterations of the loop body (dSprites/rp.py:363-482), each started from the oracle's state (parameters, buffers, Adam moments and
+    step counts): every loss within 1e-3 of the oracle's (tests/teacher_forced.py; profiles/scripts/teacher_forced_curve.py runs 1000)."""
+    import teacher_forced
+    dev, names = teacher_forced.curve("dsprites", 100)
+    assert dev.max() < 1e-3, (names, dev.max(axis=0), np.argmax(dev, axis=0))

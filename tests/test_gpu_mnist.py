@@ -252,3 +252,11 @@ def test_side_lanes_are_bit_identical_to_one_stream(dtype):
         res.append((torch.stack(out).cpu(), G.arena.flat.clone().cpu(), E.arena.flat.clone().cpu()))
     assert torch.equal(res[0][0], res[1][0])
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+def test_teacher_forced_loss_curve_100_steps_fp32():
+    """100 consecutive iterations of the loop body (MNIST/EAD-GAN_rpqmnxy.py:338-446), each started from the oracle's state (parameters, buffers, Adam moments and
+    step counts): every loss within 1e-3 of the oracle's (tests/teacher_forced.py; profiles/scripts/teacher_forced_curve.py runs 1000)."""
+    import teacher_forced
+    dev, names = teacher_forced.curve("mnist", 100)
+    assert dev.max() < 1e-3, (names, dev.max(axis=0), np.argmax(dev, axis=0))
