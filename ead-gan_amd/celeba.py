@@ -861,11 +861,16 @@ class DeviceInputs:
     of the iteration's hipGraph, so a replay needs no host work at all.  Draws are reproducible per (seed, step) and have the
     reference's distributions; they are NOT numpy's stream (parity tests keep using ``load_inputs`` with host draws)."""
 
-    def __init__(self, dataset_u8: torch.Tensor, seed: int = 0, flip: bool = True):
+    def __init__(self, dataset_u8: torch.Tensor, seed: int = 0, flip: bool = True, sampling: str = "permutation"):
+        """``sampling``: "permutation" (default) = DataLoader(shuffle=True) of the reference (:204-206): a keyed permutation of the dataset
+        per epoch, every image exactly once, batches of constant size straddle epoch ends; "replacement" = independent uniform draws"""
         _require_cuda(dataset_u8)
         if dataset_u8.dtype != torch.uint8 or dataset_u8.dim() != 4:
             raise ValueError("dataset must be a uint8 [N, C, H, W] device tensor")
+        if sampling not in ("permutation", "replacement"):
+            raise ValueError("sampling must be 'permutation' or 'replacement'")
         self.data = dataset_u8.contiguous()
+        self.sampling = sampling
         self.seed, self.flip = int(seed), flip
         dev = dataset_u8.device
         self.step = torch.zeros(1, device=dev, dtype=torch.int32)
@@ -881,13 +886,17 @@ class DeviceInputs:
         if FUSE_INPUTS:
             # the five draws + the one-hot labels as one launch, the counter tick inside the gather: 3 launches instead of 8 at the head of
             # the iteration's critical chain (the same values: a draw depends on (element, step, stream id, seed) only)
-            ops.rng_fill_multi([(ops.RNG_RANDINT, self.idx, 0, N, 1),                       # shuffle-with-replacement sampling
+            first = (ops.RNG_EPOCH_PERM, self.idx, N, 0, 1) if self.sampling == "permutation" else (ops.RNG_RANDINT, self.idx, 0, N, 1)
+            ops.rng_fill_multi([first,                                                      # which images: epoch permutation / uniform draws
                                 (ops.RNG_BERNOULLI, self.flips, 0.5, 0.0, 2),               # RandomHorizontalFlip(p=0.5)
                                 (ops.RNG_NORMAL, tr.z, 0.0, 1.0, 3), (ops.RNG_UNIFORM, tr.code, -1.0, 1.0, 4),
                                 (ops.RNG_RANDINT, tr.labels, 0, tr.G.n_classes, 5, tr.onehot)], self.seed, self.step)
             ops.gather_u8_images(self.data, self.idx, self.flips if self.flip else None, tr.real, B, C, H, W, 2.0 / 255.0, -1.0, tick=self.step)   # ToTensor + Normalize(.5,.5)
             return
-        ops.rng_fill(ops.RNG_RANDINT, self.idx, 0, N, self.seed, self.step, 1)             # shuffle-with-replacement sampling
+        if self.sampling == "permutation":
+            ops.rng_fill(ops.RNG_EPOCH_PERM, self.idx, N, 0, self.seed, self.step, 1)
+        else:
+            ops.rng_fill(ops.RNG_RANDINT, self.idx, 0, N, self.seed, self.step, 1)
         ops.rng_fill(ops.RNG_BERNOULLI, self.flips, 0.5, 0.0, self.seed, self.step, 2)     # RandomHorizontalFlip(p=0.5)
         ops.gather_u8_images(self.data, self.idx, self.flips if self.flip else None, tr.real, B, C, H, W, 2.0 / 255.0, -1.0)   # ToTensor + Normalize(.5,.5)
         ops.rng_fill(ops.RNG_NORMAL, tr.z, 0.0, 1.0, self.seed, self.step, 3)
@@ -1106,8 +1115,20 @@ class CelebATrainer:
             buckets = self._buckets(arena)
             hs = {}
             if ar is not None:
+                capturing = torch.cuda.is_current_stream_capturing() and os.environ.get("EG_COMM_CAPTURE", "0") == "0"
                 for tag, lo, hi in buckets:
-                    side.wait(side.done.pop(tag))       # KeyError: a bucket whose chain was never forked
+                    done = side.done.pop(tag)           # KeyError: a bucket whose chain was never forked
+                    if ar_async and not capturing:
+                        # eager launches (the default at N > 1): the bucket's all-reduce starts from the communication stream behind
+                        # the one lane chain that completes it and is finished on the optimizer lane; the main stream waits for neither
+                        side.comm.wait_event(done)
+                        with torch.cuda.stream(side.comm):
+                            hs[tag] = ar.start(arena.grad[lo:hi])
+                        continue
+                    # inside a hipGraph capture RCCL's stream may only ever wait for the capture's origin stream (a lane that RCCL waited
+                    # for and that later waits for RCCL is the stream-level back edge hipStreamEndCapture crashes on): started from the
+                    # main stream, which therefore waits for the bucket's chain
+                    side.wait(done)
                     if ar_async:
                         hs[tag] = ar.start(arena.grad[lo:hi])
                     else:

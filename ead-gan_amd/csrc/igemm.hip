@@ -1043,6 +1043,31 @@ extern "C" int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, con
     return 0;
 }
 
+/* eg_igemm_nt_tile for one concrete call: the planner exactly as the launch runs it -- the epilogue's kernel hints AND its split-K scratch
+ * (a launch whose scratch cannot hold the partial tiles does not split) */
+extern "C" int eg_igemm_nt_tile_ep(const eg_conv* c, int dtype, int bwd, const eg_epilogue* ep) {
+    if (!c || check_conv(c, dtype, bwd ? NEED_COUT : NEED_CIN)) return -1;
+    NtParams p;
+    memset(&p, 0, sizeof(p));
+    int nphase = 1;
+    if (bwd) { if (geom_bwd(c, dtype, p, &nphase)) return -1; }
+    else geom_fwd(c, dtype, p);
+    fill_epilogue(p, ep);
+    const size_t ws = (p.part && p.part_bytes > EG_SPLIT_CNT_BYTES) ? p.part_bytes - EG_SPLIT_CNT_BYTES : 0;
+    const int variant = ep ? ep->nt_variant : EG_NT_AUTO;
+    const NtPlan plan = nt_plan(p, nphase, vec_of(dtype), dtype == EG_F32 ? 4 : 2, ws, variant, ep ? ep->nt_splitk : 0);
+    if (plan.kind < 0) return -1;
+    if (plan.kind == EG_NT_S8) return 256 * 1000 + (plan.ns > 1 ? 148 : 147);
+    if (plan.kind == EG_NT_S8P) return 256 * 1000 + (plan.ns > 1 ? 150 : 149);
+    if (plan.kind == EG_NT_PERS) return 128 * 1000 + 135;
+    if (plan.kind == EG_NT_BUF128) return 128 * 1000 + (plan.ns > 1 ? 132 : 131);
+    const int M = p.M, N = p.N;
+    if (N <= 16) return 128 * 1000 + 16;
+    if (N <= 32) return 128 * 1000 + 32;
+    if (N <= 64 || (variant != EG_NT_REG && (long long)cdiv(M, 128) * cdiv(N, 128) * nphase < 512)) return 128 * 1000 + 64;
+    return 128 * 1000 + 128;
+}
+
 extern "C" int eg_conv_stat_blocks(const eg_conv* c, int dtype, int bwd, const eg_epilogue* ep) {
     if (!c || check_conv(c, dtype, bwd ? NEED_COUT : NEED_CIN)) return 0;
     NtParams p;

@@ -28,11 +28,50 @@ struct Philox {
 
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0,1), 24 bits
 
-// kind 0: uniform [a, b) fp32; 1: normal(mean a, std b) fp32 (Box-Muller); 2: integers in [a, b) as int64; 3: Bernoulli(a) as uint8.
+// Epoch-wise shuffling without replacement (DataLoader(shuffle=True), celebA/EAD-GAN_celebA.py:204-206; MNIST/EAD-GAN_rpqmnxy.py:244-246):
+// position pos = step * batch + i of the sample stream belongs to epoch pos / N and takes dataset index perm_epoch(pos % N), a keyed
+// bijection of [0, N) -- a 4-round Feistel network over the next even power-of-two width with cycle walking (values >= N are
+// permuted again), round keys = one Philox block of (epoch, stream id) under the sampler's seed.  Every index appears exactly once per
+// epoch, batches straddle epoch ends (the batch size is constant), nothing is stored.
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ uint32_t epoch_perm(uint32_t r, uint32_t N, const uint32_t (&k)[4]) {
+    int w = 1;
+    while ((1u << (2 * w)) < N) ++w;                     // half width: 2^(2w) >= N
+    const uint32_t mask = (1u << w) - 1u;
+    uint32_t x = r;
+    do {
+        uint32_t L = x >> w, R = x & mask;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t f = mix32(R * 0x9E3779B1u + k[i]) & mask;
+            const uint32_t t = L ^ f;
+            L = R; R = t;
+        }
+        x = (L << w) | R;
+    } while (x >= N);
+    return x;
+}
+
+// kind 0: uniform [a, b) fp32; 1: normal(mean a, std b) fp32 (Box-Muller); 2: integers in [a, b) as int64; 3: Bernoulli(a) as uint8;
+// 4: epoch permutation -- dataset indices in [0, a) as int64 for positions step * n + i (see epoch_perm).
 // Quad q of a draw depends on (q, step, stream id, seed) only -- not on the launch shape -- so one launch over several draws
 // (rng_fill_multi_kernel) writes the very values the single launches write.  onehot (kind 2): out row i also sets onehot[i][0..onehot_n).
 __device__ __forceinline__ void rng_fill_quads(int kind, void* __restrict__ out, size_t n, float a, float b, const Philox& ph, uint32_t st,
                                                uint32_t stream_id, size_t q0, size_t qstride, float* __restrict__ onehot, int onehot_n) {
+    if (kind == 4) {
+        const uint32_t N = (uint32_t)a;
+        for (size_t i = q0; i < n; i += qstride) {
+            const uint64_t pos = (uint64_t)st * n + i;
+            const uint64_t epoch = pos / N;
+            uint32_t k[4] = {(uint32_t)epoch, (uint32_t)(epoch >> 32), 0x5045524Du, stream_id};
+            ph(k);
+            reinterpret_cast<long long*>(out)[i] = (long long)epoch_perm((uint32_t)(pos - epoch * N), N, k);
+        }
+        return;
+    }
     for (size_t q = q0; q * 4 < n; q += qstride) {
         uint32_t c[4] = {(uint32_t)q, (uint32_t)(q >> 32), st, stream_id};
         ph(c);
@@ -93,7 +132,8 @@ extern "C" int eg_rng_fill_multi(const eg_rng_seg* segs, int nseg, unsigned long
     memset(&p, 0, sizeof(p));
     size_t maxq = 1;
     for (int i = 0; i < nseg; ++i) {
-        EG_REQUIRE(segs[i].out && segs[i].kind >= 0 && segs[i].kind <= 3 && (!segs[i].onehot || (segs[i].kind == 2 && segs[i].onehot_n > 0)), "eg_rng_fill_multi: bad draw %d", i);
+        EG_REQUIRE(segs[i].out && segs[i].kind >= 0 && segs[i].kind <= 4 && (!segs[i].onehot || (segs[i].kind == 2 && segs[i].onehot_n > 0)), "eg_rng_fill_multi: bad draw %d", i);
+        EG_REQUIRE(segs[i].kind != 4 || (segs[i].a >= 1.f && segs[i].a <= 16777216.f && segs[i].a == floorf(segs[i].a)), "eg_rng_fill_multi: epoch permutation needs 1 <= N <= 2^24 (a)");
         p.s[i] = segs[i];
         maxq = std::max(maxq, (segs[i].n + 3) / 4);
     }
@@ -105,7 +145,8 @@ extern "C" int eg_rng_fill_multi(const eg_rng_seg* segs, int nseg, unsigned long
 
 extern "C" int eg_rng_fill(int kind, void* out, size_t n, float a, float b, unsigned long long seed, const int* step, unsigned int stream_id,
                            eg_stream_t s) {
-    EG_REQUIRE(out && kind >= 0 && kind <= 3, "eg_rng_fill: bad argument");
+    EG_REQUIRE(out && kind >= 0 && kind <= 4, "eg_rng_fill: bad argument");
+    EG_REQUIRE(kind != 4 || (a >= 1.f && a <= 16777216.f && a == floorf(a)), "eg_rng_fill: epoch permutation needs 1 <= N <= 2^24 (a)");
     if (n == 0) return 0;
     const size_t quads = (n + 3) / 4;
     const int blocks = (int)((quads + 255) / 256 > 1024 ? 1024 : (quads + 255) / 256);

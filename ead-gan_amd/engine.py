@@ -173,6 +173,9 @@ class SideStream:
         # (X waited for Y, later Y waits for X) even though the node graph is acyclic -- profiles/scripts/capture_patterns.py.  The same
         # holds for longer cycles: the waits among the non-origin streams must form a DAG (profiles/r01_timeline_notes.md item 10).
         self.prep = _Lane(device, like)
+        # communication stream (data parallel, eager launches): a gradient bucket's all-reduce is started from here as soon as the lane
+        # chain that completes the bucket has fired its event -- the main stream never waits for a lane on the collectives' behalf
+        self.comm = torch.cuda.Stream(device)
         self._pending = []
         self.done = {}                                 # tag -> event behind a tagged lane chain (defer(..., tag=))
         # tag -> main-stream event behind the last main-stream kernel that reads the tagged bucket's parameters or panels: the event of
@@ -354,14 +357,17 @@ def bn_train_backward(dt, z, da, dz, M, C, bn, mean, invstd, act, slope, dgamma,
 class DeviceSampler:
     """Shared part of the trainers' device-side input pipelines: a uint8 dataset resident in HBM, a device step counter and
     counter-based draws (ops.rng_fill: reproducible per (seed, step, stream), the reference's distributions, NOT numpy's stream --
-    parity tests keep feeding host draws through ``load_inputs``).  Sampling is with replacement (the reference's DataLoader shuffles
-    without replacement inside an epoch).  Subclasses implement ``enqueue(trainer)``: fill the trainer's static input slots, then tick
+    parity tests keep feeding host draws through ``load_inputs``).  Sampling follows ``DataLoader(shuffle=True)``: a keyed permutation of the
+    dataset per epoch, every image exactly once (``sampling="replacement"``: independent uniform draws).  Subclasses implement ``enqueue(trainer)``: fill the trainer's static input slots, then tick
     the counter; inside ``trainer.capture(inputs=...)`` those launches are part of the iteration's hipGraph."""
 
-    def __init__(self, dataset_u8: torch.Tensor, seed: int = 0):
+    def __init__(self, dataset_u8: torch.Tensor, seed: int = 0, sampling: str = "permutation"):
         if not dataset_u8.is_cuda or dataset_u8.dtype != torch.uint8:
             raise ValueError("dataset must be a uint8 device tensor")
+        if sampling not in ("permutation", "replacement"):
+            raise ValueError("sampling must be 'permutation' (DataLoader(shuffle=True): every image once per epoch) or 'replacement'")
         self.data = dataset_u8.contiguous()
+        self.sampling = sampling
         self.seed = int(seed)
         self.step = torch.zeros(1, device=dataset_u8.device, dtype=torch.int32)
         self._buf = {}
@@ -377,7 +383,10 @@ class DeviceSampler:
 
     def sample_indices(self, B, stream_id=1):
         idx = self.buf("idx", (B,), torch.int64)
-        self.draw(ops.RNG_RANDINT, idx, 0, self.data.shape[0], stream_id)
+        if self.sampling == "permutation":               # a fresh permutation of the dataset per epoch, as the reference's DataLoader draws
+            self.draw(ops.RNG_EPOCH_PERM, idx, self.data.shape[0], 0, stream_id)
+        else:
+            self.draw(ops.RNG_RANDINT, idx, 0, self.data.shape[0], stream_id)
         return idx
 
     def labels_onehot(self, name, onehot, n_classes, stream_id):

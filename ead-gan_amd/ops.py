@@ -79,6 +79,13 @@ def epilogue(bias=None, bias_mod=0, sigma=None, act=ACT_NONE, slope=0.0, mask=No
                       stat_mode, _p(stat_out), _p(stat_aux), sp[0], sp[1], sp[2], sp[3], stat_act, stat_slope)
 
 
+def nt_tile(c, dtype, bwd, ep=None) -> int:
+    """BM * 1000 + kernel code of the kernel THIS call (its hints, its split-K scratch) is dispatched to (eg_igemm_nt_tile in the header)"""
+    if ep is None:
+        ep = epilogue()
+    return lib().query("eg_igemm_nt_tile_ep", ctypes.byref(c), dtype, int(bwd), ctypes.byref(ep))
+
+
 def conv_stat_blocks(c, dtype, bwd, ep=None) -> int:
     """row blocks of the fused column statistics this exact call (geometry, hints, scratch of ``ep``) would write; 0 = it cannot fuse them"""
     if ep is None:
@@ -139,8 +146,7 @@ def _timed(kind, c, dtype, args, ep=None):
         label = f"igemm_tn8_kernel<{tname}>" if lib().query("eg_conv_wgrad_variant", ctypes.byref(c), dtype) == 2 else f"igemm_tn_kernel<{tname}>"
         nbytes = (x_elems + y_elems) * es + w_elems * 4                     # activations + output gradients in, fp32 weight gradient out
     else:
-        tile = lib().query("eg_igemm_nt_tile", ctypes.byref(c), dtype, int(kind == "bwd"), ep.nt_variant if ep is not None else 0,
-                           (ep.nt_splitk if ep.splitk_ws else 1) if ep is not None else 1)
+        tile = nt_tile(c, dtype, kind == "bwd", ep)
         bm, bn = tile // 1000, tile % 1000
         label = {131: f"igemm_nt_buf_kernel<{tname}>", 132: f"igemm_nt_buf_kernel<{tname}>+splitk",
                  135: f"igemm_nt_pers_kernel<{tname}>",
@@ -187,6 +193,11 @@ def conv_wgrad(c, dtype, X, dY, slab, wgs_target=0) -> int:
     else:
         lib().call(*args, _stream())
     return ns.value
+
+
+def conv_wgrad_variant(c, dtype) -> int:
+    """2: the parity-class kernel (igemm_tn8) runs this weight gradient, 1: the per-tap kernel"""
+    return lib().query("eg_conv_wgrad_variant", ctypes.byref(c), dtype)
 
 
 def wgrad_reduce(slab, nsplit, n_slab, n_rows, C, T, grad, accumulate=True):
@@ -535,7 +546,7 @@ def loss_info_rpqxy(o_gen, o_trans, o_real, ld, c_cont, n_cont, n_cat, B, code, 
 
 
 # ---- device-side input pipeline -------------------------------------------------------------------
-RNG_UNIFORM, RNG_NORMAL, RNG_RANDINT, RNG_BERNOULLI = 0, 1, 2, 3
+RNG_UNIFORM, RNG_NORMAL, RNG_RANDINT, RNG_BERNOULLI, RNG_EPOCH_PERM = 0, 1, 2, 3, 4
 
 
 def rng_fill(kind, out, a, b, seed, step, stream_id):

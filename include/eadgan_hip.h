@@ -124,6 +124,8 @@ int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, const void* wp
  * buffer-descriptor kernel (plain / split-K), 135 = persistent pipeline, 147 / 148 = igemm_nt8s (plain / split-K), 149 / 150 =
  * igemm_nt8s with the input patch; -1 = the forced variant cannot run the problem.  Profiling labels and tests. */
 int eg_igemm_nt_tile(const eg_conv* c, int dtype, int bwd, int variant, int splitk);
+/* the same for ONE concrete call: the epilogue's kernel hints and ITS split-K scratch (what the launch itself will do) */
+int eg_igemm_nt_tile_ep(const eg_conv* c, int dtype, int bwd, const eg_epilogue* ep);
 /* row blocks (nrb) of the column statistics that THIS call -- eg_conv_fwd (bwd = 0) / eg_conv_bwd_data (bwd = 1) with this epilogue, its
  * kernel hints and its split-K scratch -- would write if stat_mode were set; 0 = the launch cannot fuse them (another kernel than the
  * 8-wave one, ragged row tiles, splits reduced by a second launch): the caller then runs the stand-alone reduction kernels. */
@@ -427,7 +429,9 @@ int eg_quantize_u8(const float* x, int C, int H, int W, const float* range, unsi
  * RandomHorizontalFlip / ToTensor / Normalize (celebA/EAD-GAN_celebA.py:194-206, MNIST/EAD-GAN_rpqmnxy.py:235-246) and the numpy draws
  * of z / code / labels (:308-317; :351-357) -- so that a captured hipGraph feeds itself.  Philox4x32-10, counter = (element, *step,
  * stream_id), key = seed: reproducible per (seed, step), same distributions as the reference, NOT numpy's stream.
- * kind 0: uniform [a,b) fp32; 1: normal(a, b) fp32; 2: integers in [a,b) as int64; 3: Bernoulli(a) as uint8 */
+ * kind 0: uniform [a,b) fp32; 1: normal(a, b) fp32; 2: integers in [a,b) as int64; 3: Bernoulli(a) as uint8;
+ * 4: epoch permutation (DataLoader(shuffle=True), celebA.py:204-206): int64 dataset indices in [0, N = a) for the stream positions
+ *    *step * n + i -- a keyed bijection per epoch (position / N), every index exactly once per epoch, nothing stored; N <= 2^24 */
 int eg_rng_fill(int kind, void* out, size_t n, float a, float b, unsigned long long seed, const int* step, unsigned int stream_id,
                 eg_stream_t s);
 /* several draws in ONE launch (the same values as one eg_rng_fill per draw).  onehot != NULL (kind 2 only): row i of onehot[n][onehot_n] is

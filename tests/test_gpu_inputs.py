@@ -51,6 +51,31 @@ def test_rng_distributions_and_reproducibility():
     assert abs(float((base[:-1] * base[1:]).mean())) < 5e-3 and abs(float((base[:-4] * base[4:]).mean())) < 5e-3
 
 
+@pytest.mark.parametrize("N,B", [(1000, 8), (1003, 8), (37, 128), (202599, 128)])
+def test_epoch_permutation_visits_every_image_once_per_epoch(N, B):
+    """DataLoader(shuffle=True) (celebA/EAD-GAN_celebA.py:204-206): RNG_EPOCH_PERM draws the dataset indices of stream positions
+    step * B + i; every epoch (N consecutive positions) is a permutation of [0, N), epochs differ, batches straddle epoch ends."""
+    ops = eg.ops
+    steps = (2 * N + B - 1) // B + 1
+    step = torch.zeros(1, device=DEV, dtype=torch.int32)
+    out = torch.empty(B, device=DEV, dtype=torch.int64)
+    seen = []
+    for s in range(steps):
+        ops.rng_fill(ops.RNG_EPOCH_PERM, out, N, 0, 123, step, 1)
+        seen.append(out.clone())
+        ops.counter_add(step, 1)
+    idx = torch.cat(seen).cpu()
+    e0, e1 = idx[:N], idx[N:2 * N]
+    assert int(idx.min()) >= 0 and int(idx.max()) < N
+    assert torch.equal(torch.sort(e0).values, torch.arange(N)) and torch.equal(torch.sort(e1).values, torch.arange(N))
+    if N > 100:
+        assert not torch.equal(e0, e1) and float((e0 == torch.arange(N)).float().mean()) < 0.05     # shuffled, and differently per epoch
+    # another seed / stream: another order
+    ops.rng_fill(ops.RNG_EPOCH_PERM, out, N, 0, 124, torch.zeros(1, device=DEV, dtype=torch.int32), 1)
+    if N > 1000:
+        assert not torch.equal(out.cpu(), seen[0].cpu())
+
+
 def test_gather_flip_normalize_and_onehot():
     ops = eg.ops
     g = torch.Generator().manual_seed(3)
