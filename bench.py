@@ -382,6 +382,8 @@ def main():
     G = eg.celeba.Generator(dtype=a.dtype).to(dev)
     D = eg.celeba.Discriminator(dtype=a.dtype).to(dev)
     allreduce = eg.dp.GradAllReduce(world, force=a.force_dist, wire=a.wire) if (world > 1 or a.force_dist) else None
+    if allreduce is None and os.environ.get("EG_DP_SCHEDULE_ONLY"):
+        allreduce = eg.dp.GradAllReduce(1)               # diagnostic: the data-parallel schedule (communication stream, events) with no-op collectives
     sync = eg.dp.SyncBN(world, rank) if (a.sync_bn and world > 1) else None
     tr = eg.celeba.CelebATrainer(G, D, B, dtype=a.dtype, allreduce=allreduce, overlap=not a.no_overlap, sync_bn=sync)
 

@@ -913,6 +913,9 @@ class DeviceInputs:
 BATCH_D12 = os.environ.get("EG_BATCH_D12", "0") != "0"
 # optimizer updates bucket by bucket (each bucket behind its own weight-gradient chain) instead of one update behind all chains: "0" never,
 # "1" every update, "3" the info step's two, or a comma list of g1 (generator step), d2 (discriminator step), d3, g3 (info step: D, then G)
+# data parallel: gradient buckets that cross the links as one message, in completion order (contiguous in the arenas)
+DP_START = os.environ.get("EG_DP_START", "lane")
+COMM_GROUPS = {"G": (("G4", "G3", "G2"), ("G1", "G0")), "D": (("D4", "D3"), ("D2", "D1", "D0"))}
 BUCKET_OPT = os.environ.get("EG_BUCKET_OPT", "g3")
 BUCKET_SET = {"0": set(), "1": {"g1", "d2", "d3", "g3"}, "3": {"d3", "g3"}}.get(BUCKET_OPT, set(BUCKET_OPT.split(",")))
 
@@ -1113,18 +1116,40 @@ class CelebATrainer:
             side.close_tags()
             fuse = FUSE_ADAM and (FUSE_ADAM_AT == "all" or where in FUSE_ADAM_AT.split(","))
             buckets = self._buckets(arena)
-            hs = {}
+            hs, finished = {}, set()
+
+            def finish(tag):
+                h = hs.get(tag)
+                if h is not None and id(h) not in finished:
+                    finished.add(id(h))
+                    ar.finish(h)
             if ar is not None:
                 capturing = torch.cuda.is_current_stream_capturing() and os.environ.get("EG_COMM_CAPTURE", "0") == "0"
-                for tag, lo, hi in buckets:
+                if ar_async and not capturing:
+                    # eager launches (the default at N > 1): the gradient arena crosses the links as TWO messages per update (COMM_GROUPS:
+                    # the layers whose gradients are complete early / the rest -- every collective costs the host ~40 us and a ring its
+                    # latency, five per update bought nothing), each started from the communication stream behind the lane chains that
+                    # complete it and finished on the optimizer lane: the main stream waits for neither
+                    span = {tag: (lo, hi) for tag, lo, hi in buckets}
+                    for grp in COMM_GROUPS["G" if arena is ga else "D"]:
+                        # the stream the message is started from: DP_START = "lane": the lane that ran the group's last chain (no further
+                        # stream: eight busy streams on four hardware queues stall each other), "comm": a communication stream
+                        src = side.done_lane[grp[-1]].stream if DP_START == "lane" else side.comm
+                        for tag in grp:
+                            src.wait_event(side.done.pop(tag))              # KeyError: a bucket whose chain was never forked
+                        lo, hi = min(span[t][0] for t in grp), max(span[t][1] for t in grp)
+                        assert sum(span[t][1] - span[t][0] for t in grp) == hi - lo, "a communication group must be contiguous in the arena"
+                        with torch.cuda.stream(src):
+                            h = ar.start(arena.grad[lo:hi])
+                            started = side.mark()
+                        side.opt.stream.wait_event(started)                 # (the collective's own handle orders the optimizer lane behind it too)
+                        for tag in grp:
+                            hs[tag] = h                 # whichever bucket of the group is updated first finishes the message
+                    buckets_ar = ()
+                else:
+                    buckets_ar = buckets
+                for tag, lo, hi in buckets_ar:
                     done = side.done.pop(tag)           # KeyError: a bucket whose chain was never forked
-                    if ar_async and not capturing:
-                        # eager launches (the default at N > 1): the bucket's all-reduce starts from the communication stream behind
-                        # the one lane chain that completes it and is finished on the optimizer lane; the main stream waits for neither
-                        side.comm.wait_event(done)
-                        with torch.cuda.stream(side.comm):
-                            hs[tag] = ar.start(arena.grad[lo:hi])
-                        continue
                     # inside a hipGraph capture RCCL's stream may only ever wait for the capture's origin stream (a lane that RCCL waited
                     # for and that later waits for RCCL is the stream-level back edge hipStreamEndCapture crashes on): started from the
                     # main stream, which therefore waits for the bucket's chain
@@ -1137,7 +1162,7 @@ class CelebATrainer:
             if where not in BUCKET_SET:                 # the whole arena in one update behind ALL chains
                 def whole(_ws):
                     for tag in hs:
-                        ar.finish(hs[tag])
+                        finish(tag)
                     if fuse:
                         if tick:
                             ops.adam_tick(self.steps[slot:slot + 1])
@@ -1159,8 +1184,7 @@ class CelebATrainer:
                 return
             for k, (tag, lo, hi) in enumerate(buckets):
                 def fn(_ws, tag=tag, lo=lo, hi=hi, first=(k == 0)):
-                    if tag in hs:
-                        ar.finish(hs[tag])
+                    finish(tag)
                     if fuse:
                         if tick and first:
                             ops.adam_tick(self.steps[slot:slot + 1])

@@ -178,6 +178,7 @@ class SideStream:
         self.comm = torch.cuda.Stream(device)
         self._pending = []
         self.done = {}                                 # tag -> event behind a tagged lane chain (defer(..., tag=))
+        self.done_lane = {}                            # tag -> the lane that ran the chain
         # tag -> main-stream event behind the last main-stream kernel that reads the tagged bucket's parameters or panels: the event of
         # the NEXT tagged fork (the backward passes fork a layer's chain, then launch that layer's backward-data GEMM, then move on to
         # the layer below), or close_tags() for the last one
@@ -270,6 +271,7 @@ class SideStream:
                     fn(ln.ws)
                     if tag is not None:
                         self.done[tag] = self.mark()
+                        self.done_lane[tag] = ln
         finally:
             self._flushing = False
 
