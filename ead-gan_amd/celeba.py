@@ -220,7 +220,10 @@ class _GenEngine:
             else:
                 ops.bn_fwd_eval(dt, self.z[i], self.a[i], M, W[i + 1], bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, small, ACT_RELU)
             x = self.a[i]
-        if IMG_GEMM:
+        if IMG_GEMM and IMG_DIRECT and ops.convt_img_mfma_ok(dt, self.gen.channels, self.l4g.H, self.l4g.W, G_WIDTHS[3], 4, 2, 1):
+            # the last transposed convolution + Tanh in one launch: the GEMM's 48 columns per pixel stay in LDS
+            ops.convt_img_mfma(dt, x, self.l4g.wp_fwd, self._p(10, "bias"), self.img, B, self.gen.channels, self.l4g.H, self.l4g.W, ACT_TANH, 0.0)
+        elif IMG_GEMM:
             ops.conv_fwd(self.l4g.c, dt, x, self.l4g.wp_fwd, self.cols4, None)
             ops.col2im_img(dt, self.cols4, B, self.gen.channels, self.l4g.H, self.l4g.W, 4, 2, 1, self._p(10, "bias"), ACT_TANH, 0.0, self.img)
         else:
@@ -646,7 +649,9 @@ class _DiscEngine:
                 ops.conv_bwd_data(geo, dt, sl(self.dz[i]), self.mid[i - 1].wp_bwd, sl(self.dz[i - 1]), ops.epilogue(**kw))
                 flush()
         if need_dimg:
-            if IMG_GEMM:
+            if IMG_GEMM and IMG_DIRECT and ops.convt_img_mfma_ok(dt, self.C, self.S // 2, self.S // 2, W[0], 4, 2, 1):
+                ops.convt_img_mfma(dt, sl(self.dz[0]), self.l1g.wp_fwd, None, self.dimg, B, self.C, self.S // 2, self.S // 2, ACT_NONE, 0.0)
+            elif IMG_GEMM:
                 ops.conv_fwd(self.l1g.c, dt, sl(self.dz[0]), self.l1g.wp_fwd, self.cols1, None)
                 ops.col2im_img(dt, self.cols1, B, self.C, self.S // 2, self.S // 2, 4, 2, 1, None, ACT_NONE, 0.0, self.dimg)
             else:
@@ -914,6 +919,7 @@ BATCH_D12 = os.environ.get("EG_BATCH_D12", "0") != "0"
 # optimizer updates bucket by bucket (each bucket behind its own weight-gradient chain) instead of one update behind all chains: "0" never,
 # "1" every update, "3" the info step's two, or a comma list of g1 (generator step), d2 (discriminator step), d3, g3 (info step: D, then G)
 # data parallel: gradient buckets that cross the links as one message, in completion order (contiguous in the arenas)
+SPLIT2_SET = set(filter(None, os.environ.get("EG_SPLIT2", "").split(",")))      # updates done in two pieces (early layers / rest): g1, d2, d3, g3
 DP_START = os.environ.get("EG_DP_START", "lane")
 COMM_GROUPS = {"G": (("G4", "G3", "G2"), ("G1", "G0")), "D": (("D4", "D3"), ("D2", "D1", "D0"))}
 BUCKET_OPT = os.environ.get("EG_BUCKET_OPT", "g3")
@@ -1159,6 +1165,34 @@ class CelebATrainer:
                     else:
                         ar(arena.grad[lo:hi])
             last = buckets[-1][0]
+            if where in SPLIT2_SET and ar is None:
+                # the update in TWO pieces: the layers whose gradients are complete early (COMM_GROUPS' first group: for D 77 % of the
+                # parameters) as soon as their chains are done, the rest behind all chains -- the path from the end of the backward pass
+                # to "weights are new" (the next power iteration waits for it) is an Adam over the small remainder only
+                span = {tag: (lo, hi) for tag, lo, hi in buckets}
+                early = COMM_GROUPS["G" if arena is ga else "D"][0]
+                late = tuple(t for t, _, _ in buckets if t not in early)
+
+                def piece(tags, first):
+                    lo, hi = min(span[t][0] for t in tags), max(span[t][1] for t in tags)
+                    assert sum(span[t][1] - span[t][0] for t in tags) == hi - lo
+
+                    def fn(_ws):
+                        ops.adam_step_zero(arena.flat[lo:hi], arena.grad[lo:hi], m[lo:hi], v[lo:hi], hi - lo, lr, self.betas[0], self.betas[1], 1e-8,
+                                           self.steps[slot:slot + 1], tick and first, zero)
+                        if not first and key_w:
+                            evs[key_w] = side.mark()
+                        for t in tags:
+                            eng.repack_bucket(t)
+                        if not first and key:
+                            evs[key] = side.mark()
+                    return fn
+                side.defer_opt_after(early, piece(early, True))
+                for t in late:
+                    side.done.pop(t, None)
+                    side.free.pop(t, None)
+                side.defer_opt(piece(late, False))
+                return
             if where not in BUCKET_SET:                 # the whole arena in one update behind ALL chains
                 def whole(_ws):
                     for tag in hs:

@@ -181,3 +181,135 @@ extern "C" int eg_conv_img_mfma(int dtype, const float* img0, const float* img1,
     EG_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+//   convt_img_mfma : ConvTranspose2d(128 -> C <= 3, 4, 2, 1) from 16-bit NHWC activations to an fp32 NCHW image
+//                    * the Generator's last layer + Tanh (celebA/EAD-GAN_celebA.py:90-91)
+//                    * the backward-to-image of the first Discriminator layer Conv2d(C -> 128, 4, 2, 1) (:110)
+// Before: ONE GEMM over the input pixels with N = 16 taps x C columns (cols[m][t*C + c], stored to HBM as dtype T) + eg_col2im_img
+// gathering four taps per output pixel: 29-50 us on the critical chain.  Here a workgroup takes 16 input rows of one image plus one halo
+// row on either side, runs that GEMM on the MFMA units (the 48 x 128 panel in registers, activations straight from global memory into
+// fragments), keeps the columns in LDS (rounded to T, as the stored ones were) and gathers its 32 output rows from there.
+// Same MFMA operands in the same order, same rounding of the columns, same tap order in the gather: bit-identical to GEMM + col2im.
+// ------------------------------------------------------------------------------------------------
+struct ImgTParams {
+    const void* a;            // [B][Hin][Win][128] dtype T
+    const void* wp;           // [16*C rows (n = t*C + c)][128] dtype T
+    const float* bias;        // [C] or null
+    float* out;               // [B][C][2*Hin][2*Win] fp32
+    int B, C, Hin, Win;
+    int act;
+    float slope;
+};
+
+template <typename T, int R>
+__global__ __launch_bounds__(256) void convt_img_mfma_kernel(const ImgTParams p) {
+    constexpr int K = 128, WMAX = 32, NP = 56;           // R input rows per workgroup (+ 2 halo rows); LDS pitch of a pixel's 48 columns
+    __shared__ __attribute__((aligned(16))) unsigned short s_cols[(R + 2) * WMAX * NP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int nblk = p.Hin / R, b = blockIdx.x / nblk, r0 = (blockIdx.x % nblk) * R;
+    const int ncol = 16 * p.C;                           // <= 48
+    const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp);
+    const T* __restrict__ a = reinterpret_cast<const T*>(p.a) + (size_t)b * p.Hin * p.Win * K;
+
+    // weight fragments: column tile j (n = j*16 + frow), k step s
+    uint4 bf[4][3];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int n = j * 16 + frow;
+            bf[s][j] = n < ncol ? *reinterpret_cast<const uint4*>(wp + (size_t)n * K + s * 32 + fq * 8) : make_uint4(0, 0, 0, 0);
+        }
+    // GEMM over the (R + 2) x Win pixels of this block, 16 pixels per wave and pass; rows outside the image are skipped (never gathered)
+    const int npix = (R + 2) * p.Win, ngrp = npix / 16;
+    auto fetch = [&](int g, uint4 (&af)[4]) {            // fragments of pass g: pixel g*16 + frow, k chunks s*32 + fq*8
+        const int pl = g * 16 + frow;
+        const int iy = r0 - 1 + pl / p.Win, ix = pl % p.Win;
+        const bool ok = g < ngrp && iy >= 0 && iy < p.Hin;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            af[s] = ok ? *reinterpret_cast<const uint4*>(a + ((size_t)iy * p.Win + ix) * K + s * 32 + fq * 8) : make_uint4(0, 0, 0, 0);
+    };
+    auto compute = [&](int g, const uint4 (&af)[4]) {
+        const int pl = g * 16 + frow;                    // local pixel: row pl / Win (0 = halo row r0 - 1), column pl % Win
+        f32x4 acc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) mfma_step<T>(af[s], bf[s][j], acc[j]);
+        // acc[j][r] = cols[pixel frow][n = j*16 + fq*4 + r], rounded to T like the stored columns were
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            T h[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Elt<T>::st(h + r, __fmul_rn(acc[j][r], 1.f));
+            *reinterpret_cast<uint2*>(&s_cols[(size_t)pl * NP + j * 16 + fq * 4]) = *reinterpret_cast<const uint2*>(h);
+        }
+    };
+    // two passes in flight: the loads of pass g + 4 are issued before pass g is multiplied (a wave alone would wait out every load)
+    uint4 fa[4], fb[4];
+    fetch(wave, fa);
+    for (int g = wave; g < ngrp; g += 8) {
+        fetch(g + 4, fb);
+        compute(g, fa);
+        if (g + 4 < ngrp) {
+            fetch(g + 8, fa);
+            compute(g + 4, fb);
+        }
+    }
+    __syncthreads();
+    // gather: output rows 2*r0 .. 2*(r0 + R) - 1, all columns; taps in eg_col2im_img's order (kh ascending, kw ascending)
+    const int OH = 2 * p.Hin, OW = 2 * p.Win;
+    const T* __restrict__ cols = reinterpret_cast<const T*>(s_cols);
+    for (int o = tid; o < 2 * R * OW; o += 256) {
+        const int ox = o % OW, oy = 2 * r0 + o / OW;
+        float acc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] = (p.bias && c < p.C) ? p.bias[c] : 0.f;
+        for (int kh = (oy + 1) & 1; kh < 4; kh += 2) {
+            const int iy = (oy + 1 - kh) >> 1;
+            if (iy < 0 || iy >= p.Hin) continue;
+            for (int kw = (ox + 1) & 1; kw < 4; kw += 2) {
+                const int ix = (ox + 1 - kw) >> 1;
+                if (ix < 0 || ix >= p.Win) continue;
+                const T* src = cols + (size_t)((iy - (r0 - 1)) * p.Win + ix) * NP + (kh * 4 + kw) * p.C;
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    if (c < p.C) acc[c] += Elt<T>::ld(src + c);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            if (c < p.C) p.out[(((size_t)b * p.C + c) * OH + oy) * OW + ox] = eg_act(acc[c], p.act, p.slope);
+    }
+}
+
+extern "C" int eg_convt_img_mfma_ok(int dtype, int C, int Hin, int Win, int K, int k, int stride, int pad) {
+    return dtype != EG_F32 && C >= 1 && C <= 3 && K == 128 && k == 4 && stride == 2 && pad == 1 && Hin >= 16 && (Hin % 16) == 0 && (Win == 16 || Win == 32);
+}
+
+extern "C" int eg_convt_img_mfma(int dtype, const void* a, const void* wp, const float* bias, float* out, int B, int C, int Hin, int Win, int act,
+                                 float slope, eg_stream_t s) {
+    EG_REQUIRE(a && wp && out && B > 0, "eg_convt_img_mfma: bad argument");
+    EG_REQUIRE(eg_convt_img_mfma_ok(dtype, C, Hin, Win, 128, 4, 2, 1), "eg_convt_img_mfma: 16-bit types, C <= 3, Hin %% 16 == 0, Win 16 or 32 only (use eg_conv_fwd + eg_col2im_img)");
+    ImgTParams p;
+    memset(&p, 0, sizeof(p));
+    p.a = a; p.wp = wp; p.bias = bias; p.out = out; p.B = B; p.C = C; p.Hin = Hin; p.Win = Win; p.act = act; p.slope = slope;
+    // input rows per workgroup: 8 (+ 2 halo rows: 25 % of the GEMM done twice, 36 KiB of LDS, several workgroups per CU) or 16
+    static const int rows = [] { const char* e = getenv("EG_CONVT_IMG_ROWS"); return e && atoi(e) == 16 ? 16 : 8; }();
+    if (rows == 16) {
+        const dim3 grid(B * (Hin / 16));
+        if (dtype == EG_F16) hipLaunchKernelGGL((convt_img_mfma_kernel<f16_t, 16>), grid, dim3(256), 0, (hipStream_t)s, p);
+        else hipLaunchKernelGGL((convt_img_mfma_kernel<bf16_t, 16>), grid, dim3(256), 0, (hipStream_t)s, p);
+    } else {
+        const dim3 grid(B * (Hin / 8));
+        if (dtype == EG_F16) hipLaunchKernelGGL((convt_img_mfma_kernel<f16_t, 8>), grid, dim3(256), 0, (hipStream_t)s, p);
+        else hipLaunchKernelGGL((convt_img_mfma_kernel<bf16_t, 8>), grid, dim3(256), 0, (hipStream_t)s, p);
+    }
+    EG_LAUNCH_CHECK();
+    return 0;
+}

@@ -278,6 +278,15 @@ def conv_img_mfma(dtype, imgs, wp, out, B, C, H, W, ep=None, gates=None, gate_ac
                ctypes.byref(ep) if ep is not None else None, gate_act, gate_slope, _stream())
 
 
+def convt_img_mfma_ok(dtype, C, Hin, Win, K, k, stride, pad) -> bool:
+    return bool(lib().query("eg_convt_img_mfma_ok", dtype, C, Hin, Win, K, k, stride, pad))
+
+
+def convt_img_mfma(dtype, a, wp, bias, out, B, C, Hin, Win, act=ACT_NONE, slope=0.0):
+    """ConvTranspose2d(128 -> C, 4, 2, 1) from NHWC activations to an fp32 NCHW image in one launch (GEMM columns stay in LDS)"""
+    lib().call("eg_convt_img_mfma", dtype, _p(a), _p(wp), _p(bias), _p(out), B, C, Hin, Win, act, slope, _stream())
+
+
 def cast_pad(dtype, src, dst, rows, n, npad):
     lib().call("eg_cast_pad", dtype, _p(src), _p(dst), rows, n, npad, _stream())
 

@@ -214,6 +214,13 @@ int eg_conv_img_mfma_ok(int dtype, int C, int H, int W, int N, int k, int stride
 int eg_conv_img_mfma(int dtype, const float* img0, const float* img1, const float* img2, const float* gate0, const float* gate1,
                      const float* gate2, int ntapes, const void* wp, void* out, int B, int C, int H, int W, const eg_epilogue* ep,
                      int gate_act, float gate_slope, eg_stream_t s);
+/* ConvTranspose2d(128 -> C <= 3, 4, 2, 1) from 16-bit NHWC activations a [B][Hin][Win][128] to an fp32 NCHW image [B][C][2 Hin][2 Win] in ONE
+ * launch (the GEMM's columns stay in LDS): out = act(bias + transposed convolution); wp = the [16 * C][128] panel (row t * C + c) of
+ * eg_pack_strided.  The Generator's last layer + Tanh (celebA.py:90-91) and the backward-to-image of the first Discriminator layer (:110).
+ * Bit-identical to eg_conv_fwd (N = 16 C columns) + eg_col2im_img. */
+int eg_convt_img_mfma_ok(int dtype, int C, int Hin, int Win, int K, int k, int stride, int pad);
+int eg_convt_img_mfma(int dtype, const void* a, const void* wp, const float* bias, float* out, int B, int C, int Hin, int Win, int act,
+                      float slope, eg_stream_t s);
 int eg_cast_pad(int dtype, const float* src, void* dst, int rows, int n, int npad, eg_stream_t s);
 /* col2im of a transposed convolution with C = 1 or 3 output channels (ConvTranspose2d(128 -> 3, 4, 2, 1): celebA/EAD-GAN_celebA.py:90-91; the
  * backward-to-image of Conv2d(3 -> 128, 4, 2, 1): :110).  cols [B*Hin*Win][k*k*C] (dtype T; column t*C + c, t = kh*k + kw) is the output of

@@ -48,3 +48,21 @@ for T in (1, 2, 3):
     t_old = timeit(old)
     t_new = timeit(lambda: ops.conv_img_mfma(dt, imgs, wp, out, B, C, S, S, ep))
     print(f"T={T}: im2col + GEMM {t_old:.1f} us | direct {t_new:.1f} us ({(T * B * (3 * 64 * 64 * 4 + 32 * 32 * 128 * 2)) / t_new / 1e6:.2f} TB/s algorithmic)")
+
+# transposed side: ConvTranspose2d(128 -> 3) as GEMM + col2im against the one-launch kernel
+a = torch.randn(B, 32, 32, 128, device=dev).to(torch.bfloat16)
+w3 = torch.randn(128, C, 4, 4, device=dev) * 0.05
+c2 = ops.make_conv(B, 32, 32, 128, 48, 1, 1, 0)
+wp2 = torch.empty(ops.pack_fwd_elems(c2, dt), device=dev, dtype=torch.bfloat16)
+ops.pack_strided(dt, w3, wp2, 48, 128, 128, C, 1, 16, 48)
+cols = torch.empty(B * 1024, 48, device=dev, dtype=torch.bfloat16)
+img = torch.empty(B, C, 64, 64, device=dev)
+b3 = torch.zeros(C, device=dev)
+
+
+def old_t():
+    ops.conv_fwd(c2, dt, a, wp2, cols, None)
+    ops.col2im_img(dt, cols, B, C, 32, 32, 4, 2, 1, b3, ops.ACT_TANH, 0.0, img)
+
+
+print(f"ConvT 128->3: GEMM + col2im {timeit(old_t):.1f} us | one launch {timeit(lambda: ops.convt_img_mfma(dt, a, wp2, b3, img, B, C, 32, 32, ops.ACT_TANH, 0.0)):.1f} us")

@@ -85,3 +85,32 @@ def test_other_shapes_are_refused():
     assert not ops.conv_img_mfma_ok(0, 3, 64, 64, 128, 4, 2, 1)          # fp32
     assert not ops.conv_img_mfma_ok(1, 3, 32, 32, 128, 4, 2, 1)          # 32-pixel rows
     assert not ops.conv_img_mfma_ok(1, 3, 64, 64, 64, 4, 2, 1)           # 64 output channels
+
+
+@pytest.mark.parametrize("dtype", [1, 2])
+@pytest.mark.parametrize("B,C,act", [(4, 3, 3), (128, 3, 3), (6, 3, 0), (5, 1, 3)])
+def test_transposed_image_convolution_in_one_launch(B, C, act, dtype):
+    """ConvTranspose2d(128 -> C, 4, 2, 1) (+ bias + Tanh: the Generator's last layer; plain: the backward-to-image of the first Discriminator
+    layer) as ONE launch with the GEMM's columns in LDS == eg_conv_fwd (N = 16 C columns, stored as dtype T) + eg_col2im_img, bit for bit"""
+    Hin = 32
+    g = torch.Generator().manual_seed(8)
+    tdt = ops.torch_dtype(dtype)
+    a = torch.randn(B, Hin, Hin, 128, generator=g).to(DEV).to(tdt)
+    w = (torch.randn(128, C, 4, 4, generator=g) * 0.05).to(DEV)        # ConvTranspose2d master [in = 128][out = C][4][4]
+    bias = (torch.randn(C, generator=g) * 0.1).to(DEV) if act else None
+    kp = 16 * C
+    c = ops.make_conv(B, Hin, Hin, 128, kp, 1, 1, 0)
+    wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=tdt)
+    ops.pack_strided(dtype, w, wp, kp, 128, 128, C, 1, 16, kp)          # wp[t*C + c][ci] = W[ci][c][t]
+    cols = torch.empty(B * Hin * Hin, kp, device=DEV, dtype=tdt)
+    ops.conv_fwd(c, dtype, a, wp, cols, None)
+    want = torch.empty(B, C, 2 * Hin, 2 * Hin, device=DEV)
+    ops.col2im_img(dtype, cols, B, C, Hin, Hin, 4, 2, 1, bias, act, 0.0, want)
+    assert ops.convt_img_mfma_ok(dtype, C, Hin, Hin, 128, 4, 2, 1)
+    got = torch.full_like(want, float("nan"))
+    ops.convt_img_mfma(dtype, a, wp, bias, got, B, C, Hin, Hin, act, 0.0)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    ref = F.conv_transpose2d(a.float().permute(0, 3, 1, 2), w.to(tdt).float(), bias, 2, 1)
+    ref = torch.tanh(ref) if act else ref
+    torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2)
