@@ -259,14 +259,24 @@ class _GenEngine:
             ns = ops.conv_wgrad(self.l4p.c, dt, self.patches, self.a[2], wsw.slab, wsw.wgs_target)
             ops.wgrad_reduce(wsw.slab, ns, W[3], W[3], self.kp, 1, gof("conv_blocks.10.weight"))
         wgrad_side(l4_wgrad, 0, "G4")
+        fused = (0, None)                               # (row blocks, sums) if da[i] came with its BatchNorm backward sums (then it holds dy)
         if direct:
-            # d(a) = Conv2d(C -> 128, 4, 2, 1) of d(img) * tanh'(img): straight from the two fp32 images, no patch rows
-            ops.conv_img_mfma(dt, [dimg], self.l4p.wp_fwd, self.da[2], B, C, S, S, None, gates=[self.img], gate_act=ACT_TANH)
+            # d(a) = Conv2d(C -> 128, 4, 2, 1) of d(img) * tanh'(img): straight from the two fp32 images, no patch rows -- and, in the same
+            # launch, dy = da * relu'(bn(z)) with the two sums of the last BatchNorm layer's backward
+            ep4 = None
+            if FUSE_STATS and sync is None:
+                if "bwd2" not in self._stat:
+                    nrb = ops.conv_img_mfma_stat_blocks(B, S, S)
+                    self._stat["bwd2"] = (nrb, torch.empty(2 * W[3] * nrb, device=self.inp.device, dtype=torch.float32))
+                fused = self._stat["bwd2"]
+                bn3 = gen.conv_blocks[8]
+                ep4 = ops.epilogue(stat_mode=ops.STAT_BN_BWD, stat_out=fused[1], stat_aux=self.z[2], stat_p=(self.mean[2], self.invstd[2], bn3.weight, bn3.bias),
+                                   stat_act=ACT_RELU)
+            ops.conv_img_mfma(dt, [dimg], self.l4p.wp_fwd, self.da[2], B, C, S, S, ep4, gates=[self.img], gate_act=ACT_TANH)
         else:
             ops.conv_fwd(self.l4p.c, dt, self.patches, self.l4p.wp_fwd, self.da[2], None)
         flush()
         # L3..L1
-        fused = (0, None)                               # (row blocks, sums) if da[i] came with its BatchNorm backward sums (then it holds dy)
         for i, idx in ((2, 7), (1, 4), (0, 1)):
             r = self.mid[i]
             bn = gen.conv_blocks[idx + 1]

@@ -33,10 +33,18 @@ struct ImgMfmaParams {
     float slope;
     int gate_act;
     float gate_slope;
+    // EG_STAT_BN_BWD (STAT instantiation): the output is d(activation) of a BatchNorm + activation layer; z = its BatchNorm input (layout of
+    // out), per-channel mean / invstd / gamma / beta; dy = out * act'(bn(z)) is stored instead and (sum dy, sum dy * xhat) of every tile of 64
+    // pixels go to stat_out[(which * 128 + n) * ntiles + tile]
+    const void* stat_z;
+    const float* stat_p[4];
+    float* stat_out;
+    int stat_act;
+    float stat_slope;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256, EG_IMG_CONV_OCC) void conv_img_mfma_kernel(const ImgMfmaParams p, int ntiles) {
+template <typename T, bool STAT>
+__global__ __launch_bounds__(256, STAT ? 2 : EG_IMG_CONV_OCC) void conv_img_mfma_kernel(const ImgMfmaParams p, int ntiles) {
     constexpr int N = 128, XS = 72, OS = N + 8;          // LDS row pitches in elements: 66 used columns (x = -1 .. 64); 16-byte aligned pixel rows
     __shared__ __attribute__((aligned(16))) unsigned short s_in[4][6][XS];
     __shared__ __attribute__((aligned(16))) unsigned short s_out[4][16][OS];
@@ -53,7 +61,18 @@ __global__ __launch_bounds__(256, EG_IMG_CONV_OCC) void conv_img_mfma_kernel(con
 #pragma unroll
         for (int j = 0; j < 8; ++j) bf[s][j] = *reinterpret_cast<const uint4*>(wp + (size_t)(j * 16 + frow) * 64 + s * 32 + fq * 8);
     __shared__ __attribute__((aligned(16))) float s_bias[N];
+    __shared__ __attribute__((aligned(16))) float s_red[STAT ? 4 * 2 * N : 4];      // per wave: the two sums of its 16 pixels, per channel
     if (tid < N) s_bias[tid] = p.bias ? p.bias[tid] : 0.f;      // (published by the loop's first barrier)
+    // BatchNorm backward operands per channel in LDS: mean, invstd, P = gamma * invstd, Q = beta - mean * P (published by the first barrier)
+    __shared__ __attribute__((aligned(16))) float s_par[STAT ? 4 * N : 4];
+    if constexpr (STAT) {
+        if (tid < N) {
+            const float mu = p.stat_p[0][tid], is = p.stat_p[1][tid], g = p.stat_p[2][tid], bb = p.stat_p[3][tid];
+            const float P = __fmul_rn(g, is);
+            s_par[tid] = mu; s_par[N + tid] = is; s_par[2 * N + tid] = P; s_par[3 * N + tid] = __fsub_rn(bb, __fmul_rn(mu, P));
+        }
+    }
+    const EgGradFast sgf = eg_grad_fast(p.stat_act, p.stat_slope);
     const EgActFast af = eg_act_fast(p.act, p.slope);
 
     // staging slots of this thread: elements e = tid and tid + 256 of the 4 x 6 x 16 float4 grid (channel, image row, 4-column group)
@@ -127,6 +146,7 @@ __global__ __launch_bounds__(256, EG_IMG_CONV_OCC) void conv_img_mfma_kernel(con
         const int tape = ib / p.B;
         const int gx = rem_t % gxn, oy0 = (rem_t / gxn) * 2;
         const float inv_sigma = p.sigma ? 1.f / p.sigma[tape] : 1.f;
+        const size_t pix0 = ((size_t)ib * OH + oy0 + ry) * OW + gx * 32 + (wave & 1) * 16;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             T h[4];
@@ -139,10 +159,43 @@ __global__ __launch_bounds__(256, EG_IMG_CONV_OCC) void conv_img_mfma_kernel(con
                 x = af.special ? eg_act(x, p.act, p.slope) : eg_act_apply(x, af);
                 Elt<T>::st(h + r, x);
             }
+            if constexpr (STAT) {
+                // dy = da * act'(bn(z)) (the forward's activation input z * P + Q), sums over this wave's 16 pixels by DPP row reductions
+                const uint2 zv = *reinterpret_cast<const uint2*>(reinterpret_cast<const T*>(p.stat_z) + (pix0 + frow) * N + j * 16 + fq * 4);
+                const T* ze = reinterpret_cast<const T*>(&zv);
+                float s1[4], s2[4];
+                const int nb = j * 16 + fq * 4;
+                const float4 vmu = *reinterpret_cast<const float4*>(&s_par[nb]), vis = *reinterpret_cast<const float4*>(&s_par[N + nb]);
+                const float4 vp = *reinterpret_cast<const float4*>(&s_par[2 * N + nb]), vq = *reinterpret_cast<const float4*>(&s_par[3 * N + nb]);
+                const float k_mu[4] = {vmu.x, vmu.y, vmu.z, vmu.w}, k_is[4] = {vis.x, vis.y, vis.z, vis.w};
+                const float k_p[4] = {vp.x, vp.y, vp.z, vp.w}, k_q[4] = {vq.x, vq.y, vq.z, vq.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z = Elt<T>::ld(ze + r);
+                    const float xh = (z - k_mu[r]) * k_is[r];
+                    const float dy = Elt<T>::ld(h + r) * eg_grad_apply(fmaf(z, k_p[r], k_q[r]), sgf);
+                    Elt<T>::st(h + r, dy);
+                    s1[r] = dy;
+                    s2[r] = dy * xh;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {             // sum over frow = the 16 lanes of a DPP row (fixed order)
+                    s1[r] += eg_dpp<0xB1>(s1[r]); s1[r] += eg_dpp<0x4E>(s1[r]); s1[r] += eg_dpp<0x141>(s1[r]); s1[r] += eg_dpp<0x140>(s1[r]);
+                    s2[r] += eg_dpp<0xB1>(s2[r]); s2[r] += eg_dpp<0x4E>(s2[r]); s2[r] += eg_dpp<0x141>(s2[r]); s2[r] += eg_dpp<0x140>(s2[r]);
+                }
+                if (frow == 0) {
+                    *reinterpret_cast<float4*>(&s_red[(wave * 2 + 0) * N + j * 16 + fq * 4]) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+                    *reinterpret_cast<float4*>(&s_red[(wave * 2 + 1) * N + j * 16 + fq * 4]) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+                }
+            }
             *reinterpret_cast<uint2*>(&s_out[wave][frow][j * 16 + fq * 4]) = *reinterpret_cast<const uint2*>(h);
         }
         __syncthreads();                                 // output rows complete; every wave is done reading the image rows
-        const size_t pix0 = ((size_t)ib * OH + oy0 + ry) * OW + gx * 32 + (wave & 1) * 16;
+        if constexpr (STAT) {
+            const int which = tid >> 7, n = tid & (N - 1);
+            const float t = ((s_red[(0 * 2 + which) * N + n] + s_red[(1 * 2 + which) * N + n]) + s_red[(2 * 2 + which) * N + n]) + s_red[(3 * 2 + which) * N + n];
+            p.stat_out[((size_t)which * N + n) * ntiles + tile] = t;
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = it * 4 + (lane >> 4), chunk = lane & 15;
@@ -151,6 +204,9 @@ __global__ __launch_bounds__(256, EG_IMG_CONV_OCC) void conv_img_mfma_kernel(con
         }
     }
 }
+
+/* row blocks (tiles of 64 pixels) of the EG_STAT_BN_BWD sums an eg_conv_img_mfma launch writes */
+extern "C" int eg_conv_img_mfma_stat_blocks(int B, int H, int W, int ntapes) { return (H / 4) * (W / 64) * B * ntapes; }
 
 extern "C" int eg_conv_img_mfma_ok(int dtype, int C, int H, int W, int N, int k, int stride, int pad) {
     return dtype != EG_F32 && C >= 1 && C <= 4 && N == 128 && k == 4 && stride == 2 && pad == 1 && H >= 4 && (H % 4) == 0 && (W % 64) == 0;
@@ -162,7 +218,10 @@ extern "C" int eg_conv_img_mfma(int dtype, const float* img0, const float* img1,
     EG_REQUIRE(img0 && wp && out && ntapes >= 1 && ntapes <= 3 && B > 0, "eg_conv_img_mfma: bad argument");
     EG_REQUIRE(eg_conv_img_mfma_ok(dtype, C, H, W, 128, 4, 2, 1), "eg_conv_img_mfma: 16-bit types, C <= 4, H %% 4 == 0, W %% 64 == 0 only (use eg_im2col_img + eg_conv_fwd)");
     EG_REQUIRE((ntapes < 2 || img1) && (ntapes < 3 || img2), "eg_conv_img_mfma: one image pointer per tape");
-    EG_REQUIRE(!ep || (!ep->mask && ep->out_mode == EG_OUT_NHWC && ep->stat_mode == EG_STAT_NONE && ep->bias_mod == 0), "eg_conv_img_mfma: unsupported epilogue field");
+    EG_REQUIRE(!ep || (!ep->mask && ep->out_mode == EG_OUT_NHWC && ep->bias_mod == 0 && (ep->stat_mode == EG_STAT_NONE || ep->stat_mode == EG_STAT_BN_BWD)),
+               "eg_conv_img_mfma: unsupported epilogue field");
+    const bool stat = ep && ep->stat_mode == EG_STAT_BN_BWD;
+    EG_REQUIRE(!stat || (ep->stat_out && ep->stat_aux && ep->stat_p0 && ep->stat_p1 && ep->stat_p2 && ep->stat_p3), "eg_conv_img_mfma: EG_STAT_BN_BWD needs stat_out, stat_aux (z) and stat_p0..p3");
     ImgMfmaParams p;
     memset(&p, 0, sizeof(p));
     p.img[0] = img0; p.img[1] = img1; p.img[2] = img2;
@@ -173,11 +232,19 @@ extern "C" int eg_conv_img_mfma(int dtype, const float* img0, const float* img1,
     p.act = ep ? ep->act : EG_ACT_NONE;
     p.slope = ep ? ep->slope : 0.f;
     p.gate_act = gate_act; p.gate_slope = gate_slope;
+    if (stat) {
+        p.stat_z = ep->stat_aux; p.stat_out = ep->stat_out; p.stat_act = ep->stat_act; p.stat_slope = ep->stat_slope;
+        p.stat_p[0] = ep->stat_p0; p.stat_p[1] = ep->stat_p1; p.stat_p[2] = ep->stat_p2; p.stat_p[3] = ep->stat_p3;
+    }
     const int ntiles = (H / 4) * (W / 64) * B * ntapes;  // 2 output rows x 32 columns each
     static const int wgs = [] { const char* e = getenv("EG_IMG_CONV_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256 * EG_IMG_CONV_OCC; }();
     const dim3 grid(ntiles < wgs ? ntiles : wgs);         // persistent: two workgroups per CU (181 registers) walk the tiles with the weight panel in registers
-    if (dtype == EG_F16) hipLaunchKernelGGL(conv_img_mfma_kernel<f16_t>, grid, dim3(256), 0, (hipStream_t)s, p, ntiles);
-    else hipLaunchKernelGGL(conv_img_mfma_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, p, ntiles);
+    if (stat) {
+        const dim3 gs(ntiles < 512 ? ntiles : 512);      // two workgroups per CU: the sums take the registers
+        if (dtype == EG_F16) hipLaunchKernelGGL((conv_img_mfma_kernel<f16_t, true>), gs, dim3(256), 0, (hipStream_t)s, p, ntiles);
+        else hipLaunchKernelGGL((conv_img_mfma_kernel<bf16_t, true>), gs, dim3(256), 0, (hipStream_t)s, p, ntiles);
+    } else if (dtype == EG_F16) hipLaunchKernelGGL((conv_img_mfma_kernel<f16_t, false>), grid, dim3(256), 0, (hipStream_t)s, p, ntiles);
+    else hipLaunchKernelGGL((conv_img_mfma_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)s, p, ntiles);
     EG_LAUNCH_CHECK();
     return 0;
 }

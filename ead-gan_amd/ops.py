@@ -270,6 +270,10 @@ def conv_img_mfma_ok(dtype, C, H, W, N, k, stride, pad) -> bool:
     return bool(lib().query("eg_conv_img_mfma_ok", dtype, C, H, W, N, k, stride, pad))
 
 
+def conv_img_mfma_stat_blocks(B, H, W, ntapes=1) -> int:
+    return lib().query("eg_conv_img_mfma_stat_blocks", B, H, W, ntapes)
+
+
 def conv_img_mfma(dtype, imgs, wp, out, B, C, H, W, ep=None, gates=None, gate_act=ACT_NONE, gate_slope=0.0):
     """Conv2d(C -> 128, 4, 2, 1) of up to three fp32 NCHW image tensors (tapes) straight on the MFMA units, no patch rows in HBM"""
     im = [_p(t) for t in imgs] + [None] * (3 - len(imgs))

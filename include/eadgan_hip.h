@@ -211,6 +211,9 @@ int eg_im2col_img(int dtype, const float* img, void* out, int B, int CI, int H, 
  * the convolution's input is img_t * act'(gate_t) (the input gradient of the Generator's last ConvTranspose2d + Tanh, celebA.py:90-91: img =
  * d(loss)/d(image), gate = the image).  ep: bias, sigma, act / slope only.  Bit-identical to eg_im2col_img + eg_conv_fwd on the patch rows. */
 int eg_conv_img_mfma_ok(int dtype, int C, int H, int W, int N, int k, int stride, int pad);
+/* ep->stat_mode == EG_STAT_BN_BWD is honoured too (the output feeds a BatchNorm backward: dy stored, the two sums per tile of 64 pixels
+ * to ep->stat_out[(which * 128 + n) * nrb + tile]); nrb = eg_conv_img_mfma_stat_blocks() */
+int eg_conv_img_mfma_stat_blocks(int B, int H, int W, int ntapes);
 int eg_conv_img_mfma(int dtype, const float* img0, const float* img1, const float* img2, const float* gate0, const float* gate1,
                      const float* gate2, int ntapes, const void* wp, void* out, int B, int C, int H, int W, const eg_epilogue* ep,
                      int gate_act, float gate_slope, eg_stream_t s);

@@ -114,3 +114,46 @@ def test_transposed_image_convolution_in_one_launch(B, C, act, dtype):
     ref = F.conv_transpose2d(a.float().permute(0, 3, 1, 2), w.to(tdt).float(), bias, 2, 1)
     ref = torch.tanh(ref) if act else ref
     torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [1, 2])
+def test_input_gradient_with_batchnorm_backward_sums(dtype):
+    """the same launch also forms dy = da * relu'(bn(z)) and the two sums of the BatchNorm backward of the layer below (EG_STAT_BN_BWD):
+    dy / dz / dgamma / dbeta against the stand-alone kernels on the plain launch's output"""
+    B, C, S, N = 16, 3, 64, 128
+    g = torch.Generator().manual_seed(9)
+    tdt = ops.torch_dtype(dtype)
+    dimg = torch.randn(B, C, S, S, generator=g).to(DEV)
+    img = torch.tanh(torch.randn(B, C, S, S, generator=g)).to(DEV)
+    w = (torch.randn(N, C, 4, 4, generator=g) * 0.1).to(DEV)
+    wp = torch.empty(N * 64, device=DEV, dtype=tdt)
+    ops.pack_strided(dtype, w, wp, N, C * 16, 64, 1, C * 16, 0, 1)
+    M = B * (S // 2) ** 2
+    z = torch.randn(B, S // 2, S // 2, N, generator=g).to(DEV).to(tdt)
+    gamma, beta = (torch.randn(N, generator=g) * 0.1 + 1).to(DEV), (torch.randn(N, generator=g) * 0.3).to(DEV)
+    zf = z.float().reshape(M, N)
+    mean, istd = zf.mean(0).contiguous(), (zf.var(0, unbiased=False) + 1e-5).rsqrt().contiguous()
+    da = torch.empty(B, S // 2, S // 2, N, device=DEV, dtype=tdt)
+    dy = torch.empty_like(da)
+    ops.conv_img_mfma(dtype, [dimg], wp, da, B, C, S, S, None, gates=[img], gate_act=ops.ACT_TANH)
+    nrb = ops.conv_img_mfma_stat_blocks(B, S, S)
+    stat = torch.full((2 * N * nrb,), float("nan"), device=DEV)
+    ops.conv_img_mfma(dtype, [dimg], wp, dy, B, C, S, S, ops.epilogue(stat_mode=ops.STAT_BN_BWD, stat_out=stat, stat_aux=z, stat_p=(mean, istd, gamma, beta),
+                                                                    stat_act=ops.ACT_RELU), gates=[img], gate_act=ops.ACT_TANH)
+    torch.cuda.synchronize()
+    assert torch.isfinite(stat).all()
+    pre = zf * (gamma * istd) + (beta - mean * gamma * istd)
+    near = (pre.abs() < 1e-5).reshape(da.shape)
+    assert torch.equal(dy[~near], torch.where((pre > 0).reshape(da.shape), da, torch.zeros_like(da))[~near])
+    small = torch.empty(ops.bn_ws_floats(M, N), device=DEV)
+    res = {}
+    for k in ("plain", "fused"):
+        res[k] = dict(dz=torch.empty_like(da), dg=torch.zeros(N, device=DEV), db=torch.zeros(N, device=DEV), sums=torch.empty(2 * N, device=DEV))
+    ops.bn_bwd(dtype, z, da, res["plain"]["dz"], M, N, gamma, beta, mean, istd, ops.ACT_RELU, 0.0, res["plain"]["dg"], res["plain"]["db"], res["plain"]["sums"], small)
+    ops.bn_bwd_fused(dtype, z, dy, res["fused"]["dz"], M, N, stat, nrb, gamma, beta, mean, istd, res["fused"]["dg"], res["fused"]["db"], res["fused"]["sums"], small)
+    torch.cuda.synchronize()
+    scale = float(res["plain"]["sums"].abs().max())
+    for k in ("sums", "dg", "db"):
+        torch.testing.assert_close(res["fused"][k], res["plain"][k], rtol=1e-4, atol=1e-5 * scale)
+    diff = (res["fused"]["dz"].float() - res["plain"]["dz"].float()).abs()
+    assert float(diff.max()) <= 2.0 ** -7 * float(res["plain"]["dz"].float().abs().max()) and (diff > 0).float().mean() < 2e-2
