@@ -1875,7 +1875,7 @@ extern "C" int eg_conv_wgrad_target(const eg_conv* c, int dtype, const void* X, 
 // one contiguous run of 64*T floats.  MODE 0: out += a; MODE 1: out = a (gtmp) + <a,W> partials; MODE 2: out += a - rank1.
 #define EG_RC 64
 template <int MODE>
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int NS, int N, int C, int T,
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int NS, int N, int C, int T,
                                                            float* __restrict__ out, int accumulate, const float* __restrict__ w_orig,
                                                            float* __restrict__ partials, int ntapes, const float* __restrict__ coef,
                                                            const float* __restrict__ u, const float* __restrict__ v, int row_div, int row_mul, int c_row) {
@@ -1890,12 +1890,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         for (int q = 0; q < ntapes; ++q) un[q] = coef[q] * u[(size_t)q * N + n];
     const int crow = c_row ? c_row : C;                 // row length of the destination (<= C when the slab is column padded)
     const int nv = T * (EG_RC / 4);                     // float4 elements of a full tile
-    if (cw == EG_RC && c0 + EG_RC <= crow && (C & 3) == 0 && nv <= 64 && nsplit >= 16) {
-        // few taps, many splits (the image-side layers as 1x1 convolutions: T = 1, 128 splits): the tile has only nv <= 64 vectors, so the
-        // loop below would leave most of the block idle behind a chain of nsplit loads per thread.  Here 256 / nv thread groups each take
-        // every (256 / nv)-th split, eight loads in flight, and the groups are added in group order through LDS (deterministic).
-        __shared__ float4 part[256];
-        const int G = 256 / nv, e4 = threadIdx.x % nv, sg = threadIdx.x / nv;
+    const int NTH = blockDim.x;                          // 256, or 1024 for the many-split form (the host picks)
+    if (cw == EG_RC && c0 + EG_RC <= crow && (C & 3) == 0 && nv * 2 <= NTH && nsplit >= 16) {
+        // many splits of a small tile (the image-side layers as 1x1 convolutions: T = 1, 128 splits; the 32- and 64-channel layers of the
+        // small networks: one 64 x 16 tile per output channel, 128 splits): the loop below is a chain of nsplit loads per thread with most
+        // of the chip idle.  Here blockDim / nv thread groups each take every (blockDim / nv)-th split, eight loads in flight, and the
+        // groups are added in group order through LDS (deterministic).
+        __shared__ float4 part[1024];
+        const int G = NTH / nv, e4 = threadIdx.x % nv, sg = threadIdx.x / nv;
         const int t = e4 / (EG_RC / 4), c = (e4 % (EG_RC / 4)) * 4;
         const size_t si = ((size_t)n * T + t) * C + c0 + c;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1927,7 +1929,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         }
     } else if (cw == EG_RC && c0 + EG_RC <= crow && (C & 3) == 0) {
         // full 64-channel block: 16-byte loads along the channels (one float4 per thread and slab for k = 4), same summation order
-        for (int e4 = threadIdx.x; e4 < T * (EG_RC / 4); e4 += 256) {
+        for (int e4 = threadIdx.x; e4 < T * (EG_RC / 4); e4 += NTH) {
             const int t = e4 / (EG_RC / 4), c = (e4 % (EG_RC / 4)) * 4;
             const size_t si = ((size_t)n * T + t) * C + c0 + c;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1953,7 +1955,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             tile[c * (T + 1) + t] = a.x; tile[(c + 1) * (T + 1) + t] = a.y; tile[(c + 2) * (T + 1) + t] = a.z; tile[(c + 3) * (T + 1) + t] = a.w;
         }
     } else
-    for (int e = threadIdx.x; e < T * EG_RC; e += 256) {
+    for (int e = threadIdx.x; e < T * EG_RC; e += NTH) {
         const int t = e / EG_RC, c = e % EG_RC;
         if (c < cw && c0 + c < crow) {
             const size_t si = ((size_t)n * T + t) * C + c0 + c;
@@ -1969,7 +1971,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int nout = row_div ? (n % row_div) * row_mul + n / row_div : n;
     const size_t obase = ((size_t)nout * crow + c0) * T;
     const int cwo = min(cw, crow - c0);
-    for (int e = threadIdx.x; e < cwo * T; e += 256) {
+    for (int e = threadIdx.x; e < cwo * T; e += NTH) {
         const int c = e / T, t = e % T;
         const float a = tile[c * (T + 1) + t];
         if (MODE == 1) {
@@ -2001,11 +2003,16 @@ __global__ void sn_grad_apply_kernel(const float* __restrict__ gtmp, const float
 }
 
 static inline int reduce_blocks(int n_rows, int C) { return n_rows * ((C + EG_RC - 1) / EG_RC); }
+// threads per workgroup: 1024 (several split groups per tile vector) where a launch has many splits and few, small tiles
+static inline int reduce_threads(int nsplit, int n_rows, int C, int T) {
+    const int nv = T * (EG_RC / 4);
+    return (nsplit >= 16 && nv * 2 <= 1024 && nv * 2 > 256 && reduce_blocks(n_rows, C) <= 2048) ? 1024 : 256;
+}
 static inline size_t reduce_lds(int T) { return (size_t)EG_RC * (T + 1) * sizeof(float); }
 
 extern "C" int eg_wgrad_reduce(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad, int accumulate, eg_stream_t s) {
     EG_REQUIRE(slab && grad && nsplit > 0 && n_rows <= n_slab && T > 0 && T <= 64, "eg_wgrad_reduce: bad argument");
-    hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3(reduce_blocks(n_rows, C)), dim3(256), reduce_lds(T), (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T,
+    hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3(reduce_blocks(n_rows, C)), dim3(reduce_threads(nsplit, n_rows, C, T)), reduce_lds(T), (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T,
                        grad, accumulate, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0, 0);
     EG_LAUNCH_CHECK();
     return 0;
@@ -2013,7 +2020,7 @@ extern "C" int eg_wgrad_reduce(const float* slab, int nsplit, int n_slab, int n_
 
 extern "C" int eg_wgrad_reduce_perm(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad, int row_div, int row_mul, int c_row, eg_stream_t s) {
     EG_REQUIRE(slab && grad && nsplit > 0 && n_rows <= n_slab && T > 0 && T <= 64 && row_div >= 0 && c_row >= 0 && c_row <= C, "eg_wgrad_reduce_perm: bad argument");
-    hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3(reduce_blocks(n_rows, C)), dim3(256), reduce_lds(T), (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T,
+    hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3(reduce_blocks(n_rows, C)), dim3(reduce_threads(nsplit, n_rows, C, T)), reduce_lds(T), (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T,
                        grad, 1, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, row_div, row_mul, c_row);
     EG_LAUNCH_CHECK();
     return 0;
@@ -2023,7 +2030,7 @@ extern "C" int eg_wgrad_reduce_rank1(const float* slab, int nsplit, int n_slab, 
                                      const float* coef, const float* u, const float* v, int c_row, eg_stream_t s) {
     EG_REQUIRE(slab && grad && nsplit > 0 && n_rows <= n_slab && ntapes >= 0 && ntapes <= 4 && (ntapes == 0 || (coef && u && v)) && T > 0 && T <= 64,
                "eg_wgrad_reduce_rank1: bad argument");
-    hipLaunchKernelGGL(wgrad_reduce_kernel<2>, dim3(reduce_blocks(n_rows, C)), dim3(256), reduce_lds(T), (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T,
+    hipLaunchKernelGGL(wgrad_reduce_kernel<2>, dim3(reduce_blocks(n_rows, C)), dim3(reduce_threads(nsplit, n_rows, C, T)), reduce_lds(T), (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T,
                        grad, 1, (const float*)nullptr, (float*)nullptr, ntapes, coef, u, v, 0, 0, c_row);
     EG_LAUNCH_CHECK();
     return 0;
