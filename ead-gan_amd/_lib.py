@@ -19,7 +19,7 @@ EG_F32, EG_BF16, EG_F16 = 0, 1, 2
 ACT_NONE, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = range(5)
 OUT_NHWC, OUT_NCHW_F32 = 0, 1
 # eg_epilogue.nt_variant (include/eadgan_hip.h: EG_NT_*)
-NT_AUTO, NT_REG, NT_BUF128, NT_PERS, NT_S8, NT_S8P = range(6)
+NT_AUTO, NT_REG, NT_BUF128, NT_PERS, NT_S8, NT_S8P, NT_S8H = range(7)
 # eg_epilogue.stat_mode (EG_STAT_*): column statistics of the stored tile, fused into the convolution's epilogue
 STAT_NONE, STAT_MOMENTS, STAT_BN_BWD, STAT_SN_BIAS = range(4)
 

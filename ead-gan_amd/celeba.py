@@ -204,7 +204,7 @@ class _GenEngine:
             if nrb:
                 # BatchNorm batch statistics from the transposed convolution's epilogue: z is read once (apply) instead of twice
                 ops.conv_bwd_data(r.c, dt, x, r.wp_bwd, self.z[i], ops.epilogue(bias=self._p(idx, "bias"), stat_mode=ops.STAT_MOMENTS, stat_out=stat))
-                ops.bn_fwd_train_fused(dt, self.z[i], self.a[i], M, W[i + 1], stat, nrb, 256, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean,
+                ops.bn_fwd_train_fused(dt, self.z[i], self.a[i], M, W[i + 1], stat, nrb, M // nrb, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean,
                                        bn.running_var, bn.num_batches_tracked, self.mean[i], self.invstd[i], small, ACT_RELU)
                 x = self.a[i]
                 continue
@@ -635,8 +635,8 @@ class _DiscEngine:
             if need_wgrad:
                 def layer_wgrad(wsw, i=i, m=m, geo=geo, x_in=x_in, fused=fused):
                     if fused[0]:
-                        ops.bias_grad_sn_fused(fused[1], fused[0], W[i], T * self.rows(i + 1) // 256, self.rows(i + 1) // 256, T, self.sigma[i][t0:],
-                                               gof(f"main.{2 * i}.bias"), self.coef[i])
+                        tiles_m = fused[0] // 4         # row blocks (of 256 or 128 lattice rows: the kernel's tile height) per sub-pixel phase
+                        ops.bias_grad_sn_fused(fused[1], fused[0], W[i], tiles_m, tiles_m // T, T, self.sigma[i][t0:], gof(f"main.{2 * i}.bias"), self.coef[i])
                     else:
                         ops.bias_grad_sn(dt, sl(self.dz[i]), sl(self.a[i]), m.bias, T * self.rows(i), W[i], self.rows(i), self.sigma[i][t0:], LRELU_SLOPE,
                                          wsw.small, gof(f"main.{2 * i}.bias"), self.coef[i])

@@ -731,6 +731,7 @@ __global__ __launch_bounds__(256) void nt_splitk_epilogue_kernel(const NtParams 
 // ------------------------------------------------------------------------------------------------
 bool eg_nt8p_geometry(const NtParams& p, int nphase, Nt8pGeom& g);
 template <typename T> void eg_launch_nt8s(const NtParams& p, const Nt8pGeom& g, bool patch, int nphase, int ns, hipStream_t st);
+template <typename T> void eg_launch_nt8h(const NtParams& p, int nphase, int ns, hipStream_t st);
 
 struct NtPlan { int kind, ns; };
 
@@ -789,6 +790,9 @@ static NtPlan nt_plan(const NtParams& p, int nphase, int vec, size_t esize, size
         case EG_NT_S8:
             if (!f.dma_ok || !f.c_tiles) return bad;
             return {variant, nt_splits((long long)cdiv(p.M, 256) * (p.N / 128) * nphase, 224, f.nk_min, part256, ws_bytes, splitk)};
+        case EG_NT_S8H:
+            if (!f.dma_ok || !f.c_tiles) return bad;
+            return {variant, nt_splits(f.tiles128, 224, f.nk_min, part128, ws_bytes, splitk)};
         case EG_NT_AUTO: return nt_plan_auto(p, nphase, f, ws_bytes, splitk);
         default: return {-1, 1};
     }
@@ -810,6 +814,11 @@ static NtPlan nt_plan_auto(const NtParams& p, int nphase, const NtFacts& f, size
     static const bool all_s8 = [] { const char* e = getenv("EG_NT_AUTO_S8"); return !(e && atoi(e) == 0); }();
     // (16-bit launches of at least 48 such tiles: below that -- the small networks' layers -- and in fp32 the rule set below stays ahead,
     //  profiles/r02_r_ab_auto_s8.txt)
+    // fewer than ~200 tiles of 256 x 128 (the single-tape layers: 64 or 128 such tiles on 256 CUs): the same 8-wave design on 128 x 128
+    // tiles (igemm_nt8h) -- whole K loops in place of one K split level (profiles/r03_n_nt8h_layers.txt; EG_NT_AUTO_S8H=0: igemm_nt8s)
+    static const bool use_h = [] { const char* e = getenv("EG_NT_AUTO_S8H"); return !(e && atoi(e) == 0); }();
+    if (all_s8 && use_h && f.half && wgs256 >= 48 && wgs256 < 200 && f.nk_min >= 8)
+        return {EG_NT_S8H, nt_splits(f.tiles128, 224, f.nk_min, part128, ws_bytes, splitk)};
     if (all_s8 && f.half && wgs256 >= 48) return {EG_NT_S8, nt_splits(wgs256, 224, f.nk_min, part256, ws_bytes, splitk)};
     if (splitk <= 1 && f.nk_min >= 32 && wgs256 >= 200 && wgs256 * 100 >= rounds * 256 * 85) return {EG_NT_S8, 1};
     // split K only below one workgroup per CU: at 256..511 tiles the unsplit launch wins or ties (M=8192 N=512 K=4096: 52 vs 58 us,
@@ -866,6 +875,16 @@ static int launch_nt(const NtParams& p, int nphase, int variant, int splitk, hip
         q.split_cnt = (plan.ns > 1 && inkernel) ? reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.part) + p.part_bytes - EG_SPLIT_CNT_BYTES) : nullptr;
         eg_launch_nt8s<T>(q, g, plan.kind == EG_NT_S8P, nphase, plan.ns, st);      // K splits are reduced inside the launch (last-arriving workgroup)
         if (plan.ns > 1 && !inkernel) launch_splitk_epilogue<T>(q, nphase, cdiv(p.M, 256) * 256, st);
+        return 0;
+    }
+    if (plan.kind == EG_NT_S8H) {
+        NtParams q = p;
+        q.nsplit = plan.ns;
+        q.xcd_remap = xcd;
+        q.stat_nrb = stat_nrb;
+        EG_REQUIRE(plan.ns == 1 || nt_split_inkernel(), "igemm_nt8h reduces its K splits inside the launch only (EG_NT_SPLIT_INKERNEL=0 is an igemm_nt8s experiment)");
+        q.split_cnt = plan.ns > 1 ? reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.part) + p.part_bytes - EG_SPLIT_CNT_BYTES) : nullptr;
+        eg_launch_nt8h<T>(q, nphase, plan.ns, st);
         return 0;
     }
     if (plan.kind == EG_NT_PERS) {
@@ -950,6 +969,7 @@ extern "C" int eg_igemm_nt_tile(const eg_conv* c, int dtype, int bwd, int varian
     if (plan.kind < 0) return -1;
     if (plan.kind == EG_NT_S8) return 256 * 1000 + (plan.ns > 1 ? 148 : 147);
     if (plan.kind == EG_NT_S8P) return 256 * 1000 + (plan.ns > 1 ? 150 : 149);
+    if (plan.kind == EG_NT_S8H) return 128 * 1000 + (plan.ns > 1 ? 152 : 151);
     if (plan.kind == EG_NT_PERS) return 128 * 1000 + 135;
     if (plan.kind == EG_NT_BUF128) return 128 * 1000 + (plan.ns > 1 ? 132 : 131);
     const int M = p.M, N = p.N;
@@ -988,7 +1008,9 @@ static bool nt_split_inkernel() {
     return inkernel;
 }
 static int nt_stat_blocks(const NtParams& p, int nphase, const NtPlan& plan, bool half) {
-    if (plan.kind != EG_NT_S8 || !half || (p.M % 256) != 0 || p.out_mode != EG_OUT_NHWC) return 0;
+    if (!half || p.out_mode != EG_OUT_NHWC) return 0;
+    if (plan.kind == EG_NT_S8H) return (p.M % 128) == 0 ? nphase * (p.M / 128) : 0;          // row blocks of 128
+    if (plan.kind != EG_NT_S8 || (p.M % 256) != 0) return 0;
     if (plan.ns > 1 && !nt_split_inkernel()) return 0;
     return nphase * (p.M / 256);
 }
@@ -1059,6 +1081,7 @@ extern "C" int eg_igemm_nt_tile_ep(const eg_conv* c, int dtype, int bwd, const e
     if (plan.kind < 0) return -1;
     if (plan.kind == EG_NT_S8) return 256 * 1000 + (plan.ns > 1 ? 148 : 147);
     if (plan.kind == EG_NT_S8P) return 256 * 1000 + (plan.ns > 1 ? 150 : 149);
+    if (plan.kind == EG_NT_S8H) return 128 * 1000 + (plan.ns > 1 ? 152 : 151);
     if (plan.kind == EG_NT_PERS) return 128 * 1000 + 135;
     if (plan.kind == EG_NT_BUF128) return 128 * 1000 + (plan.ns > 1 ? 132 : 131);
     const int M = p.M, N = p.N;

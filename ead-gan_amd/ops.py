@@ -11,7 +11,7 @@ import os
 import torch
 
 from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, EG_BF16, EG_F16, EG_F32, NT_AUTO, NT_BUF128,
-                   NT_PERS, NT_REG, NT_S8, NT_S8P, OUT_NCHW_F32, OUT_NHWC, STAT_BN_BWD, STAT_MOMENTS, STAT_NONE, STAT_SN_BIAS, EgConv, EgEpilogue,
+                   NT_PERS, NT_REG, NT_S8, NT_S8H, NT_S8P, OUT_NCHW_F32, OUT_NHWC, STAT_BN_BWD, STAT_MOMENTS, STAT_NONE, STAT_SN_BIAS, EgConv, EgEpilogue,
                    EgRngSeg, EgSnLayer, lib)
 
 __all__ = ["EG_F32", "EG_BF16", "EG_F16", "ACT_NONE", "ACT_LRELU", "ACT_RELU", "ACT_TANH", "ACT_SIGMOID", "OUT_NHWC",
@@ -151,7 +151,8 @@ def _timed(kind, c, dtype, args, ep=None):
         label = {131: f"igemm_nt_buf_kernel<{tname}>", 132: f"igemm_nt_buf_kernel<{tname}>+splitk",
                  135: f"igemm_nt_pers_kernel<{tname}>",
                  147: f"igemm_nt8s_kernel<{tname},im2col>", 148: f"igemm_nt8s_kernel<{tname},im2col>+splitk",
-                 149: f"igemm_nt8s_kernel<{tname},patch>", 150: f"igemm_nt8s_kernel<{tname},patch>+splitk"}.get(bn, f"igemm_nt_kernel<{tname},{bm},{bn}>")
+                 149: f"igemm_nt8s_kernel<{tname},patch>", 150: f"igemm_nt8s_kernel<{tname},patch>+splitk",
+                 151: f"igemm_nt8h_kernel<{tname}>", 152: f"igemm_nt8h_kernel<{tname}>+splitk"}.get(bn, f"igemm_nt_kernel<{tname},{bm},{bn}>")
         nbytes = (x_elems + y_elems + w_elems) * es
         if ep is not None and ep.mask:
             nbytes += (x_elems if kind == "bwd" else y_elems) * es

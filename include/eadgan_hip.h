@@ -99,6 +99,7 @@ enum { EG_STAT_NONE = 0, EG_STAT_MOMENTS = 1, EG_STAT_BN_BWD = 2, EG_STAT_SN_BIA
 #define EG_NT_BUF128 2   /* 128 x 128, 4 waves (two workgroups per CU), 2-stage buffer-descriptor LDS-DMA ring */
 #define EG_NT_PERS 3     /* persistent 128 x 128 pipeline (1-2-step image-side layers) */
 #define EG_NT_S8 4       /* 256 x 128, 8 waves, 3-K-tile LDS-DMA ring, one barrier per K tile, fragments double-buffered in registers */
+#define EG_NT_S8H 6      /* the 8-wave design on 128 x 128 tiles (waves 4 x 2, wave tile 32 x 64), ring of four K tiles: launches with too few 256-row tiles */
 #define EG_NT_S8P 5      /* the same with the A operand held in LDS as an input patch shared by the filter taps of a class: 2.6-3.5x
                           * fewer A bytes through the LDS-DMA path; K is accumulated class by class (deterministic, not bit-identical
                           * to the tap-major variants) */
@@ -122,7 +123,7 @@ int eg_conv_bwd_data(const eg_conv* c, int dtype, const void* dY, const void* wp
 /* which kernel eg_conv_fwd (bwd = 0) / eg_conv_bwd_data (bwd = 1) runs this problem on under the given hints (same planner as the
  * launches, unlimited split-K scratch): BM * 1000 + code; code = BN of the register-staged kernels, 131 / 132 = 128 x 128
  * buffer-descriptor kernel (plain / split-K), 135 = persistent pipeline, 147 / 148 = igemm_nt8s (plain / split-K), 149 / 150 =
- * igemm_nt8s with the input patch; -1 = the forced variant cannot run the problem.  Profiling labels and tests. */
+ * igemm_nt8s with the input patch, 151 / 152 = igemm_nt8h (plain / split-K); -1 = the forced variant cannot run the problem.  Profiling labels and tests. */
 int eg_igemm_nt_tile(const eg_conv* c, int dtype, int bwd, int variant, int splitk);
 /* the same for ONE concrete call: the epilogue's kernel hints and ITS split-K scratch (what the launch itself will do) */
 int eg_igemm_nt_tile_ep(const eg_conv* c, int dtype, int bwd, const eg_epilogue* ep);

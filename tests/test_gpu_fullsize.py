@@ -83,7 +83,8 @@ def test_celeba_b128(dtype):
     labels = nt_labels(launches, dt)
     # igemm_nt8s and the 128 x 128 buffer-descriptor kernel (plain and, in the 16-bit modes, with a K split; fp32 K loops are twice
     # as many K tiles long and fill the chip without)
-    assert ({147, 148} if dtype == "bf16" else {147}) <= labels, labels           # 148: the 8-wave kernel with K splits (512 -> 1024 at T = 1)
+    # 147 / 148: igemm_nt8s (plain / K splits); 151 / 152: the same design on 128 x 128 tiles (igemm_nt8h) for the single-tape layers
+    assert 147 in labels and (dtype != "bf16" or labels & {148, 151, 152}), labels
     assert not labels & {16, 32, 64, 128}, labels     # nothing of this falls back to the register-staged kernels
     # the weight-gradient GEMMs split M over workgroups at this size
     assert all(ops.conv_wgrad_ws_bytes(c, dt) > 0 for c, _ in launches)
@@ -186,7 +187,7 @@ def test_celeba_b128_bf16_layerwise_kernels():
         r, m = de.mid[i], de._m(i + 1)
         Wq = bq(m.weight_orig)
         assert ops.conv_wgrad_variant(de.geo[3]["mid"][i], dt) == 2               # the parity-class kernel
-        assert ops.nt_tile(de.geo[3]["mid"][i], dt, False) % 1000 in (147, 148) and ops.nt_tile(de.geo[3]["mid"][i], dt, True) % 1000 in (147, 148)
+        assert ops.nt_tile(de.geo[3]["mid"][i], dt, False) % 1000 in (147, 148, 151, 152) and ops.nt_tile(de.geo[3]["mid"][i], dt, True) % 1000 in (147, 148, 151, 152)
         gw_ref = torch.zeros_like(Wq)
         for t in range(3):
             sl = slice(t * B, (t + 1) * B)
