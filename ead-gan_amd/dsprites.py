@@ -651,7 +651,7 @@ class DspritesTrainer(ResidentStep):
 
     def import_adam_state(self, opt_D, opt_info):
         """moments and step counts of the two ``torch.optim.Adam`` the reference steps (dSprites/rp.py:270-279: D | G + E parameters,
-        ``.parameters()`` order) -- teacher-forced comparisons against the oracle"""
+        ``.parameters()`` order) -- teacher-forced comparisons against a CPU run of the reference loop"""
         from .engine import import_adam_moments
         n = lambda mod: len(list(mod.parameters()))
         s0 = import_adam_moments(opt_D, [(n(self.D), self.mD, self.vD)])

@@ -127,7 +127,7 @@ class Workspace:
         self._grow("sums", floats)
 
 
-LANE_WGS_TARGET = int(os.environ.get("EG_LANE_WGS", "128"))
+LANE_WGS_TARGET = int(os.environ.get("EG_LANE_WGS", "64"))      # 64: profiles/r03_o_lane_wgs_sweep.txt (128 in round 2)
 
 
 class _Lane:

@@ -482,7 +482,7 @@ class MnistTrainer(ResidentStep):
 
     def import_adam_state(self, opt_G, opt_D, opt_info):
         """moments and step counts of three ``torch.optim.Adam`` built like the reference's (MNIST/EAD-GAN_rpqmnxy.py:206-217: G | D | G + E
-        parameters, ``.parameters()`` order) -- teacher-forced comparisons against the oracle"""
+        parameters, ``.parameters()`` order) -- teacher-forced comparisons against a CPU run of the reference loop"""
         from .engine import import_adam_moments
         n = lambda mod: len(list(mod.parameters()))
         s0 = import_adam_moments(opt_G, [(n(self.G), self.mG, self.vG)])
