@@ -929,6 +929,7 @@ BATCH_D12 = os.environ.get("EG_BATCH_D12", "0") != "0"
 # optimizer updates bucket by bucket (each bucket behind its own weight-gradient chain) instead of one update behind all chains: "0" never,
 # "1" every update, "3" the info step's two, or a comma list of g1 (generator step), d2 (discriminator step), d3, g3 (info step: D, then G)
 # data parallel: gradient buckets that cross the links as one message, in completion order (contiguous in the arenas)
+ZERO_ON_PREP = os.environ.get("EG_ZERO_ON_PREP", "1") != "0"     # gradient zeroing of steps 1 / 2 on the preparation lane (0: on the main stream)
 SPLIT2_SET = set(filter(None, os.environ.get("EG_SPLIT2", "").split(",")))      # updates done in two pieces (early layers / rest): g1, d2, d3, g3
 DP_START = os.environ.get("EG_DP_START", "lane")
 COMM_GROUPS = {"G": (("G4", "G3", "G2"), ("G1", "G0")), "D": (("D4", "D3"), ("D2", "D1", "D0"))}
@@ -1254,9 +1255,15 @@ class CelebATrainer:
                 de._im2col_tape(0, self.scaled)
             else:
                 de._sn_tape(2)
+            # optimizer.zero_grad() of the generator and discriminator steps (the last updates of an iteration leave their gradients in
+            # place: callers and tests read them): here, beside the generator forward -- the first gradient write is a backward pass away
+            if ZERO_ON_PREP:
+                ops.fill_f32(ga.grad)
+                ops.fill_f32(da.grad)
             evs["sn1"] = side.mark()
         side.defer_prep(sn1)
-        ops.fill_f32(ga.grad)
+        if not ZERO_ON_PREP:
+            ops.fill_f32(ga.grad)
         gen = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
         side.wait(evs["sn1"])
         if BATCH_D12:
@@ -1283,7 +1290,8 @@ class CelebATrainer:
                 ge.forward(self.z, self.onehot, self.code, ws=self.g3_ws)
                 evs["g3fwd"] = side.mark()
         # ---- 2) discriminator step (:353-366); gen is the (detached) output of step 1; D(scaled) then D(gen), batched ----
-        ops.fill_f32(da.grad)
+        if not ZERO_ON_PREP:
+            ops.fill_f32(da.grad)
         side.flush()
         if BATCH_D12:
             out = out12
