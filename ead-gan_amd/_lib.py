@@ -49,6 +49,18 @@ class EgRngSeg(ctypes.Structure):
                 ("stream_id", ctypes.c_uint), ("onehot", ctypes.c_void_p), ("onehot_n", ctypes.c_int)]
 
 
+class EgHead(ctypes.Structure):
+    _fields_ = [("x", ctypes.c_void_p), ("wp", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("partials", ctypes.c_void_p), ("nslice", ctypes.c_int),
+                ("y", ctypes.c_void_p), ("dout", ctypes.c_void_p),
+                ("dx", ctypes.c_void_p), ("sigma", ctypes.c_void_p),
+                ("B", ctypes.c_int), ("T", ctypes.c_int), ("K", ctypes.c_int), ("Kpad", ctypes.c_int), ("N", ctypes.c_int), ("mode", ctypes.c_int),
+                ("target", ctypes.c_float * 3), ("scale", ctypes.c_float * 3),
+                ("c_cont", ctypes.c_int), ("n_cont", ctypes.c_int), ("n_cat", ctypes.c_int), ("code", ctypes.c_void_p), ("ldc", ctypes.c_int),
+                ("labels", ctypes.c_void_p), ("lcat", ctypes.c_float), ("lcon", ctypes.c_float), ("laff", ctypes.c_float),
+                ("loss", ctypes.c_void_p), ("terms", ctypes.c_void_p), ("counter", ctypes.c_void_p), ("mask_act", ctypes.c_int),
+                ("mask_slope", ctypes.c_float)]
+
+
 _SCALARS = {"int": ctypes.c_int, "float": ctypes.c_float, "size_t": ctypes.c_size_t,
             "long long": ctypes.c_longlong, "unsigned long long": ctypes.c_ulonglong, "unsigned int": ctypes.c_uint,
             "eg_stream_t": ctypes.c_void_p}

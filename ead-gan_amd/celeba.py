@@ -42,6 +42,10 @@ FUSE_STATS = os.environ.get("EG_FUSE_STATS", "1") != "0"
 
 # optimizer.step() of a convolution weight and the refresh of its packed panels as ONE launch per layer (ops.adam_pack_conv / adam_pack_rows);
 # 0: one Adam launch over the arena (or bucket) followed by the re-packing launches (A/B runs; same bits either way)
+# the discriminator's head with the sub-step's losses and the head's input gradient in two launches (K-sliced dense head; eg_head_fused: slice
+# combine + losses + dense backward, the affine term's Jacobian spread over lanes) instead of four or five on the main chain; same bits;
+# EG_FUSE_HEAD=0: the separate launches
+FUSE_HEAD = os.environ.get("EG_FUSE_HEAD", "1") != "0"
 FUSE_ADAM = os.environ.get("EG_FUSE_ADAM", "1") != "0"
 # ... per optimizer update of the pipelined step (g1, d2, d3, g3 as in EG_BUCKET_OPT; "all")
 FUSE_ADAM_AT = os.environ.get("EG_FUSE_ADAM_AT", "g3")
@@ -476,6 +480,7 @@ class _DiscEngine:
         self.out = torch.empty(NT * B, self.nout, device=dev, dtype=torch.float32)
         self.dz = [torch.empty_like(t) for t in self.a]
         self.dout_t = torch.empty(NT * B, 32, device=dev, dtype=tdt)
+        self._head_scratch = None                       # head_losses: per-sample loss terms + arrival counter
         self.dimg = torch.empty(B, C, S, S, device=dev, dtype=torch.float32)
         kd = [self.kp] + [W[i] * 16 for i in range(3)]
         self.sigma = [torch.ones(NT, device=dev, dtype=torch.float32) for _ in range(4)]
@@ -568,8 +573,9 @@ class _DiscEngine:
             if img is not None:
                 self._im2col_tape(t0 + k, img)
 
-    def forward(self, imgs, t0=0, training=True, prepared=None):
+    def forward(self, imgs, t0=0, training=True, prepared=None, head=True):
         """Runs len(imgs) forwards as tapes t0.. (power iterations in list order, like consecutive D(...) calls).
+        ``head=False``: stop in front of the head (``head_losses`` runs it together with the losses).
         ``prepared``: per-tape flags of a preceding ``prepare`` call (power iterations done for all tapes, patch rows done where
         the flag is set).  Returns the head outputs [len(imgs)*B, 19] (a view of the tape buffer)."""
         dt, B, W, ws = self.dtype, self.B, D_WIDTHS, self.ws
@@ -597,10 +603,30 @@ class _DiscEngine:
             ops.conv_fwd(g["mid"][i], dt, sl(self.a[i], i), self.mid[i].wp_fwd, sl(self.a[i + 1], i + 1), ep(i + 1))
         K = 16 * W[3]
         out = self.out[t0 * B:(t0 + T) * B]
-        ops.dense_small_fwd(dt, sl(self.a[3], 3), self.head.wp_fwd, self._m(4).bias, out, T * B, K, self.head.Kpad_fwd, self.nout, ws.small)
+        if head:
+            ops.dense_small_fwd(dt, sl(self.a[3], 3), self.head.wp_fwd, self._m(4).bias, out, T * B, K, self.head.Kpad_fwd, self.nout, ws.small)
         return out
 
-    def backward(self, t0, T, dout, grad, need_wgrad=True, need_dimg=False, side=None):
+    def head_fused_ok(self, T):
+        return FUSE_HEAD and ops.head_fused_ok(self.dtype, T, 16 * D_WIDTHS[3], self.nout)
+
+    def head_losses(self, t0, T, dout, loss, targets=None, scales=None, info=None):
+        """The head of tapes t0..t0+T-1 (after ``forward(..., head=False)``), their losses (added to ``loss[0]``), ``dout`` = d(loss)/d(head
+        output) and the head's input gradient dzs_3 -- ``backward(..., head_done=True)`` continues from there -- in TWO launches (the K-sliced
+        dense head; slice combine + losses + dense backward) with the bits of the five they replace."""
+        B, K = self.B, 16 * D_WIDTHS[3]
+        sl = lambda buf: buf[t0 * (buf.shape[0] // self.NT):]
+        if self._head_scratch is None:
+            self._head_scratch = (torch.empty(3 * B, device=self.out.device, dtype=torch.float32),
+                                  torch.zeros(1, device=self.out.device, dtype=torch.int32))
+        terms, counter = self._head_scratch
+        out = self.out[t0 * B:(t0 + T) * B]
+        ns = ops.dense_small_fwd_slices(self.dtype, sl(self.a[3]), self.head.wp_fwd, T * B, K, self.head.Kpad_fwd, self.nout, self.ws.small)
+        ops.head_fused(self.dtype, sl(self.a[3]), self.head.wp_fwd, self._m(4).bias, self.ws.small, ns, out, dout, sl(self.dz[3]), self.sigma[3][t0:],
+                       B, T, K, self.head.Kpad_fwd, self.nout, loss, terms, counter, ACT_LRELU, LRELU_SLOPE, targets=targets, scales=scales, info=info)
+        return out
+
+    def backward(self, t0, T, dout, grad, need_wgrad=True, need_dimg=False, side=None, head_done=False):
         """``dout``: d(loss)/d(head output) of tapes t0..t0+T-1, [T*B,19] fp32.  Accumulates into flat ``grad`` (arena
         layout); returns d(loss)/d(img) of tape t0 when ``need_dimg``.  With ``side`` (engine.SideStream) the weight- and
         bias-gradient work is enqueued there (see _GenEngine.backward); the caller joins before it reads ``grad``."""
@@ -624,8 +650,9 @@ class _DiscEngine:
                 ops.dense_small_bgrad(dout, gof("main.8.bias"), T * B, self.nout)
             wgrad_side(head_wgrad, 0, "D4")
         # dzs_3 = (W5^T dout) * lrelu'(a3) / sigma_3[tape]
-        ops.dense_small_bwd(dt, dout, self.head.wp_fwd, sl(self.a[3]), sl(self.dz[3]), T * B, K, self.head.Kpad_fwd, self.nout, ACT_LRELU, LRELU_SLOPE,
-                            self.sigma[3][t0:], B)
+        if not head_done:
+            ops.dense_small_bwd(dt, dout, self.head.wp_fwd, sl(self.a[3]), sl(self.dz[3]), T * B, K, self.head.Kpad_fwd, self.nout, ACT_LRELU, LRELU_SLOPE,
+                                self.sigma[3][t0:], B)
         flush()
         fused = (0, None)                               # (row blocks, sums) if dzs_i came with its column sums
         for i in (3, 2, 1, 0):
@@ -1063,6 +1090,8 @@ class CelebATrainer:
         ga, da = G.arena, D.arena
         cd, nc = G.code_dim, G.n_classes
         lcat, lcon, laff = self.lam
+        fh1 = not BATCH_D12 and de.head_fused_ok(2)      # head + losses + head backward in one launch (steps 1 and 2)
+        fh3 = de.head_fused_ok(3) and cd >= 5            # ... of the info step
         self._inputs_head()
         # ---- 1) generator adversarial step (:334-345) ----
         ops.fill_f32(ga.grad)
@@ -1071,30 +1100,39 @@ class CelebATrainer:
             out12 = self._forward_d12(gen)
             out = out12[2 * B:]
         else:
-            out = de.forward([gen], 2)
-        ops.loss_bce_sigmoid(out, 19, 0, B, 1.0, 1.0, self.losses[0:1], self.dout[2 * B:])
-        dimg = de.backward(2, 1, self.dout[2 * B:], da.grad, need_wgrad=False, need_dimg=True)
+            out = de.forward([gen], 2, head=not fh1)
+        if fh1:
+            de.head_losses(2, 1, self.dout[2 * B:], self.losses[0:1], targets=(1.0,), scales=(1.0,))
+        else:
+            ops.loss_bce_sigmoid(out, 19, 0, B, 1.0, 1.0, self.losses[0:1], self.dout[2 * B:])
+        dimg = de.backward(2, 1, self.dout[2 * B:], da.grad, need_wgrad=False, need_dimg=True, head_done=fh1)
         ge.backward(dimg, ga.grad, None, sync=self.sync_bn)
         self._reduce(ga.grad)
         self._adam(ga, self.mG, self.vG, self.lr[0], 0, True)
         # ---- 2) discriminator step (:353-366); gen is the (detached) output of step 1; D(scaled) then D(gen), batched ----
         ops.fill_f32(da.grad)
-        out = out12 if BATCH_D12 else de.forward([self.scaled, gen], 0)
-        ops.loss_bce_sigmoid(out[:B], 19, 0, B, 1.0, 0.5, self.losses[1:2], self.dout[:B])
-        ops.loss_bce_sigmoid(out[B:], 19, 0, B, 0.0, 0.5, self.losses[1:2], self.dout[B:2 * B])
-        de.backward(0, 2, self.dout[:2 * B], da.grad)
+        out = out12 if BATCH_D12 else de.forward([self.scaled, gen], 0, head=not fh1)
+        if fh1:
+            de.head_losses(0, 2, self.dout[:2 * B], self.losses[1:2], targets=(1.0, 0.0), scales=(0.5, 0.5))
+        else:
+            ops.loss_bce_sigmoid(out[:B], 19, 0, B, 1.0, 0.5, self.losses[1:2], self.dout[:B])
+            ops.loss_bce_sigmoid(out[B:], 19, 0, B, 0.0, 0.5, self.losses[1:2], self.dout[B:2 * B])
+        de.backward(0, 2, self.dout[:2 * B], da.grad, head_done=fh1)
         self._reduce(da.grad)
         self._adam(da, self.mD, self.vD, self.lr[1], 1, True)
         ops.fill_f32(da.grad)
         # ---- 3) info + affine step (:375-401): D(gen), D(scaled), D(real) batched as tapes 0,1,2 ----
         ops.fill_f32(ga.grad)
         gen = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
-        out = de.forward([gen, self.scaled, self.real], 0)
-        o_gen, o_trans, o_real = out[:B], out[B:2 * B], out[2 * B:]
-        ops.loss_mse(o_gen, 19, 1, cd, B, self.code, cd, 0.0, lcon, self.losses[2:3], self.dout[:B])
-        ops.loss_ce_softmaxed(o_gen, 19, cd + 1, nc, B, self.labels, lcat, self.losses[2:3], self.dout[:B])
-        ops.loss_affine_rpqxy(o_real, o_trans, 19, 1, B, self.code, cd, laff, self.losses[2:3], self.dout[2 * B:], self.dout[B:2 * B])
-        dimg = de.backward(0, 3, self.dout, da.grad, need_dimg=True)
+        out = de.forward([gen, self.scaled, self.real], 0, head=not fh3)
+        if fh3:
+            de.head_losses(0, 3, self.dout, self.losses[2:3], info=(1, cd, nc, self.code, self.labels, lcat, lcon, laff))
+        else:
+            o_gen, o_trans, o_real = out[:B], out[B:2 * B], out[2 * B:]
+            ops.loss_mse(o_gen, 19, 1, cd, B, self.code, cd, 0.0, lcon, self.losses[2:3], self.dout[:B])
+            ops.loss_ce_softmaxed(o_gen, 19, cd + 1, nc, B, self.labels, lcat, self.losses[2:3], self.dout[:B])
+            ops.loss_affine_rpqxy(o_real, o_trans, 19, 1, B, self.code, cd, laff, self.losses[2:3], self.dout[2 * B:], self.dout[B:2 * B])
+        dimg = de.backward(0, 3, self.dout, da.grad, need_dimg=True, head_done=fh3)
         ge.backward(dimg, ga.grad, None, sync=self.sync_bn)
         self._reduce(da.grad)
         self._reduce(ga.grad)
@@ -1115,6 +1153,8 @@ class CelebATrainer:
         side = self.side
         side.begin_step()
         evs = {}
+        fh1 = not BATCH_D12 and de.head_fused_ok(2)      # head + losses + head backward in one launch (steps 1 and 2)
+        fh3 = de.head_fused_ok(3) and cd >= 5            # ... of the info step
 
         ar = self.allreduce
         ar_async = ar is not None and hasattr(ar, "start")
@@ -1270,15 +1310,18 @@ class CelebATrainer:
             out12 = self._forward_d12(gen, prepared=True)
             out = out12[2 * B:]
         else:
-            out = de.forward([gen], 2, prepared=(False,))
+            out = de.forward([gen], 2, prepared=(False,), head=not fh1)
 
             def prep2(_ws):                             # step 2's power iterations (after step 1's in the u/v chain) and patch rows
                 de.prepare(0, [self.scaled, gen])
                 evs["prep2"] = side.mark()
             side.defer_prep(prep2)
-        ops.loss_bce_sigmoid(out, 19, 0, B, 1.0, 1.0, self.losses[0:1], self.dout[2 * B:])
+        if fh1:
+            de.head_losses(2, 1, self.dout[2 * B:], self.losses[0:1], targets=(1.0,), scales=(1.0,))
+        else:
+            ops.loss_bce_sigmoid(out, 19, 0, B, 1.0, 1.0, self.losses[0:1], self.dout[2 * B:])
         side.flush()
-        dimg = de.backward(2, 1, self.dout[2 * B:], da.grad, need_wgrad=False, need_dimg=True)
+        dimg = de.backward(2, 1, self.dout[2 * B:], da.grad, need_wgrad=False, need_dimg=True, head_done=fh1)
         ge.backward(dimg, ga.grad, side, sync=self.sync_bn)
         update(ga, self.mG, self.vG, self.lr[0], 0, True, True, ge, key="g", where="g1")                # beside the whole of step 2
         if self.g3_early:
@@ -1297,10 +1340,13 @@ class CelebATrainer:
             out = out12
         else:
             side.wait(evs["prep2"])
-            out = de.forward([self.scaled, gen], 0, prepared=(True, True))
-        ops.loss_bce_sigmoid(out[:B], 19, 0, B, 1.0, 0.5, self.losses[1:2], self.dout[:B])
-        ops.loss_bce_sigmoid(out[B:], 19, 0, B, 0.0, 0.5, self.losses[1:2], self.dout[B:2 * B])
-        de.backward(0, 2, self.dout[:2 * B], da.grad, side=side)
+            out = de.forward([self.scaled, gen], 0, prepared=(True, True), head=not fh1)
+        if fh1:
+            de.head_losses(0, 2, self.dout[:2 * B], self.losses[1:2], targets=(1.0, 0.0), scales=(0.5, 0.5))
+        else:
+            ops.loss_bce_sigmoid(out[:B], 19, 0, B, 1.0, 0.5, self.losses[1:2], self.dout[:B])
+            ops.loss_bce_sigmoid(out[B:], 19, 0, B, 0.0, 0.5, self.losses[1:2], self.dout[B:2 * B])
+        de.backward(0, 2, self.dout[:2 * B], da.grad, side=side, head_done=fh1)
         g3_first = os.environ.get("EG_G3_FIRST", "0") != "0"
         keep = side.deferred
         if g3_first:
@@ -1320,11 +1366,14 @@ class CelebATrainer:
             gen = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
         side.deferred = keep
         side.join()                                     # D's panels, power iterations, patch rows
-        out = de.forward([gen, self.scaled, self.real], 0, prepared=(False, True, True))
-        o_gen, o_trans, o_real = out[:B], out[B:2 * B], out[2 * B:]
-        ops.loss_info_rpqxy(o_gen, o_trans, o_real, 19, 1, cd, nc, B, self.code, cd, self.labels, lcat, lcon, laff, self.losses[2:3], self.dout[:B],
-                            self.dout[B:2 * B], self.dout[2 * B:])               # the three losses in one launch
-        dimg = de.backward(0, 3, self.dout, da.grad, need_dimg=True, side=side)
+        out = de.forward([gen, self.scaled, self.real], 0, prepared=(False, True, True), head=not fh3)
+        if fh3:
+            de.head_losses(0, 3, self.dout, self.losses[2:3], info=(1, cd, nc, self.code, self.labels, lcat, lcon, laff))
+        else:
+            o_gen, o_trans, o_real = out[:B], out[B:2 * B], out[2 * B:]
+            ops.loss_info_rpqxy(o_gen, o_trans, o_real, 19, 1, cd, nc, B, self.code, cd, self.labels, lcat, lcon, laff, self.losses[2:3], self.dout[:B],
+                                self.dout[B:2 * B], self.dout[2 * B:])           # the three losses in one launch
+        dimg = de.backward(0, 3, self.dout, da.grad, need_dimg=True, side=side, head_done=fh3)
         # D's update beside the generator backward; it ticks optimizer_info's counter (shared by both arenas), G's does not
         update(da, self.miD, self.viD, self.lr[2], 2, True, False, de, where="d3")
         ge.backward(dimg, ga.grad, side, sync=self.sync_bn)

@@ -296,6 +296,222 @@ extern "C" int eg_loss_info_rpqxy(const float* o_gen, const float* o_trans, cons
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// eg_head_fused (ABI header): slice sums of the dense head -> head output -> losses -> head input gradient, one launch.
+// Grid (B, KS): workgroup (b, ks) owns sample index b -- the T rows t*B + b -- and K range ks of the input gradient; every workgroup of
+// a sample adds the slices and evaluates the (cheap) losses itself, the ks = 0 one stores y / dout and the sample's loss terms.
+// The per-sample arithmetic is that of dense_small_combine_kernel, bce_sigmoid_kernel / mse_body / ce_softmaxed_body /
+// affine_reg_rpqxy_body and dense_small_bwd_kernel (small.hip: n = 0..N-1 in order, one fma per term): the same bits as the separate
+// launches.  The affine term's forward-mode Jacobian runs one derivative component per lane (Dual<1> on ten lanes instead of Dual<10> on
+// one: each component's arithmetic is independent of the others, so the values are the same) -- the one-thread form was a 20 us chain.
+// The batch sums are taken by the last ks = 0 workgroup to arrive, in the thread order of the stand-alone loss kernels (thread i owns
+// samples i, i + 256, ...; affine: i, i + 128, ...).  Hand-off: terms are written through (agent-scope stores), vmcnt(0), relaxed counter.
+// ------------------------------------------------------------------------------------------------------------------------
+template <typename E, int T, int N>
+__global__ __launch_bounds__(512) void head_fused_kernel(const eg_head h) {
+    constexpr int VEC = Elt<E>::VEC;
+    constexpr int NTH = 512;
+    __shared__ float ys[T][32], dl[T][32];
+    __shared__ float sm[16];
+    __shared__ unsigned flag;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int B = h.B, K = h.K;
+    const bool first = blockIdx.y == 0;
+    const E* __restrict__ x = reinterpret_cast<const E*>(h.x);
+    const E* __restrict__ wp = reinterpret_cast<const E*>(h.wp);
+
+    // ---- 1) y[t][n] = sum of the K slices (slice order) + bias ----
+    if (tid < T * 32) {
+        const int t = tid >> 5, n = tid & 31;
+        float tot = 0.f;
+        if (n < N) {
+            const size_t i = ((size_t)t * B + b) * N + n;
+            for (int z = 0; z < h.nslice; ++z) tot += h.partials[(size_t)z * (T * B) * N + i];
+            tot = tot + (h.bias ? h.bias[n] : 0.f);
+            if (first) h.y[i] = tot;
+        }
+        ys[t][n] = tot;
+        dl[t][n] = 0.f;
+    }
+    __syncthreads();
+
+    // ---- 2) d(loss)/d(y) of the sample's rows (other columns zero) and its loss terms ----
+    float* terms = h.terms;
+    const int mode = h.mode;
+    if (mode == 0) {
+        if (tid < T) {
+            const int t = tid;
+            const float target = h.target[t], scale = h.scale[t];
+            const float p = 1.f / (1.f + expf(-ys[t][0]));
+            const float lp = fmaxf(logf(p), -100.f), l1p = fmaxf(logf(1.f - p), -100.f);
+            const float gp = (p - target) / fmaxf((1.f - p) * p, 1e-12f) * (scale / (float)B);
+            dl[t][0] = gp * p * (1.f - p);
+            if (first) __hip_atomic_store(terms + (size_t)t * B + b, -(target * lp + (1.f - target) * l1p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if constexpr (T == 3) {
+        if (tid < 64) {
+            // tape 0 (generated): MSE of the continuous codes, then CE of the soft-maxed classes, on wave 0 with lane j = code / class j.
+            // The sums run over the lanes in index order (v_readlane, one add per element): the stand-alone bodies' order, the same bits;
+            // as a one-thread loop over register arrays indexed by `lab` this was a 27 us chain.
+            auto rl = [](float v, int j) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j)); };
+            const int lane = tid, c0 = h.c_cont, n = h.n_cont, k0 = c0 + n, nc = h.n_cat;
+            const float gs = 2.f * h.lcon / (float)(B * n);
+            const float d = lane < n ? ys[0][c0 + lane] - h.code[(size_t)b * h.ldc + lane] : 0.f;
+            const float dd = d * d;
+            float acc = 0.f;
+            for (int j = 0; j < n; ++j) acc += rl(dd, j);
+            if (lane < n) dl[0][c0 + lane] = gs * d;
+            if (first && lane == 0) __hip_atomic_store(terms + b, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool on = lane < nc;
+            const float o = on ? ys[0][k0 + lane] : -INFINITY;
+            float mx = -INFINITY;
+            for (int j = 0; j < nc; ++j) mx = fmaxf(mx, rl(o, j));
+            float q = on ? expf(o - mx) : 0.f;
+            float se = 0.f;
+            for (int j = 0; j < nc; ++j) se += rl(q, j);
+            q = q / se;
+            float mq = -INFINITY;
+            for (int j = 0; j < nc; ++j) mq = fmaxf(mq, rl(q, j));
+            const float r = on ? expf(q - mq) : 0.f;
+            float s2 = 0.f;
+            for (int j = 0; j < nc; ++j) s2 += rl(r, j);
+            const int lab = __builtin_amdgcn_readfirstlane((int)h.labels[b]);
+            const float qlab = rl(q, lab);
+            if (first && lane == 0) __hip_atomic_store(terms + (size_t)B + b, -(qlab - mq - logf(s2)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float gq = (r / s2 - (lane == lab ? 1.f : 0.f)) * (h.lcat / (float)B);
+            const float pr = gq * q;
+            float dot = 0.f;
+            for (int j = 0; j < nc; ++j) dot += rl(pr, j);
+            if (on) dl[0][k0 + lane] += q * (gq - dot);
+        }
+        if (tid >= 64 && tid < 74) {                    // tapes 1 (transformed) and 2 (real): the affine-consistency term, lane i = d/d(variable i)
+            const int i = tid - 64, c0 = h.c_cont;
+            const float gs = 2.f * h.laff / (float)(B * 5);
+            Dual<1> rc[5], tc[5], out[5];
+            for (int k = 0; k < 5; ++k) {
+                rc[k] = k == i ? dvar<1>(ys[2][c0 + k], 0) : dconst<1>(ys[2][c0 + k]);
+                tc[k] = 5 + k == i ? dvar<1>(ys[1][c0 + k], 0) : dconst<1>(ys[1][c0 + k]);
+            }
+            regularizer_rpqxy<Dual<1>>(rc, tc, out);
+            float gr = 0.f, acc = 0.f;
+            for (int j = 0; j < 5; ++j) {
+                const float d = out[j].v - h.code[(size_t)b * h.ldc + j];
+                acc += d * d;
+                gr += gs * d * out[j].d[0];
+            }
+            if (i < 5) dl[2][c0 + i] = gr;
+            else dl[1][c0 + i - 5] = gr;
+            if (i == 0 && first) __hip_atomic_store(terms + (size_t)2 * B + b, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    if (first && tid < T * 32 && (tid & 31) < N) h.dout[((size_t)(tid >> 5) * B + b) * N + (tid & 31)] = dl[tid >> 5][tid & 31];
+
+    // ---- 3) dx[t][k] = (sum_n dout[t][n] * wp[n][k]) * act'(x[t][k]) / sigma[t], k in this workgroup's range ----
+    {
+        float post[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) post[t] = h.sigma ? 1.f / h.sigma[t] : 1.f;
+        E* __restrict__ dx = reinterpret_cast<E*>(h.dx);
+        const int kper = (K / VEC + gridDim.y - 1) / gridDim.y * VEC;
+        const int kend = min(K, ((int)blockIdx.y + 1) * kper);
+        for (int k0 = blockIdx.y * kper + tid * VEC; k0 < kend; k0 += NTH * VEC) {
+            uint4 xv[T], wv[N];
+#pragma unroll
+            for (int t = 0; t < T; ++t) xv[t] = *reinterpret_cast<const uint4*>(x + ((size_t)t * B + b) * K + k0);
+#pragma unroll
+            for (int n = 0; n < N; ++n) wv[n] = *reinterpret_cast<const uint4*>(wp + (size_t)n * h.Kpad + k0);
+            float a[T][VEC];
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) a[t][j] = 0.f;
+#pragma unroll
+            for (int n = 0; n < N; ++n) {
+                const E* we = reinterpret_cast<const E*>(&wv[n]);
+                float wf[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) wf[j] = Elt<E>::ld(we + j);
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float g = dl[t][n];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) a[t][j] = fmaf(g, wf[j], a[t][j]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const E* me = reinterpret_cast<const E*>(&xv[t]);
+                uint4 ov;
+                E* oe = reinterpret_cast<E*>(&ov);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    Elt<E>::st(oe + j, a[t][j] * eg_act_grad_from_out(Elt<E>::ld(me + j), h.mask_act, h.mask_slope) * post[t]);
+                *reinterpret_cast<uint4*>(dx + ((size_t)t * B + b) * K + k0) = ov;
+            }
+        }
+    }
+
+    // ---- 4) the batch's loss: the last ks = 0 workgroup to arrive adds the terms in the stand-alone kernels' order ----
+    if (!first) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) flag = __hip_atomic_fetch_add(h.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (flag != (unsigned)(gridDim.x - 1)) return;
+    if (tid == 0) __hip_atomic_store(h.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int nterm = mode == 0 ? T : 3;
+    for (int q = 0; q < nterm; ++q) {
+        const int nthr = (mode == 1 && q == 2) ? 128 : 256;
+        float acc = 0.f;
+        if (tid < nthr)
+            for (int i = tid; i < B; i += nthr) acc += __hip_atomic_load(terms + (size_t)q * B + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the stand-alone kernels run 256 (affine: 128) threads: their block_sum adds the waves in order, zeros here for the extra waves
+        const float tot = block_sum(acc, sm);
+        if (tid == 0) {
+            float add;
+            if (mode == 0) add = h.scale[q] * tot / (float)B;
+            else if (q == 0) add = h.lcon * tot / (float)(B * h.n_cont);
+            else if (q == 1) add = h.lcat * tot / (float)B;
+            else add = h.laff * tot / (float)(B * 5);
+            h.loss[0] += add;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int eg_head_fused_ok(int dtype, int T, int K, int N) {
+    return T >= 1 && T <= 3 && N == 19 && K > 0 && K % (dtype == EG_F32 ? 4 : 8) == 0;
+}
+
+template <typename E>
+static int launch_head_fused(const eg_head& h, hipStream_t st) {
+    // K ranges of the input gradient: at least one workgroup per CU (a sample's range streams the whole N x K panel: B = 128 alone is half a chip)
+    int ks = 1;
+    while (h.B * ks < 256 && ks < 8 && h.K / (ks * 2) >= 512 * Elt<E>::VEC) ks *= 2;
+    const dim3 grid(h.B, ks);
+    switch (h.T) {
+        case 1: hipLaunchKernelGGL((head_fused_kernel<E, 1, 19>), grid, dim3(512), 0, st, h); break;
+        case 2: hipLaunchKernelGGL((head_fused_kernel<E, 2, 19>), grid, dim3(512), 0, st, h); break;
+        default: hipLaunchKernelGGL((head_fused_kernel<E, 3, 19>), grid, dim3(512), 0, st, h); break;
+    }
+    return 0;
+}
+
+extern "C" int eg_head_fused(int dtype, const eg_head* hp, eg_stream_t s) {
+    EG_REQUIRE(hp, "eg_head_fused: null argument");
+    const eg_head& h = *hp;
+    EG_REQUIRE(h.x && h.wp && h.y && h.dout && h.dx && h.loss && h.terms && h.counter && h.partials && h.nslice > 0 && h.B > 0, "eg_head_fused: bad argument");
+    EG_REQUIRE(eg_head_fused_ok(dtype, h.T, h.K, h.N) && h.Kpad >= h.K, "eg_head_fused: unsupported head (N = 19, T <= 3)");
+    EG_REQUIRE(h.mode == 0 || (h.mode == 1 && h.T == 3 && h.code && h.labels && h.n_cat <= EG_MAXCAT && h.n_cont >= 5 &&
+                               h.c_cont + h.n_cont + h.n_cat <= h.N), "eg_head_fused: bad loss description");
+    if (dtype == EG_F32) launch_head_fused<float>(h, (hipStream_t)s);
+    else if (dtype == EG_F16) launch_head_fused<f16_t>(h, (hipStream_t)s);
+    else launch_head_fused<bf16_t>(h, (hipStream_t)s);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int eg_loss_affine_rpqxy(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc, float scale,
                                     float* loss, float* d_real, float* d_trans, float* pred_out, eg_stream_t s) {
     EG_REQUIRE(o_real && o_trans && code && B > 0, "eg_loss_affine_rpqxy: bad argument");

@@ -817,7 +817,8 @@ static NtPlan nt_plan_auto(const NtParams& p, int nphase, const NtFacts& f, size
     // fewer than ~200 tiles of 256 x 128 (the single-tape layers: 64 or 128 such tiles on 256 CUs): the same 8-wave design on 128 x 128
     // tiles (igemm_nt8h) -- whole K loops in place of one K split level (profiles/r03_n_nt8h_layers.txt; EG_NT_AUTO_S8H=0: igemm_nt8s)
     static const bool use_h = [] { const char* e = getenv("EG_NT_AUTO_S8H"); return !(e && atoi(e) == 0); }();
-    if (all_s8 && use_h && f.half && wgs256 >= 48 && wgs256 < 200 && f.nk_min >= 8)
+    static const int h_below = [] { const char* e = getenv("EG_NT_S8H_BELOW"); return e ? atoi(e) : 200; }();
+    if (all_s8 && use_h && f.half && wgs256 >= 48 && wgs256 < h_below && f.nk_min >= 8)
         return {EG_NT_S8H, nt_splits(f.tiles128, 224, f.nk_min, part128, ws_bytes, splitk)};
     if (all_s8 && f.half && wgs256 >= 48) return {EG_NT_S8, nt_splits(wgs256, 224, f.nk_min, part256, ws_bytes, splitk)};
     if (splitk <= 1 && f.nk_min >= 32 && wgs256 >= 200 && wgs256 * 100 >= rounds * 256 * 85) return {EG_NT_S8, 1};

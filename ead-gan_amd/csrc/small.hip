@@ -477,6 +477,30 @@ static void launch_dense_small_fwd(const T* x, const T* wp, const float* bias, f
     hipLaunchKernelGGL(dense_small_combine_kernel, dim3(cdiv(B * N, 256)), dim3(256), 0, st, ws, ns, bias, y, B, N, sigma, sigma_rows);
 }
 
+template <typename T>
+static int launch_dense_small_slices(const T* x, const T* wp, int B, int K, int Kpad, int N, float* ws, size_t ws_floats, hipStream_t st) {
+    constexpr int VEC = Elt<T>::VEC;
+    const int groups = cdiv(B, EG_DS_ROWS);
+    int ns = 1;                                         // the slice count of launch_dense_small_fwd: the same sums
+    while (ns < 16 && groups * ns < 256 && K / (ns * 2) >= 256 * VEC) ns *= 2;
+    while (ns > 1 && (size_t)ns * B * N > ws_floats) ns /= 2;
+    const int kper = cdiv(cdiv(K, VEC), ns) * VEC;
+    hipLaunchKernelGGL(dense_small_fwd_kernel<T>, dim3(groups, ns), dim3(256), 0, st, x, wp, (const float*)nullptr, (float*)nullptr, B, K, Kpad, N,
+                       (const float*)nullptr, 0, ws, ns == 1 ? K : kper);
+    return ns;
+}
+
+extern "C" int eg_dense_small_fwd_slices(int dtype, const void* x, const void* wp, int B, int K, int Kpad, int N, float* partials, size_t ws_floats,
+                                         int* nslice_out, eg_stream_t s) {
+    EG_REQUIRE(x && wp && partials && nslice_out && N <= 64 && K % (dtype == EG_F32 ? 4 : 8) == 0 && ws_floats >= (size_t)B * N,
+               "eg_dense_small_fwd_slices: bad argument (N<=64)");
+    if (dtype == EG_F32) *nslice_out = launch_dense_small_slices<float>((const float*)x, (const float*)wp, B, K, Kpad, N, partials, ws_floats, (hipStream_t)s);
+    else if (dtype == EG_F16) *nslice_out = launch_dense_small_slices<f16_t>((const f16_t*)x, (const f16_t*)wp, B, K, Kpad, N, partials, ws_floats, (hipStream_t)s);
+    else *nslice_out = launch_dense_small_slices<bf16_t>((const bf16_t*)x, (const bf16_t*)wp, B, K, Kpad, N, partials, ws_floats, (hipStream_t)s);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
 // dx[b][k] = (sum_n dy[b][n] * Wp[n][k]) * act'(mask[b][k]);  EG_DS_ROWS batch rows per workgroup share every weight vector (one row per
 // workgroup re-read the whole N x K panel from L2 per row: 240 MB for 384 rows of the 19 x 16384 head)
 template <typename T>

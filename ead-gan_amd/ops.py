@@ -12,7 +12,7 @@ import torch
 
 from ._lib import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH, EG_BF16, EG_F16, EG_F32, NT_AUTO, NT_BUF128,
                    NT_PERS, NT_REG, NT_S8, NT_S8H, NT_S8P, OUT_NCHW_F32, OUT_NHWC, STAT_BN_BWD, STAT_MOMENTS, STAT_NONE, STAT_SN_BIAS, EgConv, EgEpilogue,
-                   EgRngSeg, EgSnLayer, lib)
+                   EgHead, EgRngSeg, EgSnLayer, lib)
 
 __all__ = ["EG_F32", "EG_BF16", "EG_F16", "ACT_NONE", "ACT_LRELU", "ACT_RELU", "ACT_TANH", "ACT_SIGMOID", "OUT_NHWC",
            "OUT_NCHW_F32"]
@@ -298,6 +298,39 @@ def cast_pad(dtype, src, dst, rows, n, npad):
 
 def act_grad_mul_bias_nchw(g, a, out, B, C, HW, act, slope, partial, gb):
     lib().call("eg_act_grad_mul_bias_nchw", _p(g), _p(a), _p(out), B, C, HW, act, slope, _p(partial), _p(gb), _stream())
+
+
+def head_fused_ok(dtype, T, K, N):
+    return bool(lib().cdll.eg_head_fused_ok(dtype, T, K, N))
+
+
+def dense_small_fwd_slices(dtype, x, wp, B, K, Kpad, N, ws):
+    """the K-slice sums of dense_small_fwd (no combine launch) -> number of slices in ``ws`` [slice][B][N]"""
+    ns = ctypes.c_int(0)
+    lib().call("eg_dense_small_fwd_slices", dtype, _p(x), _p(wp), B, K, Kpad, N, _p(ws), ws.numel(), ctypes.byref(ns), _stream())
+    return ns.value
+
+
+def head_fused(dtype, x, wp, bias, partials, nslice, y, dout, dx, sigma, B, T, K, Kpad, N, loss, terms, counter, mask_act, mask_slope, targets=None,
+               scales=None, info=None):
+    """Behind dense_small_fwd_slices: slice combine, losses and head input gradient of the T rows of every sample in one launch
+    (eg_head_fused).  ``targets`` / ``scales``: the adversarial BCE term of each tape; ``info`` = (c_cont, n_cont, n_cat, code, labels, lcat,
+    lcon, laff): the info step's three losses (tapes: generated, transformed, real)."""
+    h = EgHead()
+    h.x, h.wp, h.bias, h.y, h.dout, h.dx, h.sigma = _p(x), _p(wp), _p(bias), _p(y), _p(dout), _p(dx), _p(sigma)
+    h.partials, h.nslice = _p(partials), nslice
+    h.B, h.T, h.K, h.Kpad, h.N = B, T, K, Kpad, N
+    h.loss, h.terms, h.counter, h.mask_act, h.mask_slope = _p(loss), _p(terms), _p(counter), mask_act, float(mask_slope)
+    if info is None:
+        h.mode = 0
+        for t in range(T):
+            h.target[t], h.scale[t] = float(targets[t]), float(scales[t])
+    else:
+        h.mode = 1
+        c_cont, n_cont, n_cat, code, labels, lcat, lcon, laff = info
+        h.c_cont, h.n_cont, h.n_cat, h.code, h.ldc, h.labels = c_cont, n_cont, n_cat, _p(code), code.stride(0), _p(labels)
+        h.lcat, h.lcon, h.laff = float(lcat), float(lcon), float(laff)
+    lib().call("eg_head_fused", dtype, ctypes.byref(h), _stream())
 
 
 def dense_small_bgrad(dy, gb, B, N):

@@ -256,6 +256,10 @@ int eg_dense_small_fwd_sn(int dtype, const void* x, const void* wp, const float*
 int eg_head_prep_sn(int dtype, const float* dy, int ldy, const float* y, int ldyy, const float* bias, int rows, int N,
                     const float* sigma, int rows_per_tape, void* dys, int npad, int col0, float* gb, float* coef,
                     float* dys32, int ld32, eg_stream_t s);
+/* the K-slice sums of eg_dense_small_fwd without the combine launch: partials[slice][b][n] (ws_floats >= 16 * B * N), *nslice_out slices;
+ * eg_head_fused adds them (slice order, + bias) */
+int eg_dense_small_fwd_slices(int dtype, const void* x, const void* wp, int B, int K, int Kpad, int N, float* partials, size_t ws_floats,
+                              int* nslice_out, eg_stream_t s);
 /* dx[b] = (dy[b] Wp) * act'(mask[b]) [/ sigma[b / sigma_rows]] */
 int eg_dense_small_bwd(int dtype, const float* dy, const void* wp, const void* mask, void* dx, int B, int K,
                        int Kpad, int N, int mask_act, float mask_slope, const float* sigma, int sigma_rows,
@@ -408,6 +412,44 @@ int eg_loss_affine_rpqxy(const float* o_real, const float* o_trans, int ld, int 
 int eg_loss_info_rpqxy(const float* o_gen, const float* o_trans, const float* o_real, int ld, int c_cont, int n_cont, int n_cat, int B,
                        const float* code, int ldc, const long long* labels, float lcat, float lcon, float laff, float* loss, float* d_gen,
                        float* d_trans, float* d_real, eg_stream_t s);
+
+/* The tail of the discriminator's head in ONE launch behind eg_dense_small_fwd_slices (celebA.py:110-122 the 4x4 head convolution as a
+ * dense layer; :334-345, :353-366 the adversarial BCE terms; :375-401 the info step's three losses): the workgroups of sample index b work
+ * on the T rows t*B + b (the tapes of that sample):
+ *   y[t*B+b][n]  = sum_slices partials[slice][t*B+b][n] + bias[n]                               (= the slice combine of eg_dense_small_fwd)
+ *   dout rows    = d(loss)/d(y) of the rows, other columns zero                                 (= eg_loss_bce_sigmoid / eg_loss_info_rpqxy)
+ *   dx[t*B+b][k] = (sum_n dout[t*B+b][n] * wp[n][k]) * act'(x[t*B+b][k]) / sigma[t]              (= eg_dense_small_bwd with mask = x)
+ * and the last workgroup to finish adds the batch's loss terms to loss[0] in the order of the stand-alone loss kernels: the same bits as
+ * the four launches it replaces (combine, loss, dense backward; the loss sums for B <= 256, affine term B <= 128 -- beyond, the same
+ * terms added in another order).  mode 0: tape t carries BCE(sigmoid(y[:, 0]), target[t]) * scale[t] (T <= 3).  mode 1 (T = 3, tapes:
+ * generated, transformed, real): lcon * MSE(y_gen[:, c_cont : +n_cont], code) + lcat * CE(softmax(y_gen[:, c_cont+n_cont : +n_cat]),
+ * labels) + laff * MSE(affine_regularzier(y_real, y_trans), code[:, :5]).  terms: >= 3*B floats of scratch, counter: one zeroed unsigned
+ * (left zero).  Supported heads: N = 19 (CelebA), K a multiple of 8 elements (4 for fp32). */
+typedef struct eg_head {
+    const void* x;
+    const void* wp;
+    const float* bias;
+    const float* partials;
+    int nslice;
+    float* y;
+    float* dout;
+    void* dx;
+    const float* sigma;
+    int B, T, K, Kpad, N, mode;
+    float target[3], scale[3];
+    int c_cont, n_cont, n_cat;
+    const float* code;
+    int ldc;
+    const long long* labels;
+    float lcat, lcon, laff;
+    float* loss;
+    float* terms;
+    unsigned int* counter;
+    int mask_act;
+    float mask_slope;
+} eg_head;
+int eg_head_fused(int dtype, const eg_head* h, eg_stream_t s);
+int eg_head_fused_ok(int dtype, int T, int K, int N);
 
 /* regression target of the approximator fit (MNIST/approximate_rpqmnxy.py:43-60,119-136): affine parameters of a code */
 int eg_affine_para_rpqmnxy(const float* code, int ldc, int B, float* para, eg_stream_t s);

@@ -11,8 +11,9 @@ ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name
 g = [e for e in ev if e[4] == "0" and e[3] not in ("1",)]          # graph branches land on extra queues of stream 0
 t0, t1 = g[0][0], g[-1][1]
 ph = [e for e in ev if e[0] >= t0 and e[1] <= t1]
-once = sum(1 for e in ph if "affine_reg_rpqxy" in e[2])        # one launch per CelebA iteration (the affine regulariser of the info step)
-steps = once if once else sum(1 for e in ph if "adam_kernel" in e[2]) / 4
+once = sum(1 for e in ph if "info_losses_rpqxy" in e[2]) or sum(1 for e in ph if "affine_reg_rpqxy" in e[2])   # one launch per CelebA iteration (the info step's loss kernel)
+steps = once if once else sum(1 for e in ph if "adam_tick" in e[2]) / 3
+print(f"launches per step: {len(ph) / steps:.1f}")
 span = t1 - t0
 print(f"replay window {span / 1e6:.2f} ms, {steps:.1f} steps, {span / 1e6 / steps:.3f} ms/step")
 isg = lambda n: "igemm" in n
