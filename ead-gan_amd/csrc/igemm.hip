@@ -1898,6 +1898,7 @@ extern "C" int eg_conv_wgrad_target(const eg_conv* c, int dtype, const void* X, 
 // the rank-1 spectral-norm terms, transposes through LDS and read-modify-writes the master-layout gradient [n][c][t] as
 // one contiguous run of 64*T floats.  MODE 0: out += a; MODE 1: out = a (gtmp) + <a,W> partials; MODE 2: out += a - rank1.
 #define EG_RC 64
+__device__ int eg_reduce_chain_flag;                    // EG_REDUCE_RAGGED=0 (A/B runs): the one-chain loop for ragged channel counts
 template <int MODE>
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int NS, int N, int C, int T,
                                                            float* __restrict__ out, int accumulate, const float* __restrict__ w_orig,
@@ -1978,6 +1979,36 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
                 }
             tile[c * (T + 1) + t] = a.x; tile[(c + 1) * (T + 1) + t] = a.y; tile[(c + 2) * (T + 1) + t] = a.z; tile[(c + 3) * (T + 1) + t] = a.w;
         }
+    } else if (nsplit >= 16 && T * EG_RC * 2 <= NTH && !eg_reduce_chain_flag) {
+        // many splits of a small tile whose channel count is not a multiple of 64 (the image-side layers: 48 = 3 x 16 gathered channels,
+        // 128 splits): the loop below is ONE chain of nsplit dependent loads per thread (39 us for a 6 K-parameter gradient, at the end
+        // of every sub-step's backward pass).  As above: thread groups take every G-th split, eight loads in flight, added in group order.
+        __shared__ float parts[1024];
+        const int ne = T * EG_RC, G = min(NTH / ne, 16), e = threadIdx.x % ne, sg = threadIdx.x / ne;
+        const int t = e / EG_RC, cc = e % EG_RC;
+        const bool valid = cc < cw && c0 + cc < crow;
+        const size_t si = ((size_t)n * T + t) * C + c0 + cc;
+        float a = 0.f;
+        if (sg < G && valid) {
+            int z = sg;
+            for (; z + 7 * G < nsplit; z += 8 * G) {
+                float x[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[q] = slab[(size_t)(z + q * G) * split_stride + si];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a += x[q];
+            }
+            for (; z < nsplit; z += G) a += slab[(size_t)z * split_stride + si];
+        }
+        parts[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x < ne && valid) {
+            a = parts[threadIdx.x];
+            for (int gq = 1; gq < G; ++gq) a += parts[gq * ne + threadIdx.x];
+            if (MODE == 2)
+                for (int q = 0; q < ntapes; ++q) a -= un[q] * v[(size_t)q * crow * T + (size_t)(c0 + cc) * T + t];
+            tile[cc * (T + 1) + t] = a;
+        }
     } else
     for (int e = threadIdx.x; e < T * EG_RC; e += NTH) {
         const int t = e / EG_RC, c = e % EG_RC;
@@ -2026,7 +2057,16 @@ __global__ void sn_grad_apply_kernel(const float* __restrict__ gtmp, const float
     }
 }
 
-static inline int reduce_blocks(int n_rows, int C) { return n_rows * ((C + EG_RC - 1) / EG_RC); }
+static inline int reduce_blocks(int n_rows, int C) {
+    static const bool once = [] {
+        const char* e = getenv("EG_REDUCE_RAGGED");
+        const int v = (e && atoi(e) == 0) ? 1 : 0;
+        if (v) (void)hipMemcpyToSymbol(HIP_SYMBOL(eg_reduce_chain_flag), &v, sizeof(v));
+        return true;
+    }();
+    (void)once;
+    return n_rows * ((C + EG_RC - 1) / EG_RC);
+}
 // threads per workgroup: 1024 (several split groups per tile vector) where a launch has many splits and few, small tiles
 static inline int reduce_threads(int nsplit, int n_rows, int C, int T) {
     const int nv = T * (EG_RC / 4);
