@@ -19,7 +19,7 @@ import torch.nn as nn
 from torch.nn.utils import spectral_norm
 
 from . import ops
-from .engine import Arena, ConvRec, SideStream, Workspace, capture_step, check_usable, parse_dtype
+from .engine import Arena, ConvRec, SideStream, Workspace, capture_segments, capture_step, check_usable, parse_dtype
 from .ops import (ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, EG_BF16, EG_F32, OUT_NCHW_F32)
 
 # module-level hyper-parameters, mirroring the reference's global ``opt`` (argparse defaults, :39-51)
@@ -956,6 +956,13 @@ BATCH_D12 = os.environ.get("EG_BATCH_D12", "0") != "0"
 # optimizer updates bucket by bucket (each bucket behind its own weight-gradient chain) instead of one update behind all chains: "0" never,
 # "1" every update, "3" the info step's two, or a comma list of g1 (generator step), d2 (discriminator step), d3, g3 (info step: D, then G)
 # data parallel: gradient buckets that cross the links as one message, in completion order (contiguous in the arenas)
+# EXPERIMENT (default off): the captured iteration as FOUR hipGraphs on two streams (engine.MultiGraph): [inputs, steps 1 and 2] -> [D's
+# update + step 3's power iterations and patch rows, ONE chain] beside [step 3's generator forward] -> [rest of step 3].  In ONE hipGraph
+# the generator forward starts ~200 us after step 2's main chain ends, although the node graph lets it start at once.  Cut into graphs on
+# real streams the delay stays (4.35 -> 4.46 ms, profiles/r03_x_ab_multi_graph.txt; toys: profiles/scripts/graph_streams_toy.py -- a graph
+# WITH branches on a second stream holds back later launches on the first, a one-chain graph does not; more HSA queues make it far worse,
+# profiles/r03_y_ab_hwq.txt).  Same bits (tests/test_gpu_celeba.py).  Single process only.
+MULTI_GRAPH = os.environ.get("EG_MULTI_GRAPH", "0") != "0"
 ZERO_ON_PREP = os.environ.get("EG_ZERO_ON_PREP", "1") != "0"     # gradient zeroing of steps 1 / 2 on the preparation lane (0: on the main stream)
 SPLIT2_SET = set(filter(None, os.environ.get("EG_SPLIT2", "").split(",")))      # updates done in two pieces (early layers / rest): g1, d2, d3, g3
 DP_START = os.environ.get("EG_DP_START", "lane")
@@ -1349,6 +1356,12 @@ class CelebATrainer:
         de.backward(0, 2, self.dout[:2 * B], da.grad, side=side, head_done=fh1)
         g3_first = os.environ.get("EG_G3_FIRST", "0") != "0"
         keep = side.deferred
+        cut = getattr(self, "_cut", None)               # capture_segments: the iteration is being captured as several hipGraphs
+        if cut is not None:
+            side.join()                                 # every chain of steps 1 and 2 (and the generator's update) ends in this segment
+            side.cut()
+            cut(1, (0,))                                # second stream, behind the first segment
+            side.inline = True                          # ... as ONE chain: update, then step 3's power iterations and patch rows
         if g3_first:
             side.deferred = "1"                         # layer 0's chain, D's update and step 3's preparation are CAPTURED behind the generator forward's launches
         update(da, self.mD, self.vD, self.lr[1], 1, True, True, de, key_w="dw", where="d2")             # beside step 3's generator forward
@@ -1357,15 +1370,26 @@ class CelebATrainer:
             side.wait(evs["dw"])
             de.prepare(0, [None, self.scaled, self.real])
         side.defer_prep(prep3)
+        if cut is not None:
+            side.flush()
+            side.inline = False
+            side.cut()
+            cut(0, ())                                  # the caller's stream again: behind the first segment by stream order
         # ---- 3) info + affine step (:375-401): D(gen), D(scaled), D(real) batched as tapes 0,1,2 ----
         if self.g3_early:
             side.wait(evs["g3fwd"])
             gen = ge.img
         else:
-            side.wait(evs["g"])                         # G's panels and zeroed gradients (optimizer lane, step 1)
+            if cut is None:
+                side.wait(evs["g"])                     # G's panels and zeroed gradients (optimizer lane, step 1)
             gen = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
         side.deferred = keep
-        side.join()                                     # D's panels, power iterations, patch rows
+        if cut is not None:
+            side.join()
+            side.cut()
+            cut(0, (1,))                                # behind the second stream's segment: D's panels, power iterations, patch rows
+        else:
+            side.join()                                 # D's panels, power iterations, patch rows
         out = de.forward([gen, self.scaled, self.real], 0, prepared=(False, True, True), head=not fh3)
         if fh3:
             de.head_losses(0, 3, self.dout, self.losses[2:3], info=(1, cd, nc, self.code, self.labels, lcat, lcon, laff))
@@ -1422,6 +1446,13 @@ class CelebATrainer:
             self._step_body()
         if inputs is not None:
             self.inputs = inputs
+        if MULTI_GRAPH and self.side is not None and self.allreduce is None and not self.g3_early and not BATCH_D12:
+            self.side._live = []
+            try:
+                return capture_segments(self, self._step_with_inputs)
+            finally:
+                self.side._live = None
+                self.side.inline = False
         return capture_step(self, self._step_with_inputs)
 
     def _step_with_inputs(self):

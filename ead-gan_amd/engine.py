@@ -189,9 +189,31 @@ class SideStream:
         # after it, "once" at once for a lane's first fork of the step and after it from then on
         self.deferred = os.environ.get("EG_DEFER", "0")
         self._entered = set()
+        # lanes forked since the last cut(): an iteration captured as SEVERAL hipGraphs (capture_segments) may only join -- record an
+        # event on -- the lanes that are part of the current capture; None: every lane (one capture / eager launches)
+        self._live = None
+        # True: deferred work runs on the CURRENT stream at once (no fork): a capture segment that has to stay ONE chain -- a hipGraph with
+        # branches, launched on a second stream, holds back every later graph launch on the first (profiles/scripts/graph_streams_toy.py)
+        self.inline = False
 
     def lane(self, i: int) -> _Lane:
         return self.lanes[i % len(self.lanes)]
+
+    def _touch(self, ln):
+        if self._live is not None:
+            self._live.append(ln) if ln not in self._live else None
+
+    def _joinable(self, lanes):
+        return [ln for ln in lanes if self._live is None or ln in self._live]
+
+    def cut(self):
+        """a new capture segment begins: no lane belongs to it yet (the caller has joined them all)"""
+        assert not self._pending, "cut() with deferred work pending"
+        self._live = []
+        self.done.clear()
+        self.done_lane.clear()
+        self.free.clear()
+        self._last_tag = None
 
     def fork(self, i: int = 0) -> _Lane:
         ln = self.lane(i)
@@ -199,6 +221,7 @@ class SideStream:
         ev = torch.cuda.Event()
         ev.record()
         ln.stream.wait_event(ev)
+        self._touch(ln)
         return ln
 
     # Deferred issue.  hipGraph's executor keeps the FIRST-created child of a node on the node's own HW queue; every other child moves to
@@ -254,6 +277,12 @@ class SideStream:
             while self._pending:
                 kind, ln, ev, fn, tag = self._pending.pop(0)
                 ln.ensure()
+                if self.inline:
+                    fn(ln.ws)                           # (the events of an "optb" entry belong to chains of this very stream)
+                    if tag is not None:
+                        self.done[tag] = self.mark()
+                        self.done_lane[tag] = ln
+                    continue
                 if kind == "optb":
                     for t in ev:
                         d = self.done.pop(t, None)          # None: the caller already waited for it (data parallel)
@@ -262,8 +291,9 @@ class SideStream:
                         ln.stream.wait_event(self.free.pop(t))
                 else:
                     ln.stream.wait_event(ev)
+                self._touch(ln)
                 if kind == "opt":
-                    for other in self.lanes:
+                    for other in self._joinable(self.lanes):
                         e2 = torch.cuda.Event()
                         e2.record(other.stream)
                         ln.stream.wait_event(e2)
@@ -280,6 +310,7 @@ class SideStream:
         ev = torch.cuda.Event()
         ev.record()
         self.prep.stream.wait_event(ev)
+        self._touch(self.prep)
         return self.prep
 
     def fork_opt(self) -> _Lane:
@@ -288,7 +319,8 @@ class SideStream:
         ev = torch.cuda.Event()
         ev.record()
         self.opt.stream.wait_event(ev)
-        for ln in self.lanes:
+        self._touch(self.opt)
+        for ln in self._joinable(self.lanes):
             ev = torch.cuda.Event()
             ev.record(ln.stream)
             self.opt.stream.wait_event(ev)
@@ -310,7 +342,7 @@ class SideStream:
         """the current stream waits for the weight-gradient lanes only (not for the optimizer / preparation lanes)"""
         self.flush()
         cur = torch.cuda.current_stream()
-        for ln in self.lanes:
+        for ln in self._joinable(self.lanes):
             ev = torch.cuda.Event()
             ev.record(ln.stream)
             cur.wait_event(ev)
@@ -318,7 +350,7 @@ class SideStream:
     def join(self):
         self.flush()
         cur = torch.cuda.current_stream()
-        for ln in self.lanes + [self.opt, self.prep]:
+        for ln in self._joinable(self.lanes + [self.opt, self.prep]):
             ev = torch.cuda.Event()
             ev.record(ln.stream)
             cur.wait_event(ev)
@@ -463,6 +495,81 @@ def capture_step(trainer, body):
         trainer.capture_failed = f"{type(exc).__name__}: {exc}"
         raise CaptureFailed(trainer.capture_failed) from exc
     trainer.graph = graph
+    return trainer
+
+
+class MultiGraph:
+    """One training iteration as several hipGraphs replayed on TWO real streams, ordered by events (an experiment, see celeba.MULTI_GRAPH:
+    it did not remove the delay it was built against).  ``replay()`` is what ``torch.cuda.CUDAGraph.replay()`` is to a one-graph trainer."""
+
+    def __init__(self, device):
+        self.segments = []                              # (graph, stream index 0 = the caller's stream / 1 = the second stream, after)
+        self.second = torch.cuda.Stream(device)
+        self._done = []
+
+    def add(self, graph, stream, after):
+        self.segments.append((graph, int(stream), tuple(after)))
+        self._done.append(torch.cuda.Event())
+
+    def replay(self):
+        main = torch.cuda.current_stream()
+        streams = (main, self.second)
+        for i, (g, s, after) in enumerate(self.segments):
+            st = streams[s]
+            for j in after:                             # segments on the other stream this one reads from
+                st.wait_event(self._done[j])
+            if s == 0:
+                g.replay()
+            else:
+                with torch.cuda.stream(st):
+                    g.replay()
+            self._done[i].record(st)
+        for i, (_, s, _) in enumerate(self.segments):   # the caller's stream ends behind every segment
+            if s != 0:
+                main.wait_event(self._done[i])
+
+
+def capture_segments(trainer, body):
+    """Like capture_step, for a ``body`` that calls ``trainer._cut(stream, after)`` between segments (every lane joined): each segment
+    becomes its own hipGraph; ``trainer.graph`` is a MultiGraph.  ``after``: indices of earlier segments on the OTHER stream whose results
+    the next segment reads (same-stream order is implicit)."""
+    torch.cuda.synchronize()
+    dev = torch.cuda.current_device()
+    mg = MultiGraph(dev)
+    pool = torch.cuda.graph_pool_handle()
+    cap = torch.cuda.Stream(dev)
+    cap.wait_stream(torch.cuda.current_stream())
+    state = {"g": None, "stream": 0, "after": ()}
+
+    def begin():
+        g = torch.cuda.CUDAGraph()
+        g.capture_begin(pool=pool)
+        state["g"] = g
+
+    def end():
+        state["g"].capture_end()
+        mg.add(state["g"], state["stream"], state["after"])
+        state["g"] = None
+
+    def cut(stream=0, after=()):
+        end()
+        state["stream"], state["after"] = stream, after
+        begin()
+
+    trainer._cut = cut
+    try:
+        with torch.cuda.stream(cap):
+            begin()
+            body()
+            end()
+    except Exception as exc:
+        trainer.graph = None
+        trainer.capture_failed = f"{type(exc).__name__}: {exc}"
+        raise CaptureFailed(trainer.capture_failed) from exc
+    finally:
+        trainer._cut = None
+    torch.cuda.current_stream().wait_stream(cap)
+    trainer.graph = mg
     return trainer
 
 

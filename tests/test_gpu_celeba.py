@@ -313,6 +313,30 @@ def test_graph_replay_equals_eager():
     assert torch.equal(losses[0], losses[1]), (losses[0], losses[1])
 
 
+def test_iteration_as_four_graphs_on_two_streams_equals_one_graph(monkeypatch):
+    """EG_MULTI_GRAPH=1 (engine.MultiGraph, an experiment switch: DESIGN.md): the iteration cut into four hipGraphs replayed on two streams
+    gives the bits of the one-graph replay"""
+    B = 4
+    losses = []
+    for multi in (False, True):
+        monkeypatch.setattr(eg.celeba, "MULTI_GRAPH", multi)
+        orc, G, D = build_pair(7, "bf16")
+        tr = eg.celeba.CelebATrainer(G, D, B, dtype="bf16")
+        rng = np.random.RandomState(1)
+        real = co.synthetic_real(B, seed=5).to(DEV)
+        out = []
+        for i in range(4):
+            z, code, labels = co.draw_step_inputs(rng, B)
+            tr.load_inputs(real, z.to(DEV), code.to(DEV), labels.to(DEV))
+            if i == 1:
+                tr.capture()
+                assert hasattr(tr.graph, "segments") == multi
+            out.append(tr.step_resident().clone())
+        torch.cuda.synchronize()
+        losses.append(torch.stack(out).cpu())
+    assert torch.equal(losses[0], losses[1]), (losses[0], losses[1])
+
+
 def test_workspace_growth_keeps_captured_graphs_valid():
     """Workspaces are shared per device and grow when a larger engine is built.  A hipGraph captured before has the old addresses
     baked in: the outgrown buffers must stay alive, and the side lanes of the new trainer must get scratch of the new size.
