@@ -1137,11 +1137,12 @@ struct PackParams {
     PackPhase ph[4];
 };
 
+// (the pack kernels' bodies take their block coordinates as arguments: pack_multi_kernel below runs several layers' packs in one launch)
 template <typename T>
-__global__ void pack_kernel(const PackParams p) {
-    const PackPhase ph = p.ph[blockIdx.y];
+__device__ __forceinline__ void pack_gather_body(const PackParams& p, int bx, int by, int gx) {
+    const PackPhase ph = p.ph[by];
     const long long total = (long long)p.Nrows * ph.Kpad;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = (long long)bx * blockDim.x + threadIdx.x; i < total; i += (long long)gx * blockDim.x) {
         const int n = (int)(i / ph.Kpad), kk = (int)(i % ph.Kpad);
         float v = 0.f;
         if (kk < ph.K) {
@@ -1153,11 +1154,20 @@ __global__ void pack_kernel(const PackParams p) {
         Elt<T>::st(reinterpret_cast<T*>(p.wp) + ph.w_off + i, v);
     }
 }
+template <typename T>
+__global__ void pack_kernel(const PackParams p) { pack_gather_body<T>(p, blockIdx.x, blockIdx.y, gridDim.x); }
+
+struct PackTileParams;
+static bool pack_record_gather(const PackParams& p, int dtype, int gx, int gy);
+static bool pack_record_strided(int kind, int dtype, const float* w, void* wp, int N, int K, int Kpad, int n_div, long long s_hi, long long s_lo,
+                                long long s_k, int k_div, long long s_khi, long long s_klo, int gx);
+static bool pack_record_tile(const PackTileParams& p, int dtype, int gx, int gy);
 
 static void launch_pack(const PackParams& p, int dtype, hipStream_t st) {
     long long total = 0;
     for (int i = 0; i < p.nphase; ++i) total = total > (long long)p.Nrows * p.ph[i].Kpad ? total : (long long)p.Nrows * p.ph[i].Kpad;
     const int blocks = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+    if (pack_record_gather(p, dtype, blocks, p.nphase)) return;
     if (dtype == EG_F32) hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks, p.nphase), dim3(256), 0, st, p);
     else if (dtype == EG_F16) hipLaunchKernelGGL(pack_kernel<f16_t>, dim3(blocks, p.nphase), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks, p.nphase), dim3(256), 0, st, p);
@@ -1233,12 +1243,11 @@ struct PackTileParams {
 
 // TTC: taps (k*k) as a compile-time constant (16 for every 4x4 layer; 0 = run time): the index arithmetic below divides by it per element
 template <typename T, int TTC>
-__global__ __launch_bounds__(256) void pack_conv_tile_kernel(const PackTileParams p) {
+__device__ __forceinline__ void pack_conv_tile_body(const PackTileParams& p, float* tile, int bx, int by) {
     constexpr int VEC = Elt<T>::VEC;
     constexpr int TN = 16, TC = 32;
-    extern __shared__ float tile[];                 // [TN][TC][T + 1]
     const int TT = TTC ? TTC : p.T, TP = TT + 1;
-    const int n0 = blockIdx.x * TN, c0 = blockIdx.y * TC;
+    const int n0 = bx * TN, c0 = by * TC;
     const int tid = threadIdx.x;
     for (int e = tid; e < TN * TC * TT; e += 256) {
         const int n = e / (TC * TT), rem = e - n * (TC * TT);
@@ -1272,6 +1281,11 @@ __global__ __launch_bounds__(256) void pack_conv_tile_kernel(const PackTileParam
             *reinterpret_cast<uint4*>(dst + p.off[q] + (size_t)(c0 + c) * p.pitch[q] + n0 + ng * VEC) = ov;
         }
     }
+}
+template <typename T, int TTC>
+__global__ __launch_bounds__(256) void pack_conv_tile_kernel(const PackTileParams p) {
+    extern __shared__ float tile[];                 // [TN][TC][T + 1]
+    pack_conv_tile_body<T, TTC>(p, tile, blockIdx.x, blockIdx.y);
 }
 
 // tile-kernel parameters of a layer, or false where only the per-element gather kernels can pack it (ragged channel counts, K padding)
@@ -1317,6 +1331,7 @@ extern "C" int eg_pack_conv(const eg_conv* c, int dtype, const float* w, void* w
     }
     const dim3 grid(c->Cout / 16, c->Cin / 32);
     const size_t lds = (size_t)16 * 32 * (T + 1) * sizeof(float);
+    if (pack_record_tile(p, dtype, grid.x, grid.y)) return 0;
 #define EG_PACK_TILE(TY) do { if (T == 16) hipLaunchKernelGGL((pack_conv_tile_kernel<TY, 16>), grid, dim3(256), lds, (hipStream_t)s, p); \
                               else hipLaunchKernelGGL((pack_conv_tile_kernel<TY, 0>), grid, dim3(256), lds, (hipStream_t)s, p); } while (0)
     if (dtype == EG_F32) EG_PACK_TILE(float);
@@ -1530,34 +1545,45 @@ extern "C" int eg_adam_pack_rows(int dtype, float* w, float* g, float* m, float*
 
 // generic strided pack: wp[n][k] = w[(n / n_div) * s_hi + (n % n_div) * s_lo + k * s_k]  (k < K, else 0)
 template <typename T>
-__global__ void pack_strided_kernel(const float* __restrict__ w, T* __restrict__ wp, int N, int K, int Kpad, int n_div, long long s_hi,
-                                    long long s_lo, long long s_k) {
+__device__ __forceinline__ void pack_strided_body(const float* __restrict__ w, T* __restrict__ wp, int N, int K, int Kpad, int n_div, long long s_hi,
+                                                  long long s_lo, long long s_k, int bx, int gx) {
     const long long total = (long long)N * Kpad;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = (long long)bx * blockDim.x + threadIdx.x; i < total; i += (long long)gx * blockDim.x) {
         const int n = (int)(i / Kpad), kk = (int)(i % Kpad);
         float v = 0.f;
         if (kk < K) v = w[(n / n_div) * s_hi + (n % n_div) * s_lo + kk * s_k];
         Elt<T>::st(wp + i, v);
     }
 }
+template <typename T>
+__global__ void pack_strided_kernel(const float* __restrict__ w, T* __restrict__ wp, int N, int K, int Kpad, int n_div, long long s_hi,
+                                    long long s_lo, long long s_k) {
+    pack_strided_body<T>(w, wp, N, K, Kpad, n_div, s_hi, s_lo, s_k, blockIdx.x, gridDim.x);
+}
 
 // same with a decomposed column index: + (k / k_div) * s_khi + (k % k_div) * s_klo
 template <typename T>
-__global__ void pack_strided2_kernel(const float* __restrict__ w, T* __restrict__ wp, int N, int K, int Kpad, int n_div, long long s_hi,
-                                     long long s_lo, int k_div, long long s_khi, long long s_klo) {
+__device__ __forceinline__ void pack_strided2_body(const float* __restrict__ w, T* __restrict__ wp, int N, int K, int Kpad, int n_div, long long s_hi,
+                                                   long long s_lo, int k_div, long long s_khi, long long s_klo, int bx, int gx) {
     const long long total = (long long)N * Kpad;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = (long long)bx * blockDim.x + threadIdx.x; i < total; i += (long long)gx * blockDim.x) {
         const int n = (int)(i / Kpad), kk = (int)(i % Kpad);
         float v = 0.f;
         if (kk < K) v = w[(n / n_div) * s_hi + (n % n_div) * s_lo + (kk / k_div) * s_khi + (kk % k_div) * s_klo];
         Elt<T>::st(wp + i, v);
     }
 }
+template <typename T>
+__global__ void pack_strided2_kernel(const float* __restrict__ w, T* __restrict__ wp, int N, int K, int Kpad, int n_div, long long s_hi,
+                                     long long s_lo, int k_div, long long s_khi, long long s_klo) {
+    pack_strided2_body<T>(w, wp, N, K, Kpad, n_div, s_hi, s_lo, k_div, s_khi, s_klo, blockIdx.x, gridDim.x);
+}
 extern "C" int eg_pack_strided2(int dtype, const float* w, void* wp, int N, int K, int Kpad, int n_div, long long s_hi, long long s_lo, int k_div,
                                 long long s_khi, long long s_klo, eg_stream_t s) {
     EG_REQUIRE(w && wp && N > 0 && K > 0 && Kpad >= K && n_div > 0 && k_div > 0, "eg_pack_strided2: bad argument");
     const long long total = (long long)N * Kpad;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (pack_record_strided(2, dtype, w, wp, N, K, Kpad, n_div, s_hi, s_lo, 0, k_div, s_khi, s_klo, blocks)) return 0;
     if (dtype == EG_F32) hipLaunchKernelGGL(pack_strided2_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (float*)wp, N, K, Kpad, n_div, s_hi, s_lo, k_div, s_khi, s_klo);
     else if (dtype == EG_F16) hipLaunchKernelGGL(pack_strided2_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (f16_t*)wp, N, K, Kpad, n_div, s_hi, s_lo, k_div, s_khi, s_klo);
     else hipLaunchKernelGGL(pack_strided2_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)wp, N, K, Kpad, n_div, s_hi, s_lo, k_div, s_khi, s_klo);
@@ -1570,9 +1596,118 @@ extern "C" int eg_pack_strided(int dtype, const float* w, void* wp, int N, int K
     EG_REQUIRE(w && wp && N > 0 && K > 0 && Kpad >= K && n_div > 0, "eg_pack_strided: bad argument");
     const long long total = (long long)N * Kpad;
     const int blocks = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (pack_record_strided(1, dtype, w, wp, N, K, Kpad, n_div, s_hi, s_lo, s_k, 1, 0, 0, blocks)) return 0;
     if (dtype == EG_F32) hipLaunchKernelGGL(pack_strided_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (float*)wp, N, K, Kpad, n_div, s_hi, s_lo, s_k);
     else if (dtype == EG_F16) hipLaunchKernelGGL(pack_strided_kernel<f16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (f16_t*)wp, N, K, Kpad, n_div, s_hi, s_lo, s_k);
     else hipLaunchKernelGGL(pack_strided_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)s, w, (bf16_t*)wp, N, K, Kpad, n_div, s_hi, s_lo, s_k);
+    EG_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Several packs in ONE launch.  The small networks re-pack 7-12 panels per optimizer update, each a 5 us launch of a few workgroups on a
+// chain that is launch-bound end to end (dSprites: 46 of 290 launches per iteration).  eg_pack_record_begin() turns the pack entry points
+// above into recorders (nothing is launched), eg_pack_record_end() hands the recorded jobs to the caller, who keeps them in device memory;
+// eg_pack_multi() runs them: workgroup -> job by the jobs' first-workgroup table, then the SAME body the stand-alone kernel runs.
+// ------------------------------------------------------------------------------------------------
+struct PackStridedParams {
+    const float* w;
+    void* wp;
+    int N, K, Kpad, n_div, k_div;
+    long long s_hi, s_lo, s_k, s_khi, s_klo;
+};
+struct PackJob {
+    int kind;           // 0 gather (pack_kernel), 1 strided, 2 strided2, 3 tile
+    int dtype;
+    int gx, gy;         // the stand-alone launch's grid
+    int block0;         // first workgroup of this job in the joint launch
+    int pad;
+    union {
+        PackParams g;
+        PackStridedParams s;
+        PackTileParams t;
+    };
+};
+static thread_local std::vector<PackJob>* g_pack_rec = nullptr;
+
+static bool pack_record_gather(const PackParams& p, int dtype, int gx, int gy) {
+    if (!g_pack_rec) return false;
+    PackJob j;
+    memset(&j, 0, sizeof(j));
+    j.kind = 0; j.dtype = dtype; j.gx = gx; j.gy = gy; j.g = p;
+    g_pack_rec->push_back(j);
+    return true;
+}
+static bool pack_record_strided(int kind, int dtype, const float* w, void* wp, int N, int K, int Kpad, int n_div, long long s_hi, long long s_lo,
+                                long long s_k, int k_div, long long s_khi, long long s_klo, int gx) {
+    if (!g_pack_rec) return false;
+    PackJob j;
+    memset(&j, 0, sizeof(j));
+    j.kind = kind; j.dtype = dtype; j.gx = gx; j.gy = 1;
+    j.s = PackStridedParams{w, wp, N, K, Kpad, n_div, k_div, s_hi, s_lo, s_k, s_khi, s_klo};
+    g_pack_rec->push_back(j);
+    return true;
+}
+static bool pack_record_tile(const PackTileParams& p, int dtype, int gx, int gy) {
+    if (!g_pack_rec) return false;
+    PackJob j;
+    memset(&j, 0, sizeof(j));
+    j.kind = 3; j.dtype = dtype; j.gx = gx; j.gy = gy; j.t = p;
+    g_pack_rec->push_back(j);
+    return true;
+}
+
+template <typename T>
+__device__ __forceinline__ void pack_job_run(const PackJob& j, float* tile, int bx, int by) {
+    switch (j.kind) {
+        case 0: pack_gather_body<T>(j.g, bx, by, j.gx); break;
+        case 1: pack_strided_body<T>(j.s.w, reinterpret_cast<T*>(j.s.wp), j.s.N, j.s.K, j.s.Kpad, j.s.n_div, j.s.s_hi, j.s.s_lo, j.s.s_k, bx, j.gx); break;
+        case 2: pack_strided2_body<T>(j.s.w, reinterpret_cast<T*>(j.s.wp), j.s.N, j.s.K, j.s.Kpad, j.s.n_div, j.s.s_hi, j.s.s_lo, j.s.k_div, j.s.s_khi, j.s.s_klo, bx, j.gx); break;
+        default:
+            if (j.t.T == 16) pack_conv_tile_body<T, 16>(j.t, tile, bx, by);
+            else pack_conv_tile_body<T, 0>(j.t, tile, bx, by);
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
+    __shared__ float tile[16 * 32 * 17];
+    int ji = 0;
+    while (ji + 1 < njobs && (int)blockIdx.x >= jobs[ji + 1].block0) ++ji;      // (uniform: scalar loads)
+    const PackJob& j = jobs[ji];
+    const int local = blockIdx.x - j.block0, bx = local % j.gx, by = local / j.gx;
+    if (j.dtype == EG_F32) pack_job_run<float>(j, tile, bx, by);
+    else if (j.dtype == EG_F16) pack_job_run<f16_t>(j, tile, bx, by);
+    else pack_job_run<bf16_t>(j, tile, bx, by);
+}
+
+extern "C" int eg_pack_record_begin(void) {
+    EG_REQUIRE(!g_pack_rec, "eg_pack_record_begin: already recording");
+    g_pack_rec = new std::vector<PackJob>();
+    return 0;
+}
+extern "C" size_t eg_pack_job_bytes(void) { return sizeof(PackJob); }
+/* ends the recording; copies the jobs (eg_pack_job_bytes() each) into host memory `jobs_out` of `cap_bytes` bytes; *njobs / *nblocks: what
+ * eg_pack_multi wants back together with a DEVICE copy of jobs_out */
+extern "C" int eg_pack_record_end(void* jobs_out, size_t cap_bytes, int* njobs, int* nblocks) {
+    EG_REQUIRE(g_pack_rec, "eg_pack_record_end: not recording");
+    std::vector<PackJob>* rec = g_pack_rec;
+    g_pack_rec = nullptr;
+    int nb = 0;
+    for (PackJob& j : *rec) { j.block0 = nb; nb += j.gx * j.gy; }
+    const size_t need = rec->size() * sizeof(PackJob);
+    const bool ok = jobs_out && njobs && nblocks && need <= cap_bytes;
+    if (ok) {
+        memcpy(jobs_out, rec->data(), need);
+        *njobs = (int)rec->size();
+        *nblocks = nb;
+    }
+    delete rec;
+    EG_REQUIRE(ok, "eg_pack_record_end: the job table does not fit (or null argument)");
+    return 0;
+}
+extern "C" int eg_pack_multi(const void* jobs_dev, int njobs, int nblocks, eg_stream_t s) {
+    EG_REQUIRE(jobs_dev && njobs > 0 && nblocks > 0, "eg_pack_multi: bad argument");
+    hipLaunchKernelGGL(pack_multi_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)s, reinterpret_cast<const PackJob*>(jobs_dev), njobs);
     EG_LAUNCH_CHECK();
     return 0;
 }

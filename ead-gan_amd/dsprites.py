@@ -58,6 +58,7 @@ class _PxyEngine:
         self.out = torch.empty(B, self.nout, device=dev, dtype=torch.float32)
         self.repack()
 
+    @ops.batched_packs
     def repack(self):
         cb = self.mod.conv_block
         ops.pack_strided(self.dtype, cb[0].weight, self.l0.wp_fwd, TRUNK[0], self.k0, self.l0.Kpad_fwd, 1, self.k0, 0, 1)
@@ -232,6 +233,7 @@ class _GenEngine:
         ws.need_sums(128)
         self.repack()
 
+    @ops.batched_packs
     def repack(self):
         dt, g = self.dtype, self.gen
         cb = g.conv_block
@@ -475,6 +477,7 @@ class _PxyTrainEngine:
         self.out = torch.empty(NB, self.nout, device=dev, dtype=torch.float32)
         self.repack()
 
+    @ops.batched_packs
     def repack(self):
         cb = self.mod.conv_block
         ops.pack_strided(self.dtype, cb[0].weight, self.l0.wp_fwd, TRUNK[0], self.k0, self.l0.Kpad_fwd, 1, self.k0, 0, 1)

@@ -95,6 +95,11 @@ class _GenEngine:
         return m
 
     def repack(self):
+        self._repack_masters()
+        self.c3.pack(self.w3pad)                        # (reads the padded copy the batch above has just written: its own launch)
+
+    @ops.batched_packs
+    def _repack_masters(self):
         dt, g = self.dtype, self.gen
         hw = g.init_size ** 2
         w, b = g.l1[0].weight, g.l1[0].bias
@@ -105,7 +110,6 @@ class _GenEngine:
         self.c2.pack(g.conv_blocks[6].weight)
         self.c3f.pack(g.conv_blocks[9].weight)
         ops.pack_strided(EG_F32, g.conv_blocks[9].weight, self.w3pad, self.CH, 576, 576, 1, 576, 0, 1)
-        self.c3.pack(self.w3pad)
 
     def forward(self, noise, labels, code, training=True, sync=None):
         """``training=False``: BatchNorm with the running statistics, nothing updated (module.eval()).  ``sync`` (a dp.SyncBN):
@@ -627,6 +631,7 @@ class ApproximatorTrainer:
     def _lin(self, i):
         return self.mlp.fc_block[2 * i]
 
+    @ops.batched_packs
     def repack(self):
         ops.pack_strided(self.dtype, self._lin(0).weight, self.l[0].wp_fwd, 256, 6, self.l[0].Kpad_fwd, 1, 6, 0, 1)
         for i in (1, 2, 3):

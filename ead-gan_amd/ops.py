@@ -304,6 +304,54 @@ def head_fused_ok(dtype, T, K, N):
     return bool(lib().cdll.eg_head_fused_ok(dtype, T, K, N))
 
 
+PACK_BATCH = os.environ.get("EG_PACK_BATCH", "1") != "0"      # 0: every pack its own launch (A/B runs)
+
+
+class PackBatch:
+    """The pack launches issued by ``fn()`` as ONE launch (eg_pack_record_begin / _end / eg_pack_multi).  Eager calls record again (host
+    work only) and re-upload the job table if a pointer or a geometry changed; inside a hipGraph capture the table of the last eager call
+    is launched as it is (the capture contract: an eager iteration has run on the same buffers)."""
+    MAX_JOBS = 64
+
+    def __init__(self):
+        self.host = None
+        self.dev = None
+        self.n = self.nb = 0
+
+    def run(self, fn):
+        if not PACK_BATCH:
+            return fn()
+        if not (self.dev is not None and torch.cuda.is_current_stream_capturing()):
+            jb = lib().cdll.eg_pack_job_bytes()
+            cap = self.MAX_JOBS * jb
+            buf = ctypes.create_string_buffer(cap)
+            n, nb = ctypes.c_int(0), ctypes.c_int(0)
+            lib().call("eg_pack_record_begin")
+            try:
+                fn()
+            finally:
+                lib().call("eg_pack_record_end", buf, cap, ctypes.byref(n), ctypes.byref(nb))
+            host = buf.raw[:n.value * jb]
+            if host != self.host:
+                self.host, self.n, self.nb = host, n.value, nb.value
+                self.dev = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(torch.device("cuda", torch.cuda.current_device())) if host else None
+        if self.dev is not None and self.n:
+            lib().call("eg_pack_multi", _p(self.dev), self.n, self.nb, _stream())
+
+
+def batched_packs(fn):
+    """decorator of an engine's ``repack...`` method: its pack launches run as one (PackBatch per method and argument tuple)"""
+    def wrapper(self, *a):
+        batches = self.__dict__.setdefault("_pack_batches", {})
+        key = (fn.__name__,) + a
+        b = batches.get(key)
+        if b is None:
+            b = batches[key] = PackBatch()
+        return b.run(lambda: fn(self, *a))
+    wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
+    return wrapper
+
+
 def dense_small_fwd_slices(dtype, x, wp, B, K, Kpad, N, ws):
     """the K-slice sums of dense_small_fwd (no combine launch) -> number of slices in ``ws`` [slice][B][N]"""
     ns = ctypes.c_int(0)

@@ -139,6 +139,7 @@ class TrunkEngine:
         self.repack()
 
     # ------------------------------------------------------------------------------------------------------------------
+    @ops.batched_packs
     def repack(self):
         dt = self.dtype
         self.l0img.pack(self.convs[0].weight_orig)

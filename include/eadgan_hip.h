@@ -256,6 +256,15 @@ int eg_dense_small_fwd_sn(int dtype, const void* x, const void* wp, const float*
 int eg_head_prep_sn(int dtype, const float* dy, int ldy, const float* y, int ldyy, const float* bias, int rows, int N,
                     const float* sigma, int rows_per_tape, void* dys, int npad, int col0, float* gb, float* coef,
                     float* dys32, int ld32, eg_stream_t s);
+/* Several weight packs in ONE launch (the small networks re-pack 7-12 panels per optimizer update, each a launch of a few workgroups on
+ * a launch-bound chain).  Between eg_pack_record_begin() and eg_pack_record_end() the calling thread's eg_pack_fwd / eg_pack_bwd /
+ * eg_pack_conv / eg_pack_strided / eg_pack_strided2 calls launch nothing and are recorded as jobs; _end copies the jobs (eg_pack_job_bytes()
+ * bytes each) to host memory jobs_out and returns their count and the joint launch's workgroup count; eg_pack_multi runs a DEVICE copy of the
+ * job table: the same panel bytes as the recorded calls launched one by one. */
+int eg_pack_record_begin(void);
+size_t eg_pack_job_bytes(void);
+int eg_pack_record_end(void* jobs_out, size_t cap_bytes, int* njobs, int* nblocks);
+int eg_pack_multi(const void* jobs_dev, int njobs, int nblocks, eg_stream_t s);
 /* the K-slice sums of eg_dense_small_fwd without the combine launch: partials[slice][b][n] (ws_floats >= 16 * B * N), *nslice_out slices;
  * eg_head_fused adds them (slice order, + bias) */
 int eg_dense_small_fwd_slices(int dtype, const void* x, const void* wp, int B, int K, int Kpad, int N, float* partials, size_t ws_floats,

@@ -854,3 +854,55 @@ def test_pack_conv_tiled_equals_per_element_pack(dtype, k, stride, pad, Cin, Cou
     ops.pack_conv(c, dtype, w, f2, None)
     torch.cuda.synchronize()
     assert torch.equal(f0, f2)
+
+
+@pytest.mark.parametrize("dtype", [0, 1, 2])
+def test_packs_in_one_launch_give_the_same_panels(dtype):
+    """ops.PackBatch (eg_pack_record_begin / _end / eg_pack_multi): the weight packs of several layers as ONE launch -- tile kernel (4x4
+    stride-2 layer, both panels), per-element gather (ragged channel count), the two strided packs, an fp32 job beside 16-bit ones --
+    against the same packs launched one by one: identical panel bytes; the second run reuses the uploaded job table."""
+    tdt = ops.torch_dtype(dtype)
+    g = torch.Generator().manual_seed(3)
+    layers = [ops.make_conv(8, 16, 16, 64, 32, 4, 2, 1), ops.make_conv(8, 8, 8, 24, 40, 3, 1, 1), ops.make_conv(8, 8, 8, 32, 64, 4, 2, 1)]
+    masters = [torch.randn(c.Cout, c.Cin, c.k, c.k, generator=g).to(DEV) for c in layers]
+    w2 = torch.randn(1024, 128, generator=g).to(DEV)
+    bias = torch.randn(1024, generator=g).to(DEV)
+
+    def buffers():
+        bufs = []
+        for c in layers:
+            bufs.append((torch.full((ops.pack_fwd_elems(c, dtype),), 7, device=DEV, dtype=tdt),
+                         torch.full((ops.pack_bwd_elems(c, dtype),), 7, device=DEV, dtype=tdt) if c.stride <= 2 and c.k == 4 else None))
+        kp = ops.round_up(1024, ops.bk(dtype))
+        return bufs, torch.full((1024 * 128,), 7, device=DEV, dtype=tdt), torch.full((128 * kp,), 7, device=DEV, dtype=tdt), torch.full((1024,), 7.0, device=DEV)
+
+    def packs(bufs, f2, b2, bperm):
+        for c, w, (pf, pb) in zip(layers, masters, bufs):
+            ops.pack_conv(c, dtype, w, pf, pb)
+        ops.pack_strided(dtype, w2, f2, 1024, 128, 128, 64, 128, 16 * 128, 1)
+        ops.pack_strided2(dtype, w2, b2, 128, 1024, ops.round_up(1024, ops.bk(dtype)), 1, 1, 0, 64, 128, 16 * 128)
+        ops.pack_strided(0, bias, bperm, 1024, 1, 1, 64, 1, 16, 0)
+
+    ref = buffers()
+    packs(*ref)
+    got = buffers()
+    batch = ops.PackBatch()
+    batch.run(lambda: packs(*got))
+    torch.cuda.synchronize()
+    assert batch.n >= 6 and batch.dev is not None
+
+    def flat(b):
+        out = []
+        for pf, pb in b[0]:
+            out += [pf] + ([pb] if pb is not None else [])
+        return out + list(b[1:])
+    for a, b in zip(flat(ref), flat(got)):
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+    table = batch.dev
+    for t in flat(got):
+        t.fill_(3)
+    batch.run(lambda: packs(*got))
+    torch.cuda.synchronize()
+    assert batch.dev is table                                # same pointers, same geometry: no new upload
+    for a, b in zip(flat(ref), flat(got)):
+        assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
