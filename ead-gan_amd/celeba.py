@@ -965,6 +965,11 @@ BATCH_D12 = os.environ.get("EG_BATCH_D12", "0") != "0"
 # WITH branches on a second stream holds back later launches on the first, a one-chain graph does not; more HSA queues make it far worse,
 # profiles/r03_y_ab_hwq.txt).  Same bits (tests/test_gpu_celeba.py).  Single process only.
 MULTI_GRAPH = os.environ.get("EG_MULTI_GRAPH", "0") != "0"
+# EXPERIMENT (default off): step 3's generator forward between the forward and the backward of step 2 (pipelined body).  Same bits, but
+# slower, 4.46 -> 4.61 ms (profiles/r03_zb_ab_g3_mid.txt): behind step 2's backward the discriminator's update and step 3's power
+# iterations then run with nothing beside them -- that chain (update -> three power iterations -> patch rows), not the generator forward,
+# is what step 3's discriminator forward waits for.
+G3_MID = os.environ.get("EG_G3_MID", "0") != "0"
 ZERO_ON_PREP = os.environ.get("EG_ZERO_ON_PREP", "1") != "0"     # gradient zeroing of steps 1 / 2 on the preparation lane (0: on the main stream)
 SPLIT2_SET = set(filter(None, os.environ.get("EG_SPLIT2", "").split(",")))      # updates done in two pieces (early layers / rest): g1, d2, d3, g3
 DP_START = os.environ.get("EG_DP_START", "lane")
@@ -1355,10 +1360,19 @@ class CelebATrainer:
         else:
             ops.loss_bce_sigmoid(out[:B], 19, 0, B, 1.0, 0.5, self.losses[1:2], self.dout[:B])
             ops.loss_bce_sigmoid(out[B:], 19, 0, B, 0.0, 0.5, self.losses[1:2], self.dout[B:2 * B])
+        cut = getattr(self, "_cut", None)               # capture_segments: the iteration is being captured as several hipGraphs
+        g3_mid = G3_MID and cut is None and not self.g3_early and not BATCH_D12
+        if g3_mid:
+            # Step 3's generator forward HERE, between the discriminator step's forward and backward: it reads only G (new since step
+            # 1's update, long done) and writes only G's activations and the image buffer, whose step-1 content step 2 no longer needs
+            # (the discriminator read it in its forward; the patch rows its weight gradient reads were built by prep2).  Placed where
+            # the loop has it -- behind step 2's backward -- it starts ~200 us late and runs beside the power iterations at 2/3 speed
+            # (DESIGN.md 6.0); here it is plain main-chain work between two GEMM sequences.  Same kernels, same operands: same bits.
+            side.wait(evs["g"])
+            gen3 = ge.forward(self.z, self.onehot, self.code, sync=self.sync_bn)
         de.backward(0, 2, self.dout[:2 * B], da.grad, side=side, head_done=fh1)
         g3_first = os.environ.get("EG_G3_FIRST", "0") != "0"
         keep = side.deferred
-        cut = getattr(self, "_cut", None)               # capture_segments: the iteration is being captured as several hipGraphs
         if cut is not None:
             side.join()                                 # every chain of steps 1 and 2 (and the generator's update) ends in this segment
             side.cut()
@@ -1381,6 +1395,8 @@ class CelebATrainer:
         if self.g3_early:
             side.wait(evs["g3fwd"])
             gen = ge.img
+        elif g3_mid:
+            gen = gen3
         else:
             if cut is None:
                 side.wait(evs["g"])                     # G's panels and zeroed gradients (optimizer lane, step 1)

@@ -49,3 +49,29 @@ t_all = time.perf_counter() - t_all0
 print(f"host enqueue {t_enq / n * 1e3:.3f} ms/iter, GPU drained {t_all / n * 1e3:.3f} ms/iter")
 for i, a in enumerate(acc):
     print(f"segment {i} (stream {mg.segments[i][1]}): hipGraphLaunch {a / n * 1e6:.0f} us on the host")
+
+# GPU-side: when does each segment start and end relative to the end of the first segment (timing events on the segments' streams)?
+T = lambda: torch.cuda.Event(enable_timing=True)
+recs = []
+for it in range(12):
+    streams = (main, mg.second)
+    ev = {}
+    for i, (gr, s, after) in enumerate(mg.segments):
+        st = streams[s]
+        for j in after:
+            st.wait_event(mg._done[j])
+        with torch.cuda.stream(st):
+            b, e = T(), T()
+            b.record()
+            gr.replay()
+            e.record()
+        ev[i] = (b, e)
+        mg._done[i].record(st)
+    main.wait_event(mg._done[1])
+    recs.append(ev)
+torch.cuda.synchronize()
+for it in (5, 8, 11):
+    ev = recs[it]
+    a_end = ev[0][1]
+    print("iteration", it, " ".join(f"seg{i}: {a_end.elapsed_time(ev[i][0]) * 1e3:+7.0f}..{a_end.elapsed_time(ev[i][1]) * 1e3:+7.0f} us" for i in range(1, len(mg.segments))),
+          f"(segment 0 took {ev[0][0].elapsed_time(ev[0][1]) * 1e3:.0f} us)")
