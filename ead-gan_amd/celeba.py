@@ -965,6 +965,7 @@ BATCH_D12 = os.environ.get("EG_BATCH_D12", "0") != "0"
 # WITH branches on a second stream holds back later launches on the first, a one-chain graph does not; more HSA queues make it far worse,
 # profiles/r03_y_ab_hwq.txt).  Same bits (tests/test_gpu_celeba.py).  Single process only.
 MULTI_GRAPH = os.environ.get("EG_MULTI_GRAPH", "0") != "0"
+LAZY_PATCHES = os.environ.get("EG_LAZY_PATCHES", "1") != "0"
 # EXPERIMENT (default off): step 3's generator forward between the forward and the backward of step 2 (pipelined body).  Same bits, but
 # slower, 4.46 -> 4.61 ms (profiles/r03_zb_ab_g3_mid.txt): behind step 2's backward the discriminator's update and step 3's power
 # iterations then run with nothing beside them -- that chain (update -> three power iterations -> patch rows), not the generator forward,
@@ -1382,9 +1383,13 @@ class CelebATrainer:
             side.deferred = "1"                         # layer 0's chain, D's update and step 3's preparation are CAPTURED behind the generator forward's launches
         update(da, self.mD, self.vD, self.lr[1], 1, True, True, de, key_w="dw", where="d2")             # beside step 3's generator forward
 
-        def prep3(_ws):                                 # step 3's three power iterations (new weights), patch rows of scaled / real
+        # the first layer reads the images themselves (IMG_DIRECT): the patch rows are only the weight gradient's operand and are built by
+        # its own chain in step 3's backward -- not here, on the chain step 3's discriminator forward waits for (EG_LAZY_PATCHES=0: here)
+        lazy = LAZY_PATCHES and de.img_direct
+
+        def prep3(_ws):                                 # step 3's three power iterations (new weights) [, patch rows of scaled / real]
             side.wait(evs["dw"])
-            de.prepare(0, [None, self.scaled, self.real])
+            de.prepare(0, [None, None, None] if lazy else [None, self.scaled, self.real])
         side.defer_prep(prep3)
         if cut is not None:
             side.flush()
@@ -1408,7 +1413,7 @@ class CelebATrainer:
             cut(0, (1,))                                # behind the second stream's segment: D's panels, power iterations, patch rows
         else:
             side.join()                                 # D's panels, power iterations, patch rows
-        out = de.forward([gen, self.scaled, self.real], 0, prepared=(False, True, True), head=not fh3)
+        out = de.forward([gen, self.scaled, self.real], 0, prepared=(False, False, False) if lazy else (False, True, True), head=not fh3)
         if fh3:
             de.head_losses(0, 3, self.dout, self.losses[2:3], info=(1, cd, nc, self.code, self.labels, lcat, lcon, laff))
         else:
