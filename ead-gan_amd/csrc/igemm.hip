@@ -97,7 +97,10 @@ static int geom_bwd(const eg_conv* c, int dtype, NtParams& p, int* nphase) {
 // ------------------------------------------------------------------------------------------------
 // igemm_nt
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WGM, int WGN>
+// STAT: the epilogue with column statistics (eg_epilogue.stat_mode; 16-bit types, whole 128-row tiles, ONE column tile: N == BN) -- the
+// small networks' 32- and 64-channel layers, whose BatchNorm / bias-gradient reductions were 2-3 extra launches per layer on a chain
+// that is launch-bound end to end
+template <typename T, int BM, int BN, int WGM, int WGN, bool STAT = false>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
     constexpr int VEC = Elt<T>::VEC;
     constexpr int BK = 8 * VEC;
@@ -207,6 +210,13 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
 
     // ---- epilogue ----
     // acc[i][j][r] = C[m = m0 + (wm*TM+i)*16 + frow][n = n0 + (wn*TN+j)*16 + fq*4 + r]
+    if constexpr (STAT) {
+        NtEpiPre<T, TM, TN, 0> epi;
+        nt_epi_prefetch<T, BM, BN, TM, TN, 256, 0>(epi, p, ph, m0, n0, wm * TM * 16, wn * TN * 16, tid, frow, fq);
+        nt_epilogue_lds_stat<T, BM, BN, TM, TN, 256, 0>(epi, p, ph, acc, smem, m0, n0, wm * TM * 16, wn * TN * 16, tid, frow, fq,
+                                                        blockIdx.z * gridDim.x + blockIdx.x, 0, 1);
+        return;
+    }
     if (p.out_mode == EG_OUT_NHWC && (p.N % VEC) == 0) {
         // the shared epilogue: fp32 tile through LDS (16-byte chunks XOR-swizzled by row), then whole 16-byte vector stores
         nt_epilogue_lds<T, BM, BN, TM, TN, 256>(p, ph, acc, smem, m0, n0, wm * TM * 16, wn * TN * 16, tid, frow, fq);
@@ -839,6 +849,14 @@ template <typename T, int BM, int BN, int WGM, int WGN>
 static void launch_nt_cfg(const NtParams& p, int nphase, hipStream_t st) {
     dim3 grid(cdiv(p.M, BM), cdiv(p.N, BN), nphase);
     const size_t lds = 2 * (BM + BN) * 128 > BM * BN * 4 ? 2 * (BM + BN) * 128 : BM * BN * 4;
+    if constexpr (sizeof(T) == 2 && (BN == 64 || BN == 32)) {
+        if (p.stat_mode != EG_STAT_NONE) {              // (nt_stat_blocks has checked: whole tiles, N == BN)
+            // fp32 tile + the statistics' reduction scratch [2][rows lanes][BN] behind its first row
+            const size_t need = (size_t)(1 + 2 * (256 / (BN / 8))) * BN * 4;
+            hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, WGM, WGN, true>), grid, dim3(256), lds > need ? lds : need, st, p);
+            return;
+        }
+    }
     hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, WGM, WGN>), grid, dim3(256), lds, st, p);
 }
 
@@ -943,14 +961,16 @@ static int launch_nt(const NtParams& p, int nphase, int variant, int splitk, hip
             hipLaunchKernelGGL((igemm_nt_buf_kernel<T>), dim3(cdiv(p.M, 128), p.N / 128, nphase), dim3(256), lds, st, q);
         return 0;
     }
+    NtParams q = p;
+    q.stat_nrb = stat_nrb;
     if (p.N <= 16)
-        launch_nt_cfg<T, 128, 16, 4, 1>(p, nphase, st);
+        launch_nt_cfg<T, 128, 16, 4, 1>(q, nphase, st);
     else if (p.N <= 32)
-        launch_nt_cfg<T, 128, 32, 4, 1>(p, nphase, st);
+        launch_nt_cfg<T, 128, 32, 4, 1>(q, nphase, st);
     else if (p.N <= 64 || (variant != EG_NT_REG && (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * nphase < 512))
-        launch_nt_cfg<T, 128, 64, 2, 2>(p, nphase, st);
+        launch_nt_cfg<T, 128, 64, 2, 2>(q, nphase, st);
     else
-        launch_nt_cfg<T, 128, 128, 2, 2>(p, nphase, st);
+        launch_nt_cfg<T, 128, 128, 2, 2>(q, nphase, st);
     return 0;
 }
 
@@ -1011,6 +1031,9 @@ static bool nt_split_inkernel() {
 static int nt_stat_blocks(const NtParams& p, int nphase, const NtPlan& plan, bool half) {
     if (!half || p.out_mode != EG_OUT_NHWC) return 0;
     if (plan.kind == EG_NT_S8H) return (p.M % 128) == 0 ? nphase * (p.M / 128) : 0;          // row blocks of 128
+    // the register-staged kernel on 128 x 64 / 128 x 32 tiles (the small networks' layers): one column tile, whole row tiles
+    static const bool reg_stat = [] { const char* e = getenv("EG_NT_REG_STAT"); return !(e && atoi(e) == 0); }();
+    if (plan.kind == EG_NT_REG) return (reg_stat && (p.N == 64 || p.N == 32) && (p.M % 128) == 0) ? nphase * (p.M / 128) : 0;
     if (plan.kind != EG_NT_S8 || (p.M % 256) != 0) return 0;
     if (plan.ns > 1 && !nt_split_inkernel()) return 0;
     return nphase * (p.M / 256);
@@ -2467,10 +2490,11 @@ __global__ void colsum_sn_final_t_kernel(const float* __restrict__ stat, int nrb
 
 extern "C" int eg_bias_grad_sn_fused(const float* stat, int nrb, int N, int tiles_m, int tiles_per_tape, int ntapes, const float* sigma, float* gb,
                                      float* coef, eg_stream_t s) {
-    EG_REQUIRE(stat && sigma && gb && coef && nrb > 0 && N > 0 && (N % 128) == 0 && tiles_m > 0 && (nrb % tiles_m) == 0 && tiles_per_tape > 0 &&
-               ntapes > 0 && ntapes <= 4 && tiles_per_tape * ntapes == tiles_m, "eg_bias_grad_sn_fused: bad argument");
-    hipLaunchKernelGGL(colsum_sn_final_t_kernel, dim3(cdiv(N + ntapes, 4)), dim3(256), 0, (hipStream_t)s, stat, nrb, N, tiles_m, tiles_per_tape, N / 128, ntapes,
-                       sigma, gb, coef);
+    EG_REQUIRE(stat && sigma && gb && coef && nrb > 0 && N > 0 && ((N % 128) == 0 || N == 64 || N == 32) && tiles_m > 0 && (nrb % tiles_m) == 0 &&
+               tiles_per_tape > 0 && ntapes > 0 && ntapes <= 4 && tiles_per_tape * ntapes == tiles_m, "eg_bias_grad_sn_fused: bad argument");
+    // (column tiles of the producing launch: 128 wide for the 8-wave kernels, the whole row for the register-staged kernel's N = 32 / 64)
+    hipLaunchKernelGGL(colsum_sn_final_t_kernel, dim3(cdiv(N + ntapes, 4)), dim3(256), 0, (hipStream_t)s, stat, nrb, N, tiles_m, tiles_per_tape,
+                       N >= 128 ? N / 128 : 1, ntapes, sigma, gb, coef);
     EG_LAUNCH_CHECK();
     return 0;
 }

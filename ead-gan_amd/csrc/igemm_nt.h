@@ -475,13 +475,19 @@ __device__ __forceinline__ void nt_epilogue_lds_stat(const NtEpiPre<T, TM, TN, P
             o1[0] = t1;
         }
     }
-    if (mode == EG_STAT_SN_BIAS && tid < BNW) {        // waves 0 and 1 (BNW = 128): the tile's dot, added in wave order
-        const float w = wave_sum(t2);
+    constexpr int NWV = (BNW + 63) / 64;               // waves that hold the column threads (2 for BNW = 128, 1 for 64 / 32)
+    if (mode == EG_STAT_SN_BIAS && tid < NWV * 64) {   // the tile's dot, added in wave order (whole waves: the threads beyond BNW add zeros)
+        const float w = wave_sum(tid < BNW ? t2 : 0.f);
         if ((tid & 63) == 0) red[2 * RPP * BNW + (tid >> 6)] = w;
     }
     if (mode == EG_STAT_SN_BIAS) {
         __syncthreads();
-        if (tid == 0) p.stat_out[(size_t)p.N * p.stat_nrb + (size_t)rb * tiles_n + n_tile] = red[2 * RPP * BNW] + red[2 * RPP * BNW + 1];
+        if (tid == 0) {
+            float d = red[2 * RPP * BNW];
+#pragma unroll
+            for (int w = 1; w < NWV; ++w) d += red[2 * RPP * BNW + w];
+            p.stat_out[(size_t)p.N * p.stat_nrb + (size_t)rb * tiles_n + n_tile] = d;
+        }
     }
 }
 
