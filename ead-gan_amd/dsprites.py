@@ -14,7 +14,7 @@ import torch.nn as nn
 from torch.nn.utils import spectral_norm
 
 from . import ops
-from .celeba import IMG_GEMM, _HipModule, _require_cuda, transformation_2D      # noqa: F401
+from .celeba import FUSE_STATS, IMG_GEMM, _HipModule, _require_cuda, transformation_2D      # noqa: F401
 from .engine import Arena, ConvRec, DeviceSampler, ResidentStep, SideStream, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step, check_usable, parse_dtype
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, EG_F32, OUT_NCHW_F32
 from .trunk import Head, TrunkEngine
@@ -194,6 +194,7 @@ class _GenEngine:
         dev = gen.arena.flat.device
         tdt = ops.torch_dtype(dtype)
         self.ws = ws = Workspace.get(dev)
+        self._stat = {}                                 # fused-statistics buffers per launch (celeba._GenEngine._stat_buf)
         self.cin = gen.n_classes + gen.code_dim
         self.cpad = ops.round_up(self.cin, 8)
         self.CH = gen.channels
@@ -233,6 +234,13 @@ class _GenEngine:
         ws.need_sums(128)
         self.repack()
 
+    def _stat_buf(self, key, c, bwd, ep, C):
+        """(nrb, buffer) if the launch described by (c, bwd, ep) can take its column statistics in the epilogue, else (0, None)"""
+        if key not in self._stat:
+            nrb = ops.conv_stat_blocks(c, self.dtype, bwd, ep) if FUSE_STATS else 0
+            self._stat[key] = (nrb, torch.empty(2 * C * nrb, device=self.inp.device, dtype=torch.float32) if nrb else None)
+        return self._stat[key]
+
     @ops.batched_packs
     def repack(self):
         dt, g = self.dtype, self.gen
@@ -261,8 +269,17 @@ class _GenEngine:
         x = self.h
         for i, idx in enumerate((0, 3, 6)):
             r = self.mid[i]
-            ops.conv_bwd_data(r.c, dt, x, r.wp_bwd, self.z[i], ops.epilogue(bias=cb[idx].bias))
             bn = cb[idx + 1]
+            M = B * (8 << i) ** 2
+            nrb, stat = self._stat_buf(("fwd", i), r.c, True, ops.epilogue(bias=cb[idx].bias), 64) if (training and sync is None) else (0, None)
+            if nrb:
+                # BatchNorm batch statistics from the transposed convolution's epilogue (celeba._GenEngine.forward): two launches instead of three
+                ops.conv_bwd_data(r.c, dt, x, r.wp_bwd, self.z[i], ops.epilogue(bias=cb[idx].bias, stat_mode=ops.STAT_MOMENTS, stat_out=stat))
+                ops.bn_fwd_train_fused(dt, self.z[i], self.a[i], M, 64, stat, nrb, M // nrb, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean,
+                                       bn.running_var, bn.num_batches_tracked, self.mean[i], self.invstd[i], ws.small, ACT_RELU)
+                x = self.a[i]
+                continue
+            ops.conv_bwd_data(r.c, dt, x, r.wp_bwd, self.z[i], ops.epilogue(bias=cb[idx].bias))
             if training:
                 bn_train_forward(dt, self.z[i], self.a[i], B * (8 << i) ** 2, 64, bn, self.mean[i], self.invstd[i], ws.small, ACT_RELU, 0.0, sync,
                                  self.sync_scratch.stats[i])
@@ -296,13 +313,28 @@ class _GenEngine:
             ns = ops.conv_wgrad(self.l4p.c, dt, self.patches, self.a[2], wsw.slab, wsw.wgs_target)
             ops.wgrad_reduce_perm(wsw.slab, ns, 64, 64, self.kp, 1, gof("conv_block.9.weight"), 0, 0, self.k0)
         wgrad_side(l4_wgrad)
-        ops.conv_fwd(self.l4p.c, dt, self.patches, self.l4p.wp_fwd, self.da[2], None)
+
+        def bn_bwd_ep(i, c):
+            """(row blocks, sums, epilogue) if the launch that produces da[i] can also form dy = da * relu'(bn(z)) and the two sums of layer
+            i's BatchNorm backward (celeba._GenEngine.backward), else (0, None, None)"""
+            nrb, stat = self._stat_buf(("bwd", i), c, False, ops.epilogue(), 64) if sync is None else (0, None)
+            if not nrb:
+                return 0, None, None
+            bnl = cb[(0, 3, 6)[i] + 1]
+            return nrb, stat, ops.epilogue(stat_mode=ops.STAT_BN_BWD, stat_out=stat, stat_aux=self.z[i], stat_p=(self.mean[i], self.invstd[i], bnl.weight, bnl.bias),
+                                           stat_act=ACT_RELU)
+        fused = bn_bwd_ep(2, self.l4p.c)
+        ops.conv_fwd(self.l4p.c, dt, self.patches, self.l4p.wp_fwd, self.da[2], fused[2])
         for i, idx in ((2, 6), (1, 3), (0, 0)):
             r = self.mid[i]
             bn = cb[idx + 1]
             M = B * (8 << i) ** 2
-            bn_train_backward(dt, self.z[i], self.da[i], self.dz[i], M, 64, bn, self.mean[i], self.invstd[i], ACT_RELU, 0.0,
-                              gof(f"conv_block.{idx + 1}.weight"), gof(f"conv_block.{idx + 1}.bias"), ws, sync, self.sync_scratch.sums[i])
+            if fused[0]:
+                ops.bn_bwd_fused(dt, self.z[i], self.da[i], self.dz[i], M, 64, fused[1], fused[0], bn.weight, bn.bias, self.mean[i], self.invstd[i],
+                                 gof(f"conv_block.{idx + 1}.weight"), gof(f"conv_block.{idx + 1}.bias"), ws.sums, ws.small)
+            else:
+                bn_train_backward(dt, self.z[i], self.da[i], self.dz[i], M, 64, bn, self.mean[i], self.invstd[i], ACT_RELU, 0.0,
+                                  gof(f"conv_block.{idx + 1}.weight"), gof(f"conv_block.{idx + 1}.bias"), ws, sync, self.sync_scratch.sums[i])
             x_in = self.a[i - 1] if i > 0 else self.h
 
             def mid_wgrad(wsw, i=i, idx=idx, r=r, M=M, x_in=x_in):
@@ -311,7 +343,8 @@ class _GenEngine:
                 ops.bias_grad(dt, self.dz[i], M, 64, wsw.small, gof(f"conv_block.{idx}.bias"))
             wgrad_side(mid_wgrad)
             if i > 0:
-                ops.conv_fwd(r.c, dt, self.dz[i], r.wp_fwd, self.da[i - 1], None)
+                fused = bn_bwd_ep(i - 1, r.c)
+                ops.conv_fwd(r.c, dt, self.dz[i], r.wp_fwd, self.da[i - 1], fused[2])
             else:                                    # into the ReLU output of fc2: mask fused into the epilogue
                 ops.conv_fwd(r.c, dt, self.dz[i], r.wp_fwd, self.dh, ops.epilogue(mask=self.h, mask_act=ACT_RELU))
 
