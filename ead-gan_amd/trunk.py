@@ -18,6 +18,7 @@ from .engine import ConvRec, Workspace
 from .ops import ACT_LRELU, ACT_NONE, EG_F32, OUT_NCHW_F32
 
 IMG_GEMM = os.environ.get("EG_IMG_GEMM", "1") == "1"     # as in celeba.py
+FUSE_STATS = os.environ.get("EG_FUSE_STATS", "1") != "0"  # as in celeba.py
 
 SN_EPS = 1e-12
 
@@ -40,6 +41,7 @@ class TrunkEngine:
         self.owner, self.convs, self.conv_names, self.bns, self.bn_names = owner, convs, conv_names, bns, bn_names
         self.fcs, self.fc_names = list(fcs or []), list(fc_names or [])
         self.heads, self.B, self.dtype, self.NT, self.k, self.slope = heads, B, dtype, NT, k, slope
+        self._stat = {}                                 # fused-statistics buffers per (layer, tapes) (_sn_stat)
         self.in_ch, self.S = in_ch, size
         dev = owner.arena.flat.device
         self.ws = ws = Workspace.get(dev)
@@ -241,6 +243,19 @@ class TrunkEngine:
         return {h.name: self.outs[h.name][t0 * B:(t0 + T) * B] for h in self.heads if h.compute}
 
     # ------------------------------------------------------------------------------------------------------------------
+    def _sn_stat(self, i, T, c, ep):
+        """fused sums of layer i's bias gradient / spectral-norm coefficient in the backward-data launch that produces dzs_i (T tapes): (row
+        blocks, buffer), (0, None) where that launch cannot take them (4x4 stride-2 layers, whole 128-row tiles per tape and phase)"""
+        key = (i, T)
+        if key not in self._stat:
+            ok = FUSE_STATS and self.taps == 16 and self.rows(i + 1) % 128 == 0 and self.dtype != EG_F32
+            nrb = ops.conv_stat_blocks(c, self.dtype, True, ep) if ok else 0
+            if nrb % (4 * T):
+                nrb = 0
+            N = self.W[i]
+            self._stat[key] = (nrb, torch.empty(N * nrb + nrb * max(N // 128, 1), device=self.patches.device, dtype=torch.float32) if nrb else None)
+        return self._stat[key]
+
     def _bwd_pass(self, t0, T, douts, grad, need_wgrad, need_dimg, side=None):
         dt, B, ws, L = self.dtype, self.B, self.ws, self.L
         gof = lambda name: self.owner.arena.grad_of(name, grad)
@@ -307,6 +322,7 @@ class TrunkEngine:
         else:
             ops.dense_small_bwd(dt, dys32, self.head_rec.wp_fwd, self._sl(self.a[last], t0), self._sl(self.dz[last], t0), rows, self.K, kpad, self.ncomb,
                                 ACT_LRELU, self.slope, self.sigma[last][t0:], B)
+        fused = (0, None)                               # (row blocks, sums) if dzs_i came with its bias-gradient sums / spectral-norm dots
         for i in range(L - 1, -1, -1):
             bn = self.bns[i]
             if bn is not None:
@@ -317,20 +333,28 @@ class TrunkEngine:
                                 ws.sums, ws.small, ACT_LRELU, self.slope, self.sigma[i][t0:t0 + 1])
             geo = g["l0p"] if i == 0 else g["mid"][i - 1]
             if need_wgrad:
-                def layer_wgrad(wsw, i=i, geo=geo, nm=self.conv_names[i]):
-                    ops.bias_grad_sn(dt, self._sl(self.dz[i], t0), self._sl(self.a[i], t0), self.convs[i].bias, T * self.rows(i), self.W[i], self.rows(i),
-                                     self.sigma[i][t0:], self.slope, wsw.small, gof(nm + ".bias"), self.coef[i])
+                def layer_wgrad(wsw, i=i, geo=geo, nm=self.conv_names[i], fused=fused):
+                    if fused[0]:
+                        tiles_m = fused[0] // 4         # row blocks (128 lattice rows) per sub-pixel phase of the launch that produced dzs_i
+                        ops.bias_grad_sn_fused(fused[1], fused[0], self.W[i], tiles_m, tiles_m // T, T, self.sigma[i][t0:], gof(nm + ".bias"), self.coef[i])
+                    else:
+                        ops.bias_grad_sn(dt, self._sl(self.dz[i], t0), self._sl(self.a[i], t0), self.convs[i].bias, T * self.rows(i), self.W[i], self.rows(i),
+                                         self.sigma[i][t0:], self.slope, wsw.small, gof(nm + ".bias"), self.coef[i])
                     ns = ops.conv_wgrad(geo, dt, self._inp(i, t0), self._sl(self.dz[i], t0), wsw.slab, wsw.wgs_target)
                     ops.wgrad_reduce_rank1(wsw.slab, ns, self.W[i], self.W[i], self.cin[i], self.taps if i > 0 else 1, gof(nm + ".weight_orig"), T,
                                            self.coef[i], self.u[i][t0:], self.v[i][t0:], self.k0 if i == 0 else 0)
                 wgrad_side(layer_wgrad)
+            fused = (0, None)
             if i > 0:
                 if self.bns[i - 1] is not None:
                     ops.conv_bwd_data(geo, dt, self._sl(self.dz[i], t0), self.mid[i - 1].wp_bwd, self._sl(self.dyb[i - 1], t0), None)
                 else:
-                    ops.conv_bwd_data(geo, dt, self._sl(self.dz[i], t0), self.mid[i - 1].wp_bwd, self._sl(self.dz[i - 1], t0),
-                                      ops.epilogue(sigma=self.sigma[i - 1][t0:], sigma_rows=self.rows(i), mask=self._sl(self.a[i - 1], t0), mask_act=ACT_LRELU,
-                                                   mask_slope=self.slope))
+                    kw = dict(sigma=self.sigma[i - 1][t0:], sigma_rows=self.rows(i), mask=self._sl(self.a[i - 1], t0), mask_act=ACT_LRELU, mask_slope=self.slope)
+                    # ... and, from the same tile, layer i-1's bias-gradient column sums and spectral-norm coefficient (celeba._DiscEngine.backward)
+                    fused = self._sn_stat(i - 1, T, geo, ops.epilogue(**kw)) if need_wgrad else (0, None)
+                    if fused[0]:
+                        kw.update(stat_mode=ops.STAT_SN_BIAS, stat_out=fused[1], stat_p=(self.convs[i - 1].bias,), stat_slope=self.slope)
+                    ops.conv_bwd_data(geo, dt, self._sl(self.dz[i], t0), self.mid[i - 1].wp_bwd, self._sl(self.dz[i - 1], t0), ops.epilogue(**kw))
         if need_dimg:
             if self.l0g is not None and IMG_GEMM:
                 ops.conv_fwd(self.l0g.c, dt, self._sl(self.dz[0], t0), self.l0g.wp_fwd, self.cols0, None)
