@@ -506,6 +506,7 @@ class _DiscEngine:
                 self._sn_arrays.append(ops.sn_layers(ent))
             # own scratch: the power iterations may run on a side stream while the main stream uses the shared workspace
             self.sn_scratch = torch.empty(ops.sn_multi_ws_floats(self._sn_arrays[0]), device=self.ws.device, dtype=torch.float32)
+            self.sn_counters = torch.zeros(16, device=self.ws.device, dtype=torch.int32)      # arrival counters of the two-launch iteration
         return self._sn_arrays[t]
 
     def _m(self, i):
@@ -555,7 +556,7 @@ class _DiscEngine:
         return self._stat[key]
 
     def _sn_tape(self, t, training=True):
-        ops.sn_power_iter_multi(self._sn(t), self.sn_scratch, training, SN_EPS)
+        ops.sn_power_iter_multi(self._sn(t), self.sn_scratch, training, SN_EPS, self.sn_counters)
         if not training:
             for i in range(4):
                 self.u[i][t].copy_(self._m(i).weight_u)

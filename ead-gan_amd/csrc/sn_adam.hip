@@ -188,13 +188,125 @@ __global__ void snm_u_final_kernel(const SnMulti p, int training) {
     if (threadIdx.x == 0) p.sigma[l][0] = sg;
 }
 
+// ---- the same iteration in TWO launches: each stage's per-layer finish by the last workgroup of the layer to arrive ---------------------
+// (W^T u partial sums + the norm of v; W v + the norm of u and sigma).  On the chains that wait for a power iteration -- step 3 of the
+// CelebA iteration runs three in a row on freshly updated weights, the small networks six per iteration -- every launch is a dependent
+// ~5-10 us.  The finishing code is the 1024-thread code of snm_v_final / snm_u_final: stage one runs 1024-thread workgroups (each k's
+// partial sum does not depend on the workgroup shape), stage two's 256-thread workgroup walks the 16 "virtual waves" of that code in
+// order, so u, v and sigma keep their bits.  Hand-off: partial results are written through (agent-scope stores), vmcnt(0), a relaxed
+// counter per layer and stage (caller-owned, zeroed once, left at zero).
+__global__ __launch_bounds__(1024) void snm2_wtu_v_kernel(const SnMulti p, unsigned* __restrict__ cnt) {
+    __shared__ float sm[16];
+    __shared__ unsigned flag;
+    const int l = blockIdx.z, R = p.R[l], Kd = p.Kd[l];
+    if ((int)blockIdx.x * 1024 >= Kd) return;           // (uniform: this layer has fewer column blocks than the widest one)
+    const int k = blockIdx.x * 1024 + threadIdx.x;
+    float* partial = p.ws + p.ws_off[l];
+    if (k < Kd) {
+        const int rb = (R + SN_NRB - 1) / SN_NRB;
+        const int r0 = blockIdx.y * rb, r1 = min(R, r0 + rb);
+        const float* __restrict__ W = p.w[l];
+        const float* __restrict__ u = p.u[l];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int r = r0;
+        for (; r + 3 < r1; r += 4) {
+            a0 += W[(size_t)r * Kd + k] * u[r];
+            a1 += W[(size_t)(r + 1) * Kd + k] * u[r + 1];
+            a2 += W[(size_t)(r + 2) * Kd + k] * u[r + 2];
+            a3 += W[(size_t)(r + 3) * Kd + k] * u[r + 3];
+        }
+        for (; r < r1; ++r) a0 += W[(size_t)r * Kd + k] * u[r];
+        __hip_atomic_store(partial + (size_t)blockIdx.y * Kd + k, (a0 + a1) + (a2 + a3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned total = (unsigned)((Kd + 1023) / 1024) * SN_NRB;
+    if (threadIdx.x == 0) flag = __hip_atomic_fetch_add(cnt + 2 * l, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (flag != total - 1) return;
+    if (threadIdx.x == 0) __hip_atomic_store(cnt + 2 * l, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // snm_v_final_kernel's body (1024 threads)
+    float* v = p.v[l];
+    float* v_snap = p.v_snap[l];
+    float ss = 0.f;
+    for (int kk = threadIdx.x; kk < Kd; kk += 1024) {
+        float t = 0.f;
+        for (int r = 0; r < SN_NRB; ++r) t += __hip_atomic_load(partial + (size_t)r * Kd + kk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[kk] = t;
+        ss += t * t;
+    }
+    const float nrm = sqrtf(block_sum(ss, sm));
+    const float inv = 1.f / fmaxf(nrm, p.eps);
+    for (int kk = threadIdx.x; kk < Kd; kk += 1024) {
+        const float vn = v[kk] * inv;
+        v[kk] = vn;
+        if (v_snap) v_snap[kk] = vn;
+    }
+}
+
+// block_sum of a 1024-thread workgroup, computed by 256 threads: virtual thread vt = 64 * vw + lane of virtual wave vw = w, w + 4, w + 8,
+// w + 12 belongs to physical wave w; wave sums go to sm[vw], then the 16 are added in order (block_sum's order)
+template <typename F>
+__device__ __forceinline__ float block_sum_as_1024(F&& value_of_virtual_thread, float* sm) {
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int vw = w + 4 * q;
+        const float s = wave_sum(value_of_virtual_thread(64 * vw + lane));
+        if (lane == 0) sm[vw] = s;
+    }
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < 16; ++i) r += sm[i];
+    return r;
+}
+
+__global__ __launch_bounds__(256) void snm2_wv_u_kernel(const SnMulti p, unsigned* __restrict__ cnt) {
+    __shared__ float sm[16];
+    __shared__ unsigned flag;
+    const int l = blockIdx.z, R = p.R[l], Kd = p.Kd[l];
+    const int r = blockIdx.x;
+    if (r >= R) return;
+    const float* __restrict__ W = p.w[l] + (size_t)r * Kd;
+    const float* __restrict__ v = p.v[l];
+    float* s = p.ws + p.ws_off[l] + (size_t)SN_NRB * Kd;
+    float a = 0.f;
+    for (int k = threadIdx.x; k < Kd; k += blockDim.x) a += W[k] * v[k];
+    const float tot = block_sum(a, sm);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(s + r, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        flag = __hip_atomic_fetch_add(cnt + 2 * l + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (flag != (unsigned)(R - 1)) return;
+    if (threadIdx.x == 0) __hip_atomic_store(cnt + 2 * l + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // snm_u_final_kernel's training body as its 1024 threads would run it
+    float* u = p.u[l];
+    auto sr = [&](int i) { return __hip_atomic_load(s + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const float nrm = sqrtf(block_sum_as_1024([&](int vt) { float ss = 0.f; for (int i = vt; i < R; i += 1024) { const float x = sr(i); ss += x * x; } return ss; }, sm));
+    const float inv = 1.f / fmaxf(nrm, p.eps);
+    const float sg = block_sum_as_1024([&](int vt) {
+        float d = 0.f;
+        for (int i = vt; i < R; i += 1024) {
+            const float x = sr(i), un = x * inv;
+            u[i] = un;
+            if (p.u_snap[l]) p.u_snap[l][i] = un;
+            d += un * x;
+        }
+        return d; }, sm);
+    if (threadIdx.x == 0) p.sigma[l][0] = sg;
+}
+
 extern "C" size_t eg_sn_multi_ws_floats(const eg_sn_layer* layers, int nlayers) {
     size_t tot = 0;
     for (int i = 0; i < nlayers; ++i) tot += (size_t)SN_NRB * layers[i].Kd + layers[i].R;
     return tot;
 }
 
-extern "C" int eg_sn_power_iter_multi(const eg_sn_layer* layers, int nlayers, float* ws, int training, float eps, eg_stream_t s) {
+extern "C" int eg_sn_power_iter_multi2(const eg_sn_layer* layers, int nlayers, float* ws, unsigned int* counters, int training, float eps,
+                                       eg_stream_t s) {
     EG_REQUIRE(layers && ws && nlayers > 0 && nlayers <= SN_MAXL, "eg_sn_power_iter_multi: bad argument");
     SnMulti p;
     memset(&p, 0, sizeof(p));
@@ -211,6 +323,12 @@ extern "C" int eg_sn_power_iter_multi(const eg_sn_layer* layers, int nlayers, fl
     }
     p.ws = ws; p.eps = eps;
     hipStream_t st = (hipStream_t)s;
+    if (training && counters) {
+        hipLaunchKernelGGL(snm2_wtu_v_kernel, dim3(cdiv(maxK, 1024), SN_NRB, nlayers), dim3(1024), 0, st, p, counters);
+        hipLaunchKernelGGL(snm2_wv_u_kernel, dim3(maxR, 1, nlayers), dim3(256), 0, st, p, counters);
+        EG_LAUNCH_CHECK();
+        return 0;
+    }
     if (training) {
         hipLaunchKernelGGL(snm_wtu_partial_kernel, dim3(cdiv(maxK, 256), SN_NRB, nlayers), dim3(256), 0, st, p);
         hipLaunchKernelGGL(snm_v_final_kernel, dim3(1, 1, nlayers), dim3(1024), 0, st, p);
@@ -219,6 +337,10 @@ extern "C" int eg_sn_power_iter_multi(const eg_sn_layer* layers, int nlayers, fl
     hipLaunchKernelGGL(snm_u_final_kernel, dim3(1, 1, nlayers), dim3(1024), 0, st, p, training);
     EG_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int eg_sn_power_iter_multi(const eg_sn_layer* layers, int nlayers, float* ws, int training, float eps, eg_stream_t s) {
+    return eg_sn_power_iter_multi2(layers, nlayers, ws, nullptr, training, eps, s);
 }
 
 // ---- Adam -----------------------------------------------------------------------------------------

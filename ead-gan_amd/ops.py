@@ -496,8 +496,19 @@ def sn_multi_ws_floats(arr):
     return lib().query("eg_sn_multi_ws_floats", arr, len(arr))
 
 
-def sn_power_iter_multi(arr, ws, training=True, eps=1e-12):
-    lib().call("eg_sn_power_iter_multi", arr, len(arr), _p(ws), int(training), eps, _stream())
+# EXPERIMENT (default off): the power iteration of a network's layers as two launches instead of four (eg_sn_power_iter_multi2: each stage's
+# per-layer finish by the last workgroup to arrive).  Same bits, but slower in the step: CelebA 4.33 -> 4.38 ms, dSprites 1.413 -> 1.424
+# (profiles/r03_zf_ab_sn2.txt) -- the wide first stage runs 1024-thread workgroups and every layer's finish waits for its last row.
+SN_TWO_LAUNCHES = os.environ.get("EG_SN2", "0") != "0"
+
+
+def sn_power_iter_multi(arr, ws, training=True, eps=1e-12, counters=None):
+    """``counters``: int32 tensor of >= 2 * len(arr) zeros owned by the caller (one per engine and stream of use): the iteration runs as two
+    launches instead of four, same bits (eg_sn_power_iter_multi2)"""
+    if counters is None or not SN_TWO_LAUNCHES:
+        lib().call("eg_sn_power_iter_multi", arr, len(arr), _p(ws), int(training), eps, _stream())
+    else:
+        lib().call("eg_sn_power_iter_multi2", arr, len(arr), _p(ws), _p(counters), int(training), eps, _stream())
 
 
 def adam_step(p, g, m, v, n, lr, b1, b2, eps, step, tick=True):

@@ -137,6 +137,7 @@ class TrunkEngine:
                     for h in heads if h.sn]
             self._sn_arrays.append(ops.sn_layers(ent))
         ws.need_small(ops.sn_multi_ws_floats(self._sn_arrays[0]))
+        self.sn_counters = torch.zeros(16, device=dev, dtype=torch.int32)       # arrival counters of the two-launch power iteration
         self.imgs = [None] * NT
         self.repack()
 
@@ -222,7 +223,7 @@ class TrunkEngine:
         for kk, img in enumerate(imgs):
             t = t0 + kk
             self.imgs[t] = img
-            ops.sn_power_iter_multi(self._sn_arrays[t], self.ws.small, training, SN_EPS)
+            ops.sn_power_iter_multi(self._sn_arrays[t], self.ws.small, training, SN_EPS, self.sn_counters)
             if not training:
                 for i, c in enumerate(self.convs):
                     self.u[i][t].copy_(c.weight_u)

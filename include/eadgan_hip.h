@@ -343,6 +343,11 @@ typedef struct eg_sn_layer {
 } eg_sn_layer;
 size_t eg_sn_multi_ws_floats(const eg_sn_layer* layers, int nlayers);
 int eg_sn_power_iter_multi(const eg_sn_layer* layers, int nlayers, float* ws, int training, float eps, eg_stream_t s);
+/* the same iteration (same u, v, sigma bits) in TWO launches instead of four: each stage's per-layer finish runs in the last workgroup of
+ * the layer to arrive.  counters: >= 2 * nlayers unsigned, zeroed once by the caller, left at zero; NULL (or training == 0) = the four
+ * launches of eg_sn_power_iter_multi.  One counters array must not be lent to two calls that may run concurrently. */
+int eg_sn_power_iter_multi2(const eg_sn_layer* layers, int nlayers, float* ws, unsigned int* counters, int training, float eps,
+                            eg_stream_t s);
 
 /* --- Adam (torch.optim.Adam, celebA/EAD-GAN_celebA.py:211-217) over a flat fp32 arena ----------------------- */
 int eg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float b1, float b2, float eps,

@@ -543,6 +543,20 @@ def test_spectral_norm_multi_layer_launch_matches_single():
         torch.testing.assert_close(us, u1, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(vs, v1, rtol=1e-5, atol=1e-6)
         torch.testing.assert_close(sg, s1, rtol=1e-5, atol=1e-6)
+    # the two-launch form (each stage finished by the layer's last workgroup to arrive): the four-launch form's bits, twice in a row
+    # (the arrival counters must come back to zero)
+    state = [(u.clone(), v.clone()) for (w, u, v, sg, us, vs) in ent]
+    ops.sn_power_iter_multi(arr, ws, True, 1e-12)
+    four = [(u.clone(), v.clone(), sg.clone(), us.clone(), vs.clone()) for (w, u, v, sg, us, vs) in ent]
+    counters = torch.zeros(16, device=DEV, dtype=torch.int32)
+    for rep in range(2):
+        for (w, u, v, sg, us, vs), (u0, v0) in zip(ent, state):
+            u.copy_(u0); v.copy_(v0); sg.fill_(-1); us.fill_(-1); vs.fill_(-1)
+        ops.sn_power_iter_multi(arr, ws, True, 1e-12, counters)
+        torch.cuda.synchronize()
+        assert int(counters.abs().sum()) == 0
+        for (w, u, v, sg, us, vs), (u4, v4, s4, us4, vs4) in zip(ent, four):
+            assert torch.equal(u, u4) and torch.equal(v, v4) and torch.equal(sg, s4) and torch.equal(us, us4) and torch.equal(vs, vs4)
 
 
 # eg_epilogue.nt_variant values (include/eadgan_hip.h EG_NT_*) -> label eg_igemm_nt_tile reports for the 128-column cases below
