@@ -519,7 +519,7 @@ def test_tanh_backward_with_bias_gradient_and_cast_pad():
         assert float(dst.float().abs()[:, 19:].max()) == 0.0
 
 
-def test_spectral_norm_multi_layer_launch_matches_single():
+def test_spectral_norm_multi_layer_launch_matches_single(monkeypatch):
     g = torch.Generator().manual_seed(13)
     shapes = [(128, 48), (256, 2048), (512, 4096), (16, 9)]
     ws_single = torch.empty(max(ops.sn_ws_floats(r, k) for r, k in shapes), device=DEV)
@@ -549,6 +549,7 @@ def test_spectral_norm_multi_layer_launch_matches_single():
     ops.sn_power_iter_multi(arr, ws, True, 1e-12)
     four = [(u.clone(), v.clone(), sg.clone(), us.clone(), vs.clone()) for (w, u, v, sg, us, vs) in ent]
     counters = torch.zeros(16, device=DEV, dtype=torch.int32)
+    monkeypatch.setattr(ops, "SN_TWO_LAUNCHES", True)       # (an experiment switch, default off: EG_SN2)
     for rep in range(2):
         for (w, u, v, sg, us, vs), (u0, v0) in zip(ent, state):
             u.copy_(u0); v.copy_(v0); sg.fill_(-1); us.fill_(-1); vs.fill_(-1)
