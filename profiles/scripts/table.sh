@@ -8,7 +8,7 @@ run --workload celeba --dtype bf16 --batch 512
 run --workload celeba --dtype bf16 --batch 128 --resident-inputs
 run --workload celeba --dtype bf16 --batch 128 --no-graph
 run --workload celeba --dtype bf16 --batch 128 --force-dist
-run --workload celeba --dtype bf16 --batch 128 --force-dist --wire bf16
+MASTER_PORT=29531 run --workload celeba --dtype bf16 --batch 128 --force-dist --wire bf16     # (own port: the previous row's socket may still be closing)
 run --workload mnist --dtype f32 --batch 256
 run --workload mnist --dtype bf16 --batch 128
 run --workload dsprites --dtype bf16 --batch 128
