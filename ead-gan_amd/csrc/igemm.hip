@@ -100,7 +100,10 @@ static int geom_bwd(const eg_conv* c, int dtype, NtParams& p, int* nphase) {
 // STAT: the epilogue with column statistics (eg_epilogue.stat_mode; 16-bit types, whole 128-row tiles, ONE column tile: N == BN) -- the
 // small networks' 32- and 64-channel layers, whose BatchNorm / bias-gradient reductions were 2-3 extra launches per layer on a chain
 // that is launch-bound end to end
-template <typename T, int BM, int BN, int WGM, int WGN, bool STAT = false>
+// SPLITK: blockIdx.z = phase * nsplit + split; every workgroup runs a slice of the K loop, the last of a tile's workgroups to arrive adds
+// the fp32 partial tiles in split order (its own from registers) and runs the epilogue (protocol and comments: igemm_nt8s.hip).  For the
+// small networks' few-row / deep-K launches (a 4 x 4 output map: 16-48 tiles on 256 CUs, 16 dependent K steps of ~1.4 us each).
+template <typename T, int BM, int BN, int WGM, int WGN, bool STAT = false, bool SPLITK = false>
 __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
     constexpr int VEC = Elt<T>::VEC;
     constexpr int BK = 8 * VEC;
@@ -111,7 +114,9 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
     static_assert(WGM * WGN == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const NtPhase ph = p.ph[blockIdx.z];
+    const int nsplit = SPLITK && p.nsplit > 1 ? p.nsplit : 1;
+    const int phase = blockIdx.z / nsplit, split = blockIdx.z - phase * nsplit;
+    const NtPhase ph = p.ph[phase];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -130,13 +135,20 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
         a_y[i] = ((m >> p.lOW) & OHm) * p.sy + ph.dy0;
         a_x[i] = (m & OWm) * p.sx + ph.dx0;
     }
-    // tap state of this thread's 16-byte chunk
-    int kc = chunk * VEC, ty = 0, tx = 0;
-    while (kc >= p.C) { kc -= p.C; if (++tx == ph.TW) { tx = 0; ++ty; } }
-
     const T* __restrict__ src = reinterpret_cast<const T*>(p.src);
     const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp) + ph.w_off;
-    const int nk = ph.Kpad / BK;
+    const int nk_all = ph.Kpad / BK;
+    const int per = (nk_all + nsplit - 1) / nsplit;
+    const int kt0 = split * per;
+    const int nk = max(0, min(per, nk_all - kt0));
+    // tap state of this thread's 16-byte chunk at K tile kt0
+    int kc = kt0 * BK + chunk * VEC, ty = 0, tx = 0;
+    if (kc >= p.C) {
+        const int tap = kc / p.C;
+        kc -= tap * p.C;
+        ty = tap / ph.TW;
+        tx = tap - ty * ph.TW;
+    }
 
     uint4 ra[A_LD], rb[B_LD];
     auto gload = [&](int kt) {
@@ -184,12 +196,12 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
 
     const int frow = lane & 15, fq = lane >> 4;
     if (nk > 0) {
-        gload(0);
+        gload(kt0);
         lstore(0);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) gload(kt + 1);
+        if (kt + 1 < nk) gload(kt0 + kt + 1);
         const char* sa = smem + (kt & 1) * STAGE;
         const char* sb = sa + BM * 128;
 #pragma unroll
@@ -208,13 +220,70 @@ __global__ __launch_bounds__(256) void igemm_nt_kernel(const NtParams p) {
         __syncthreads();
     }
 
+    if (SPLITK && nsplit > 1) {
+        const int nphase = gridDim.z / nsplit;
+        const size_t Mpad = (size_t)gridDim.x * BM;
+        const size_t slab = (size_t)nphase * Mpad * p.N;
+        float* part = p.part + ((size_t)phase * Mpad + m0) * p.N + n0;
+        float* mine = part + (size_t)split * slab;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int row = (wm * TM + i) * 16 + frow;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float* a = mine + (size_t)row * p.N + (wn * TN + j) * 16 + fq * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) __hip_atomic_store(a + r, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // written through
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* cnt = p.split_cnt + ((size_t)phase * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        volatile unsigned* flag = reinterpret_cast<volatile unsigned*>(smem);
+        if (tid == 0) flag[0] = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (flag[0] != (unsigned)(nsplit - 1)) return;
+        if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f32x4 sum[TM][TN];
+        for (int s = 0; s < nsplit; ++s) {             // uniform; own partial from registers: the order does not depend on who is last
+            if (s == split) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) sum[i][j] = s == 0 ? acc[i][j] : sum[i][j] + acc[i][j];
+                continue;
+            }
+            const float* other = part + (size_t)s * slab;
+            f32x4 ld[TM][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 16 + frow;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float* a = other + (size_t)row * p.N + (wn * TN + j) * 16 + fq * 4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ld[i][j][r] = __hip_atomic_load(a + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) sum[i][j] = s == 0 ? ld[i][j] : sum[i][j] + ld[i][j];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = sum[i][j];
+        __syncthreads();
+    }
+
     // ---- epilogue ----
     // acc[i][j][r] = C[m = m0 + (wm*TM+i)*16 + frow][n = n0 + (wn*TN+j)*16 + fq*4 + r]
     if constexpr (STAT) {
         NtEpiPre<T, TM, TN, 0> epi;
         nt_epi_prefetch<T, BM, BN, TM, TN, 256, 0>(epi, p, ph, m0, n0, wm * TM * 16, wn * TN * 16, tid, frow, fq);
         nt_epilogue_lds_stat<T, BM, BN, TM, TN, 256, 0>(epi, p, ph, acc, smem, m0, n0, wm * TM * 16, wn * TN * 16, tid, frow, fq,
-                                                        blockIdx.z * gridDim.x + blockIdx.x, 0, 1);
+                                                        phase * gridDim.x + blockIdx.x, 0, 1);
         return;
     }
     if (p.out_mode == EG_OUT_NHWC && (p.N % VEC) == 0) {
@@ -847,17 +916,45 @@ static NtPlan nt_plan_auto(const NtParams& p, int nphase, const NtFacts& f, size
 
 template <typename T, int BM, int BN, int WGM, int WGN>
 static void launch_nt_cfg(const NtParams& p, int nphase, hipStream_t st) {
-    dim3 grid(cdiv(p.M, BM), cdiv(p.N, BN), nphase);
+    const int ns = p.nsplit > 1 ? p.nsplit : 1;
+    dim3 grid(cdiv(p.M, BM), cdiv(p.N, BN), nphase * ns);
     const size_t lds = 2 * (BM + BN) * 128 > BM * BN * 4 ? 2 * (BM + BN) * 128 : BM * BN * 4;
     if constexpr (sizeof(T) == 2 && (BN == 64 || BN == 32)) {
         if (p.stat_mode != EG_STAT_NONE) {              // (nt_stat_blocks has checked: whole tiles, N == BN)
             // fp32 tile + the statistics' reduction scratch [2][rows lanes][BN] behind its first row
             const size_t need = (size_t)(1 + 2 * (256 / (BN / 8))) * BN * 4;
-            hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, WGM, WGN, true>), grid, dim3(256), lds > need ? lds : need, st, p);
+            if (ns > 1) hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, WGM, WGN, true, true>), grid, dim3(256), lds > need ? lds : need, st, p);
+            else hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, WGM, WGN, true>), grid, dim3(256), lds > need ? lds : need, st, p);
+            return;
+        }
+    }
+    if constexpr (BN == 64 || BN == 32) {
+        if (ns > 1) {
+            hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, WGM, WGN, false, true>), grid, dim3(256), lds, st, p);
             return;
         }
     }
     hipLaunchKernelGGL((igemm_nt_kernel<T, BM, BN, WGM, WGN>), grid, dim3(256), lds, st, p);
+}
+
+// K splits of the register-staged kernel (N = 32 / 64, NHWC output): few tiles and a deep K loop
+// EXPERIMENT, default off (EG_NT_REG_SPLIT=1 or eg_epilogue.nt_splitk > 1 turn it on): correct (tested) but slower in the small networks'
+// steps -- dSprites 1.415 -> 1.503 ms, colored / MNIST +0.2-0.8 % (profiles/r03_zg_ab_reg_split.txt): the 16-48-tile launches it targets
+// are not the ~22 us the profiler shows for them once the profiler is off, and the split adds partial-tile traffic and a serial finish.
+template <typename T>
+static int nt_reg_splits(const NtParams& p, int nphase, int forced) {
+    static const bool env_on = [] { const char* e = getenv("EG_NT_REG_SPLIT"); return e && atoi(e) != 0; }();
+    const bool on = env_on || forced > 1;
+    if (!on || p.out_mode != EG_OUT_NHWC || !(p.N == 64 || p.N == 32) || (p.N % Elt<T>::VEC) != 0 || !p.part || p.part_bytes <= EG_SPLIT_CNT_BYTES) return 1;
+    const long long tiles = (long long)cdiv(p.M, 128) * nphase;
+    int nk = 1 << 30;
+    for (int i = 0; i < nphase; ++i) nk = std::min(nk, p.ph[i].Kpad / (8 * Elt<T>::VEC));
+    if (tiles >= 96 || nk < 8 || tiles > EG_SPLIT_CNT_BYTES / 4) return 1;
+    int ns = 1;
+    while (tiles * ns < 128 && ns < 16 && nk / (ns * 2) >= 2 && (forced <= 1 || ns * 2 <= forced)) ns *= 2;
+    const size_t per_split = (size_t)nphase * cdiv(p.M, 128) * 128 * p.N * 4;
+    while (ns > 1 && (size_t)ns * per_split > p.part_bytes - EG_SPLIT_CNT_BYTES) ns /= 2;
+    return ns;
 }
 
 template <typename T>
@@ -963,6 +1060,8 @@ static int launch_nt(const NtParams& p, int nphase, int variant, int splitk, hip
     }
     NtParams q = p;
     q.stat_nrb = stat_nrb;
+    q.nsplit = nt_reg_splits<T>(p, nphase, splitk);
+    q.split_cnt = q.nsplit > 1 ? reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p.part) + p.part_bytes - EG_SPLIT_CNT_BYTES) : nullptr;
     if (p.N <= 16)
         launch_nt_cfg<T, 128, 16, 4, 1>(q, nphase, st);
     else if (p.N <= 32)

@@ -491,6 +491,12 @@ __global__ __launch_bounds__(512) void igemm_nt8s_kernel(const NtParams p, const
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // the loads above are asm outputs: for the compiler they are ready at once.  Pin every use behind the wait (volatile asm
+            // statements keep their order; the uses below depend on these outputs) -- without it the scheduler may hoist an add above it.
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(ld[i][j]));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll

@@ -921,3 +921,59 @@ def test_packs_in_one_launch_give_the_same_panels(dtype):
     assert batch.dev is table                                # same pointers, same geometry: no new upload
     for a, b in zip(flat(ref), flat(got)):
         assert torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(128, 8, 64, 64, 4, 2, 1), (96, 8, 64, 32, 4, 2, 1), (40, 8, 32, 64, 4, 2, 1)])
+def test_few_row_deep_k_launch_splits_k_inside_the_register_staged_kernel(case, dtype):
+    """The small networks' last trunk layer (64 -> 64, 8x8 -> 4x4: 16-48 tiles of 128 rows, 16 K steps) with split-K scratch lent and the
+    per-call hint nt_splitk = 8 (an experiment, default off: DESIGN.md 6.0): the K loop is cut into slices reduced inside the launch by the
+    last workgroup to arrive -- against torch and against the unsplit launch
+    (no scratch), forward and backward-data (the four sub-pixel phases, with fused column statistics on 16-bit types)."""
+    B, H, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(5)
+    x = rq(torch.randn(B, Cin, H, H, generator=g), dtype)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * 0.05
+    b = torch.randn(Cout, generator=g)
+    c = ops.make_conv(B, H, H, Cin, Cout, k, s, p)
+    tdt = ops.torch_dtype(dtype)
+    wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=tdt)
+    ops.pack_fwd(c, dtype, w.to(DEV), wp)
+    want = F.leaky_relu(F.conv2d(x, rq(w, dtype), b, s, p), 0.2)
+    OH = want.shape[-1]
+    ws = torch.zeros(eg.engine.SPLITK_WS_BYTES // 4, device=DEV)
+    ys = {}
+    for name, scratch in (("plain", None), ("split", ws)):
+        ys[name] = torch.empty(B, OH, OH, Cout, device=DEV, dtype=tdt)
+        ops.conv_fwd(c, dtype, nhwc(x, dtype), wp, ys[name], ops.epilogue(bias=b.to(DEV), act=ops.ACT_LRELU, slope=0.2, splitk_ws=scratch, nt_splitk=8 if scratch is not None else 0))
+    torch.cuda.synchronize()
+    assert float(ws[-1024:].abs().sum()) == 0.0                               # the arrival counters are left at zero
+    rt, at = tol(dtype, Cin * k * k)
+    torch.testing.assert_close(nchw(ys["split"]), want, rtol=rt, atol=at)
+    torch.testing.assert_close(ys["split"].float(), ys["plain"].float(), rtol=rt, atol=at)
+    assert (ys["split"] != ys["plain"]).float().mean() < (1e-6 if dtype == 0 else 2e-2) or dtype == 0      # another summation order: rounding-level differences only
+    # backward-data of the same layer (conv view of a ConvTranspose: 4 phases x 2 x 2 taps) with BatchNorm moments from the epilogue
+    cb = ops.make_conv(B, 2 * OH, 2 * OH, Cout, Cin, 4, 2, 1)
+    dy = rq(torch.randn(B, Cin, OH, OH, generator=g), dtype)
+    wb = torch.randn(Cin, Cout, 4, 4, generator=g) * 0.05
+    wpb = torch.empty(ops.pack_bwd_elems(cb, dtype), device=DEV, dtype=tdt)
+    ops.pack_bwd(cb, dtype, wb.to(DEV), wpb)
+    want_b = F.conv_transpose2d(dy, rq(wb, dtype), None, 2, 1)
+    zs = {}
+    for name, scratch in (("plain", None), ("split", ws)):
+        zs[name] = torch.empty(B, 2 * OH, 2 * OH, Cout, device=DEV, dtype=tdt)
+        hint = 8 if scratch is not None else 0
+        ep = ops.epilogue(splitk_ws=scratch, nt_splitk=hint)
+        nrb = ops.conv_stat_blocks(cb, dtype, True, ep) if dtype != 0 else 0
+        if nrb:
+            stat = torch.full((2 * Cout * nrb,), float("nan"), device=DEV)
+            ep = ops.epilogue(splitk_ws=scratch, nt_splitk=hint, stat_mode=ops.STAT_MOMENTS, stat_out=stat)
+        ops.conv_bwd_data(cb, dtype, nhwc(dy, dtype), wpb, zs[name], ep)
+        torch.cuda.synchronize()
+        if nrb:
+            M = B * 4 * OH * OH
+            mean = stat[:Cout * nrb].reshape(Cout, nrb).mean(1)
+            torch.testing.assert_close(mean, zs[name].float().reshape(M, Cout).mean(0), rtol=1e-3, atol=1e-4)
+    rt, at = tol(dtype, Cin * 4)
+    torch.testing.assert_close(nchw(zs["split"]), want_b, rtol=rt, atol=at)
+    torch.testing.assert_close(zs["split"].float(), zs["plain"].float(), rtol=rt, atol=at)
