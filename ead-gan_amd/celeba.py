@@ -199,7 +199,7 @@ class _GenEngine:
         dt, B, W = self.dtype, self.B, G_WIDTHS
         small = (ws or self.ws).small
         ops.concat_cast(dt, noise, labels, code, self.inp, B, self.cpad)
-        ops.conv_fwd(self.l0.c, dt, self.inp, self.l0.wp_fwd, self.h0, ops.epilogue(bias=self._p(0, "bias"), bias_mod=W[0]))
+        ops.conv_fwd(self.l0.c, dt, self.inp, self.l0.wp_fwd, self.h0, ops.epilogue(bias=self._p(0, "bias"), bias_mod=W[0], nt_variant=G0_VARIANT))
         x = self.h0
         for i, idx in enumerate((1, 4, 7)):
             r = self.mid[i]
@@ -967,6 +967,9 @@ BATCH_D12 = os.environ.get("EG_BATCH_D12", "0") != "0"
 # profiles/r03_y_ab_hwq.txt).  Same bits (tests/test_gpu_celeba.py).  Single process only.
 MULTI_GRAPH = os.environ.get("EG_MULTI_GRAPH", "0") != "0"
 LAZY_PATCHES = os.environ.get("EG_LAZY_PATCHES", "1") != "0"
+# kernel hint of the generator's first layer (ONE 128-row tile x 128 column tiles, 4 K steps: 1 GFLOP): the register-staged kernel (1) runs it
+# in ~10 us where the planner's persistent pipeline (0) takes 22-24; same bits; step -0.6 % (profiles/r03_zh_ab_g0_variant.txt)
+G0_VARIANT = int(os.environ.get("EG_G0_VARIANT", "1"))
 # EXPERIMENT (default off): step 3's generator forward between the forward and the backward of step 2 (pipelined body).  Same bits, but
 # slower, 4.46 -> 4.61 ms (profiles/r03_zb_ab_g3_mid.txt): behind step 2's backward the discriminator's update and step 3's power
 # iterations then run with nothing beside them -- that chain (update -> three power iterations -> patch rows), not the generator forward,
