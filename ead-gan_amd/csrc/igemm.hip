@@ -2156,8 +2156,12 @@ extern "C" int eg_conv_wgrad_target(const eg_conv* c, int dtype, const void* X, 
 // one contiguous run of 64*T floats.  MODE 0: out += a; MODE 1: out = a (gtmp) + <a,W> partials; MODE 2: out += a - rank1.
 #define EG_RC 64
 __device__ int eg_reduce_chain_flag;                    // EG_REDUCE_RAGGED=0 (A/B runs): the one-chain loop for ragged channel counts
-template <int MODE>
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int NS, int N, int C, int T,
+// LEAN: the instantiation for launches with < 16 splits (every big layer: 2-8 slabs): no split-group scratch (4.4 KiB of LDS instead of
+// 24) and four loads in flight instead of eight (<= 48 VGPRs) -- its workgroups then fit on a CU beside a resident 8-wave GEMM workgroup
+// (147 KiB of LDS, 2 x 232 VGPRs per SIMD lane), so a reduction forked beside the main chain's GEMMs no longer waits for their tiles to
+// retire.  Same summation order as the eight-deep loop (one add per slab, in slab order): same bits.
+template <int MODE, bool LEAN = false>
+__global__ __launch_bounds__(LEAN ? 256 : 1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, int NS, int N, int C, int T,
                                                            float* __restrict__ out, int accumulate, const float* __restrict__ w_orig,
                                                            float* __restrict__ partials, int ntapes, const float* __restrict__ coef,
                                                            const float* __restrict__ u, const float* __restrict__ v, int row_div, int row_mul, int c_row) {
@@ -2173,7 +2177,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     const int crow = c_row ? c_row : C;                 // row length of the destination (<= C when the slab is column padded)
     const int nv = T * (EG_RC / 4);                     // float4 elements of a full tile
     const int NTH = blockDim.x;                          // 256, or 1024 for the many-split form (the host picks)
-    if (cw == EG_RC && c0 + EG_RC <= crow && (C & 3) == 0 && nv * 2 <= NTH && nsplit >= 16) {
+    if (!LEAN && cw == EG_RC && c0 + EG_RC <= crow && (C & 3) == 0 && nv * 2 <= NTH && nsplit >= 16) {
         // many splits of a small tile (the image-side layers as 1x1 convolutions: T = 1, 128 splits; the 32- and 64-channel layers of the
         // small networks: one 64 x 16 tile per output channel, 128 splits): the loop below is a chain of nsplit loads per thread with most
         // of the chip idle.  Here blockDim / nv thread groups each take every (blockDim / nv)-th split, eight loads in flight, and the
@@ -2215,28 +2219,31 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
             const int t = e4 / (EG_RC / 4), c = (e4 % (EG_RC / 4)) * 4;
             const size_t si = ((size_t)n * T + t) * C + c0 + c;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-            // eight slabs' loads in flight, added in slab order (the sum's order is unchanged: bit-identical to the one-by-one loop; a
-            // thread owns ONE float4 of the tile, so without this the loop is a chain of nsplit exposed HBM latencies)
+            // eight (LEAN: four) slabs' loads in flight, added in slab order (the sum's order is unchanged: bit-identical to the one-by-one
+            // loop; a thread owns ONE float4 of the tile, so without this the loop is a chain of nsplit exposed HBM latencies)
+            constexpr int DEPTH = LEAN ? 4 : 8;
             int z = 0;
-            for (; z + 8 <= nsplit; z += 8) {
-                float4 x[8];
+            for (; z + DEPTH <= nsplit; z += DEPTH) {
+                float4 x[DEPTH];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) x[q] = *reinterpret_cast<const float4*>(slab + (size_t)(z + q) * split_stride + si);
+                for (int q = 0; q < DEPTH; ++q) x[q] = *reinterpret_cast<const float4*>(slab + (size_t)(z + q) * split_stride + si);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { a.x += x[q].x; a.y += x[q].y; a.z += x[q].z; a.w += x[q].w; }
+                for (int q = 0; q < DEPTH; ++q) { a.x += x[q].x; a.y += x[q].y; a.z += x[q].z; a.w += x[q].w; }
             }
             for (; z < nsplit; ++z) {
                 const float4 x = *reinterpret_cast<const float4*>(slab + z * split_stride + si);
                 a.x += x.x; a.y += x.y; a.z += x.z; a.w += x.w;
             }
-            if (MODE == 2)
+            if (MODE == 2 && !LEAN) {
+#pragma unroll 1
                 for (int q = 0; q < ntapes; ++q) {
                     const float* vq = v + (size_t)q * crow * T + (size_t)(c0 + c) * T + t;
                     a.x -= un[q] * vq[0]; a.y -= un[q] * vq[T]; a.z -= un[q] * vq[2 * T]; a.w -= un[q] * vq[3 * T];
                 }
+            }
             tile[c * (T + 1) + t] = a.x; tile[(c + 1) * (T + 1) + t] = a.y; tile[(c + 2) * (T + 1) + t] = a.z; tile[(c + 3) * (T + 1) + t] = a.w;
         }
-    } else if (nsplit >= 16 && T * EG_RC * 2 <= NTH && !eg_reduce_chain_flag) {
+    } else if (!LEAN && nsplit >= 16 && T * EG_RC * 2 <= NTH && !eg_reduce_chain_flag) {
         // many splits of a small tile whose channel count is not a multiple of 64 (the image-side layers: 48 = 3 x 16 gathered channels,
         // 128 splits): the loop below is ONE chain of nsplit dependent loads per thread (39 us for a 6 K-parameter gradient, at the end
         // of every sub-step's backward pass).  As above: thread groups take every G-th split, eight loads in flight, added in group order.
@@ -2273,7 +2280,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
             const size_t si = ((size_t)n * T + t) * C + c0 + c;
             float a = 0.f;
             for (int z = 0; z < nsplit; ++z) a += slab[z * split_stride + si];
-            if (MODE == 2)
+            if (MODE == 2 && !LEAN)
                 for (int q = 0; q < ntapes; ++q) a -= un[q] * v[(size_t)q * crow * T + (size_t)(c0 + c) * T + t];
             tile[c * (T + 1) + t] = a;
         }
@@ -2285,7 +2292,13 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     const int cwo = min(cw, crow - c0);
     for (int e = threadIdx.x; e < cwo * T; e += NTH) {
         const int c = e / T, t = e % T;
-        const float a = tile[c * (T + 1) + t];
+        float a = tile[c * (T + 1) + t];
+        if (MODE == 2 && LEAN) {
+            // the rank-1 spectral-norm terms here, on the way out: v[q][(c0 + c) * T + t] is v_q[c0 * T + e] -- contiguous along e (the
+            // load phase gathers it with stride T); the same subtractions in the same order on the same values -> the same bits
+#pragma unroll 1
+            for (int q = 0; q < ntapes; ++q) a -= un[q] * v[(size_t)q * crow * T + (size_t)c0 * T + e];
+        }
         if (MODE == 1) {
             out[obase + e] = a;
             dot += a * w_orig[obase + e];
@@ -2330,9 +2343,17 @@ static inline int reduce_threads(int nsplit, int n_rows, int C, int T) {
     return (nsplit >= 16 && nv * 2 <= 1024 && nv * 2 > 256 && reduce_blocks(n_rows, C) <= 2048) ? 1024 : 256;
 }
 static inline size_t reduce_lds(int T) { return (size_t)EG_RC * (T + 1) * sizeof(float); }
+static inline bool reduce_lean(int nsplit) {
+    static const bool on = [] { const char* e = getenv("EG_REDUCE_LEAN"); return !(e && atoi(e) == 0); }();
+    return on && nsplit < 16;
+}
 
 extern "C" int eg_wgrad_reduce(const float* slab, int nsplit, int n_slab, int n_rows, int C, int T, float* grad, int accumulate, eg_stream_t s) {
     EG_REQUIRE(slab && grad && nsplit > 0 && n_rows <= n_slab && T > 0 && T <= 64, "eg_wgrad_reduce: bad argument");
+    if (reduce_lean(nsplit))
+        hipLaunchKernelGGL((wgrad_reduce_kernel<0, true>), dim3(reduce_blocks(n_rows, C)), dim3(256), reduce_lds(T), (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T,
+                           grad, accumulate, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0, 0);
+    else
     hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3(reduce_blocks(n_rows, C)), dim3(reduce_threads(nsplit, n_rows, C, T)), reduce_lds(T), (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T,
                        grad, accumulate, (const float*)nullptr, (float*)nullptr, 0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0, 0);
     EG_LAUNCH_CHECK();
@@ -2351,6 +2372,10 @@ extern "C" int eg_wgrad_reduce_rank1(const float* slab, int nsplit, int n_slab, 
                                      const float* coef, const float* u, const float* v, int c_row, eg_stream_t s) {
     EG_REQUIRE(slab && grad && nsplit > 0 && n_rows <= n_slab && ntapes >= 0 && ntapes <= 4 && (ntapes == 0 || (coef && u && v)) && T > 0 && T <= 64,
                "eg_wgrad_reduce_rank1: bad argument");
+    if (reduce_lean(nsplit))
+        hipLaunchKernelGGL((wgrad_reduce_kernel<2, true>), dim3(reduce_blocks(n_rows, C)), dim3(256), reduce_lds(T), (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T,
+                           grad, 1, (const float*)nullptr, (float*)nullptr, ntapes, coef, u, v, 0, 0, c_row);
+    else
     hipLaunchKernelGGL(wgrad_reduce_kernel<2>, dim3(reduce_blocks(n_rows, C)), dim3(reduce_threads(nsplit, n_rows, C, T)), reduce_lds(T), (hipStream_t)s, slab, nsplit, n_slab, n_rows, C, T,
                        grad, 1, (const float*)nullptr, (float*)nullptr, ntapes, coef, u, v, 0, 0, c_row);
     EG_LAUNCH_CHECK();
