@@ -176,7 +176,6 @@ class _GenEngine:
                     r.c, dt, p, g, m, v, lr, b1, b2, 1e-8, step, zero, r.wp_fwd, r.wp_bwd))
         return None
 
-    @ops.batched_packs
     def repack_bucket(self, tag):
         """re-pack the panels of one gradient bucket's layers (the optimizer lane updates bucket by bucket)"""
         g, dt = self.gen, self.dtype
@@ -526,7 +525,6 @@ class _DiscEngine:
                     r.c, self.dtype, p, g, m, v, lr, b1, b2, 1e-8, step, zero, r.wp_fwd, r.wp_bwd))
         return None
 
-    @ops.batched_packs
     def repack_bucket(self, tag):
         """re-pack the panels of one gradient bucket's layer (see _GenEngine.repack_bucket)"""
         if tag == "D0":

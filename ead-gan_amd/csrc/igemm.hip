@@ -1352,6 +1352,7 @@ extern "C" int eg_pack_bwd(const eg_conv* c, int dtype, const float* w, void* wp
 // panel and [c][tap'][n] rows of every backward (sub-pixel phase) panel.  The per-element gather above reads the master with a
 // 64-byte (forward) or Cin*64-byte (backward) stride and was 5-9 % of a CelebA iteration.
 // ------------------------------------------------------------------------------------------------
+#define EG_PACKM_TC 8       // Cin tile of the tile jobs inside pack_multi_kernel (the stand-alone tile kernel uses 32)
 struct PackTileParams {
     const float* w;
     void* wp_fwd;          // may be null
@@ -1364,10 +1365,10 @@ struct PackTileParams {
 };
 
 // TTC: taps (k*k) as a compile-time constant (16 for every 4x4 layer; 0 = run time): the index arithmetic below divides by it per element
-template <typename T, int TTC>
+template <typename T, int TTC, int TC = 32>
 __device__ __forceinline__ void pack_conv_tile_body(const PackTileParams& p, float* tile, int bx, int by) {
     constexpr int VEC = Elt<T>::VEC;
-    constexpr int TN = 16, TC = 32;
+    constexpr int TN = 16;
     const int TT = TTC ? TTC : p.T, TP = TT + 1;
     const int n0 = bx * TN, c0 = by * TC;
     const int tid = threadIdx.x;
@@ -1453,7 +1454,7 @@ extern "C" int eg_pack_conv(const eg_conv* c, int dtype, const float* w, void* w
     }
     const dim3 grid(c->Cout / 16, c->Cin / 32);
     const size_t lds = (size_t)16 * 32 * (T + 1) * sizeof(float);
-    if (pack_record_tile(p, dtype, grid.x, grid.y)) return 0;
+    if (pack_record_tile(p, dtype, grid.x, c->Cin / EG_PACKM_TC)) return 0;     // (the joint launch tiles Cin by EG_PACKM_TC)
 #define EG_PACK_TILE(TY) do { if (T == 16) hipLaunchKernelGGL((pack_conv_tile_kernel<TY, 16>), grid, dim3(256), lds, (hipStream_t)s, p); \
                               else hipLaunchKernelGGL((pack_conv_tile_kernel<TY, 0>), grid, dim3(256), lds, (hipStream_t)s, p); } while (0)
     if (dtype == EG_F32) EG_PACK_TILE(float);
@@ -1786,13 +1787,15 @@ __device__ __forceinline__ void pack_job_run(const PackJob& j, float* tile, int 
         case 1: pack_strided_body<T>(j.s.w, reinterpret_cast<T*>(j.s.wp), j.s.N, j.s.K, j.s.Kpad, j.s.n_div, j.s.s_hi, j.s.s_lo, j.s.s_k, bx, j.gx); break;
         case 2: pack_strided2_body<T>(j.s.w, reinterpret_cast<T*>(j.s.wp), j.s.N, j.s.K, j.s.Kpad, j.s.n_div, j.s.s_hi, j.s.s_lo, j.s.k_div, j.s.s_khi, j.s.s_klo, bx, j.gx); break;
         default:
-            if (j.t.T == 16) pack_conv_tile_body<T, 16>(j.t, tile, bx, by);
-            else pack_conv_tile_body<T, 0>(j.t, tile, bx, by);
+            if (j.t.T == 16) pack_conv_tile_body<T, 16, EG_PACKM_TC>(j.t, tile, bx, by);
+            else pack_conv_tile_body<T, 0, EG_PACKM_TC>(j.t, tile, bx, by);
     }
 }
 
+// (tile jobs 16 x 8 channels x taps: 8.5 KiB of LDS and 33 VGPRs -- the joint launch fits on a CU beside a resident 8-wave GEMM workgroup,
+//  like the per-element pack kernels it replaces did; the stand-alone tile kernel's 16 x 32 tile needs 34 KiB)
 __global__ __launch_bounds__(256) void pack_multi_kernel(const PackJob* __restrict__ jobs, int njobs) {
-    __shared__ float tile[16 * 32 * 17];
+    __shared__ float tile[16 * EG_PACKM_TC * 17];
     int ji = 0;
     while (ji + 1 < njobs && (int)blockIdx.x >= jobs[ji + 1].block0) ++ji;      // (uniform: scalar loads)
     const PackJob& j = jobs[ji];
