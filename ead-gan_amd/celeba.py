@@ -662,17 +662,22 @@ class _DiscEngine:
             x_in = sl(self.a[i - 1]) if i > 0 else sl(self.patches)
             if need_wgrad:
                 def layer_wgrad(wsw, i=i, m=m, geo=geo, x_in=x_in, fused=fused):
+                    if i == 0:
+                        for t in range(t0, t0 + T):     # patch rows of tapes whose forward ran straight from the image
+                            if not self.patch_ok[t]:
+                                self._im2col_tape(t, self.imgs[t])
+                    # the weight-gradient GEMM first: the column sums below (only the slab reduce needs their coefficient) do not fit on a CU
+                    # beside a resident GEMM workgroup and used to hold the chain's GEMM back by ~50 us
+                    if WGRAD_FIRST:
+                        ns = ops.conv_wgrad(geo, dt, x_in, sl(self.dz[i]), wsw.slab, wsw.wgs_target)
                     if fused[0]:
                         tiles_m = fused[0] // 4         # row blocks (of 256 or 128 lattice rows: the kernel's tile height) per sub-pixel phase
                         ops.bias_grad_sn_fused(fused[1], fused[0], W[i], tiles_m, tiles_m // T, T, self.sigma[i][t0:], gof(f"main.{2 * i}.bias"), self.coef[i])
                     else:
                         ops.bias_grad_sn(dt, sl(self.dz[i]), sl(self.a[i]), m.bias, T * self.rows(i), W[i], self.rows(i), self.sigma[i][t0:], LRELU_SLOPE,
                                          wsw.small, gof(f"main.{2 * i}.bias"), self.coef[i])
-                    if i == 0:
-                        for t in range(t0, t0 + T):     # patch rows of tapes whose forward ran straight from the image
-                            if not self.patch_ok[t]:
-                                self._im2col_tape(t, self.imgs[t])
-                    ns = ops.conv_wgrad(geo, dt, x_in, sl(self.dz[i]), wsw.slab, wsw.wgs_target)
+                    if not WGRAD_FIRST:
+                        ns = ops.conv_wgrad(geo, dt, x_in, sl(self.dz[i]), wsw.slab, wsw.wgs_target)
                     taps = 16 if i > 0 else 1
                     ops.wgrad_reduce_rank1(wsw.slab, ns, W[i], W[i], self.cin[i], taps, gof(f"main.{2 * i}.weight_orig"), T, self.coef[i],
                                            self.u[i][t0:], self.v[i][t0:])
@@ -965,6 +970,7 @@ BATCH_D12 = os.environ.get("EG_BATCH_D12", "0") != "0"
 # profiles/r03_y_ab_hwq.txt).  Same bits (tests/test_gpu_celeba.py).  Single process only.
 MULTI_GRAPH = os.environ.get("EG_MULTI_GRAPH", "0") != "0"
 LAZY_PATCHES = os.environ.get("EG_LAZY_PATCHES", "1") != "0"
+WGRAD_FIRST = os.environ.get("EG_WGRAD_FIRST", "1") != "0"     # D's lane chains: the weight-gradient GEMM before the bias-gradient sums
 # kernel hint of the generator's first layer (ONE 128-row tile x 128 column tiles, 4 K steps: 1 GFLOP): the register-staged kernel (1) runs it
 # in ~10 us where the planner's persistent pipeline (0) takes 22-24; same bits; step -0.6 % (profiles/r03_zh_ab_g0_variant.txt)
 G0_VARIANT = int(os.environ.get("EG_G0_VARIANT", "1"))
