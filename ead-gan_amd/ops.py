@@ -128,6 +128,27 @@ def pack_strided2(dtype, w, wp, N, K, Kpad, n_div, s_hi, s_lo, k_div, s_khi, s_k
 RECORDER = None
 
 
+_SPACER_CYCLES = None
+
+
+def _spacer(us=25.0):
+    """A spin kernel of ~25 us in front of a timed launch (torch.cuda._sleep, calibrated once): the start event, the launch and the end event
+    are enqueued while the GPU is still spinning, so the bracket holds the kernel and not the host's launch time -- eager launches behind a
+    run of short kernels find the GPU idle otherwise (bench.py's table read 77 us for a 44 us launch, profiles/r03_no_overlap_gemm_by_grid.txt).
+    It touches no memory: the cache state the timed kernel sees is the step's own."""
+    global _SPACER_CYCLES
+    if _SPACER_CYCLES is None:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(100000)
+        torch.cuda.synchronize()
+        a.record()
+        torch.cuda._sleep(1000000)
+        b.record()
+        torch.cuda.synchronize()
+        _SPACER_CYCLES = max(1000, int(us * 1e-3 * 1000000 / max(a.elapsed_time(b), 1e-3)))
+    torch.cuda._sleep(_SPACER_CYCLES)
+
+
 def _out_hw(c):
     return ((c.H << c.up) + 2 * c.pad - c.k) // c.stride + 1, ((c.W << c.up) + 2 * c.pad - c.k) // c.stride + 1
 
@@ -157,6 +178,7 @@ def _timed(kind, c, dtype, args, ep=None):
         if ep is not None and ep.mask:
             nbytes += (x_elems if kind == "bwd" else y_elems) * es
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    _spacer()
     e0.record()
     lib().call(*args, _stream())
     e1.record()
