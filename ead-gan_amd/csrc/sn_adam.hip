@@ -351,26 +351,46 @@ __global__ void adam_tick_kernel(int* step) { step[0] += 1; }
 // elements [0, head) and [head + 4*nvec, n) one per thread (the unaligned ends of an arena slice), the middle as float4; the four arrays
 // are slices of sibling arenas at the same element offset, so one `head` aligns all of them.  ZERO: the gradient is cleared in the
 // same pass (optimizer.zero_grad() of the next backward pass that accumulates into it).
-template <bool ZERO>
+template <bool ZERO, bool V2>
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n, size_t head,
                             size_t nvec, float lr, float b1, float b2, float eps, const int* __restrict__ step) {
     const AdamCoef c = adam_coef(lr, b1, b2, eps, step);
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
-    float4* p4 = reinterpret_cast<float4*>(p + head);
-    float4* g4 = reinterpret_cast<float4*>(g + head);
-    float4* m4 = reinterpret_cast<float4*>(m + head);
-    float4* v4 = reinterpret_cast<float4*>(v + head);
-    for (size_t i = tid; i < nvec; i += nth) {
-        float4 pi = p4[i], mi = m4[i], vi = v4[i];
-        const float4 gi = g4[i];
+    // 8-byte vectors (two per 16-byte slot `nvec` counts): with 16-byte ones the kernel needs 50-54 VGPRs, with these 48 -- what a wave
+    // may use on a SIMD beside the two 232-register waves of a resident 8-wave GEMM workgroup: the updates on the optimizer
+    // lane run beside the next sub-step's GEMMs.  Same element arithmetic.
+    if constexpr (!V2) {                                 // (the 16-byte form: A/B runs, EG_ADAM_V2=0)
+        float4* p4 = reinterpret_cast<float4*>(p + head);
+        float4* g4 = reinterpret_cast<float4*>(g + head);
+        float4* m4 = reinterpret_cast<float4*>(m + head);
+        float4* v4 = reinterpret_cast<float4*>(v + head);
+        for (size_t i = tid; i < nvec; i += nth) {
+            float4 pi = p4[i], mi = m4[i], vi = v4[i];
+            const float4 gi = g4[i];
+            adam_elem(pi.x, gi.x, mi.x, vi.x, c);
+            adam_elem(pi.y, gi.y, mi.y, vi.y, c);
+            adam_elem(pi.z, gi.z, mi.z, vi.z, c);
+            adam_elem(pi.w, gi.w, mi.w, vi.w, c);
+            m4[i] = mi;
+            v4[i] = vi;
+            p4[i] = pi;
+            if (ZERO) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else {
+    float2* p2 = reinterpret_cast<float2*>(p + head);
+    float2* g2 = reinterpret_cast<float2*>(g + head);
+    float2* m2 = reinterpret_cast<float2*>(m + head);
+    float2* v2 = reinterpret_cast<float2*>(v + head);
+    for (size_t i = tid; i < 2 * nvec; i += nth) {
+        float2 pi = p2[i], mi = m2[i], vi = v2[i];
+        const float2 gi = g2[i];
         adam_elem(pi.x, gi.x, mi.x, vi.x, c);
         adam_elem(pi.y, gi.y, mi.y, vi.y, c);
-        adam_elem(pi.z, gi.z, mi.z, vi.z, c);
-        adam_elem(pi.w, gi.w, mi.w, vi.w, c);
-        m4[i] = mi;
-        v4[i] = vi;
-        p4[i] = pi;
-        if (ZERO) g4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        m2[i] = mi;
+        v2[i] = vi;
+        p2[i] = pi;
+        if (ZERO) g2[i] = make_float2(0.f, 0.f);
+    }
     }
     const size_t tail0 = head + 4 * nvec, nends = head + (n - tail0);
     for (size_t e = tid; e < nends; e += nth) {
@@ -394,8 +414,14 @@ static void launch_adam(float* p, float* g, float* m, float* v, size_t n, float 
     if (!same) head = 0;
     const size_t work = same ? (nvec > 8 ? nvec : 8) : n;          // differently aligned slices: every element through the scalar loop
     const int blocks = (int)((work + 255) / 256 > 2048 ? 2048 : (work + 255) / 256);
-    if (zero) hipLaunchKernelGGL(adam_kernel<true>, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, head, nvec, lr, b1, b2, eps, step);
-    else hipLaunchKernelGGL(adam_kernel<false>, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, head, nvec, lr, b1, b2, eps, step);
+    static const bool v2 = [] { const char* e = getenv("EG_ADAM_V2"); return !(e && atoi(e) == 0); }();
+    if (v2) {
+        if (zero) hipLaunchKernelGGL((adam_kernel<true, true>), dim3(blocks), dim3(256), 0, st, p, g, m, v, n, head, nvec, lr, b1, b2, eps, step);
+        else hipLaunchKernelGGL((adam_kernel<false, true>), dim3(blocks), dim3(256), 0, st, p, g, m, v, n, head, nvec, lr, b1, b2, eps, step);
+    } else {
+        if (zero) hipLaunchKernelGGL((adam_kernel<true, false>), dim3(blocks), dim3(256), 0, st, p, g, m, v, n, head, nvec, lr, b1, b2, eps, step);
+        else hipLaunchKernelGGL((adam_kernel<false, false>), dim3(blocks), dim3(256), 0, st, p, g, m, v, n, head, nvec, lr, b1, b2, eps, step);
+    }
 }
 
 /* In-place Adam over a flat fp32 arena.  `step` is a device int32 incremented by this call (so a captured
