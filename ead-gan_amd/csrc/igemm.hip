@@ -1405,10 +1405,10 @@ __device__ __forceinline__ void pack_conv_tile_body(const PackTileParams& p, flo
         }
     }
 }
-template <typename T, int TTC>
+template <typename T, int TTC, int TC = 32>
 __global__ __launch_bounds__(256) void pack_conv_tile_kernel(const PackTileParams p) {
     extern __shared__ float tile[];                 // [TN][TC][T + 1]
-    pack_conv_tile_body<T, TTC>(p, tile, blockIdx.x, blockIdx.y);
+    pack_conv_tile_body<T, TTC, TC>(p, tile, blockIdx.x, blockIdx.y);
 }
 
 // tile-kernel parameters of a layer, or false where only the per-element gather kernels can pack it (ragged channel counts, K padding)
@@ -1452,11 +1452,16 @@ extern "C" int eg_pack_conv(const eg_conv* c, int dtype, const float* w, void* w
         if (wp_bwd) if (int e = eg_pack_bwd(c, dtype, w, wp_bwd, s)) return e;
         return 0;
     }
-    const dim3 grid(c->Cout / 16, c->Cin / 32);
-    const size_t lds = (size_t)16 * 32 * (T + 1) * sizeof(float);
+    // Cin tile: 32 (64-byte panel stores, 34 KiB of LDS) or 8 (16-byte stores, 8.5 KiB: fits on a CU beside a resident 8-wave GEMM workgroup:
+    // the re-packing on the optimizer lane then runs beside the next sub-step's GEMMs; EG_PACK_TC, A/B in profiles/r03_zm_ab_pack_tc.txt)
+    static const int tc = [] { const char* e = getenv("EG_PACK_TC"); return (e && atoi(e) == 32) ? 32 : 8; }();
+    const dim3 grid(c->Cout / 16, c->Cin / tc);
+    const size_t lds = (size_t)16 * tc * (T + 1) * sizeof(float);
     if (pack_record_tile(p, dtype, grid.x, c->Cin / EG_PACKM_TC)) return 0;     // (the joint launch tiles Cin by EG_PACKM_TC)
-#define EG_PACK_TILE(TY) do { if (T == 16) hipLaunchKernelGGL((pack_conv_tile_kernel<TY, 16>), grid, dim3(256), lds, (hipStream_t)s, p); \
-                              else hipLaunchKernelGGL((pack_conv_tile_kernel<TY, 0>), grid, dim3(256), lds, (hipStream_t)s, p); } while (0)
+#define EG_PACK_TILE(TY) do { if (tc == 32) { if (T == 16) hipLaunchKernelGGL((pack_conv_tile_kernel<TY, 16>), grid, dim3(256), lds, (hipStream_t)s, p); \
+                                              else hipLaunchKernelGGL((pack_conv_tile_kernel<TY, 0>), grid, dim3(256), lds, (hipStream_t)s, p); } \
+                              else { if (T == 16) hipLaunchKernelGGL((pack_conv_tile_kernel<TY, 16, 8>), grid, dim3(256), lds, (hipStream_t)s, p); \
+                                     else hipLaunchKernelGGL((pack_conv_tile_kernel<TY, 0, 8>), grid, dim3(256), lds, (hipStream_t)s, p); } } while (0)
     if (dtype == EG_F32) EG_PACK_TILE(float);
     else if (dtype == EG_F16) EG_PACK_TILE(f16_t);
     else EG_PACK_TILE(bf16_t);
