@@ -149,7 +149,10 @@ class DeviceInputs(ds.DeviceInputs):
     :372), then the dSprites draws (:405-446)."""
 
     def enqueue(self, tr: "ColoredTrainer"):
+        self.begin_draws()                              # sprite indices, colour gains, codes and labels (+ one-hot rows): one launch
+        idx = self.sample_indices(tr.B, 1)
         self.draw(ops.RNG_UNIFORM, tr.gains, 0.5, 1.0, 2)
-        ops.u8_colorize(self.sprites(tr), tr.gains, tr.img, tr.B, 3, 64 * 64)
         self.codes_and_labels(tr, 3)
+        self.end_draws()
+        ops.u8_colorize(self.sprites(tr, idx), tr.gains, tr.img, tr.B, 3, 64 * 64)
         self.tick()

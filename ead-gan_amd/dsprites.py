@@ -862,10 +862,10 @@ class DeviceInputs(DeviceSampler):
     numpy draws in the reference's order: code ~ U(-1,1), labels ~ randint, then again for the joint step).  ``dataset_u8``: uint8
     [N,64,64] sprites with values {0,1}."""
 
-    def sprites(self, tr):
+    def sprites(self, tr, idx=None):
         B = tr.B
         batch = self.buf("sprites", (B,) + tuple(self.data.shape[1:]), torch.uint8)
-        torch.index_select(self.data, 0, self.sample_indices(B, 1), out=batch)
+        torch.index_select(self.data, 0, self.sample_indices(B, 1) if idx is None else idx, out=batch)
         return batch
 
     def codes_and_labels(self, tr, first_stream):
@@ -875,6 +875,9 @@ class DeviceInputs(DeviceSampler):
         self.labels_onehot("labels2", tr.onehot2, tr.nc, first_stream + 3)
 
     def enqueue(self, tr: "DspritesTrainer"):
-        ops.u8_to_f32(self.sprites(tr), tr.img)
+        self.begin_draws()                              # sprite indices, codes and labels (+ one-hot rows): one launch
+        idx = self.sample_indices(tr.B, 1)
         self.codes_and_labels(tr, 2)
+        self.end_draws()
+        ops.u8_to_f32(self.sprites(tr, idx), tr.img)
         self.tick()

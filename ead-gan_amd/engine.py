@@ -388,6 +388,9 @@ def bn_train_backward(dt, z, da, dz, M, C, bn, mean, invstd, act, slope, dgamma,
     ops.bn_bwd_from_sums(dt, z, da, dz, M, C, sums, M * sync.world, bn.weight, bn.bias, mean, invstd, act, slope, ws.small)
 
 
+FUSE_DRAWS = os.environ.get("EG_FUSE_INPUTS", "1") != "0"      # (the switch of celeba.FUSE_INPUTS)
+
+
 class DeviceSampler:
     """Shared part of the trainers' device-side input pipelines: a uint8 dataset resident in HBM, a device step counter and
     counter-based draws (ops.rng_fill: reproducible per (seed, step, stream), the reference's distributions, NOT numpy's stream --
@@ -412,7 +415,23 @@ class DeviceSampler:
             t = self._buf[name] = torch.empty(shape, device=self.data.device, dtype=dtype)
         return t
 
+    # Draws of one iteration as ONE launch (eg_rng_fill_multi: the values of one eg_rng_fill per draw -- a value depends on (element, step,
+    # stream id, seed) only, not on the launch it comes from): between begin_draws() and end_draws() the draw methods below only collect.
+    _draws = None
+
+    def begin_draws(self):
+        if FUSE_DRAWS:
+            self._draws = []
+
+    def end_draws(self):
+        draws, self._draws = self._draws, None
+        if draws:
+            ops.rng_fill_multi(draws, self.seed, self.step)
+
     def draw(self, kind, out, a, b, stream_id):
+        if self._draws is not None:
+            self._draws.append((kind, out, a, b, stream_id))
+            return
         ops.rng_fill(kind, out, a, b, self.seed, self.step, stream_id)
 
     def sample_indices(self, B, stream_id=1):
@@ -423,8 +442,12 @@ class DeviceSampler:
             self.draw(ops.RNG_RANDINT, idx, 0, self.data.shape[0], stream_id)
         return idx
 
-    def labels_onehot(self, name, onehot, n_classes, stream_id):
-        lab = self.buf(name, (onehot.shape[0],), torch.int64)
+    def labels_onehot(self, name, onehot, n_classes, stream_id, lab=None):
+        if lab is None:
+            lab = self.buf(name, (onehot.shape[0],), torch.int64)
+        if self._draws is not None:
+            self._draws.append((ops.RNG_RANDINT, lab, 0, n_classes, stream_id, onehot))      # the one-hot rows written by the same launch
+            return lab
         self.draw(ops.RNG_RANDINT, lab, 0, n_classes, stream_id)
         ops.onehot(lab, onehot, onehot.shape[0], n_classes)
         return lab

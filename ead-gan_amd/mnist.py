@@ -15,7 +15,7 @@ from torch.nn.utils import spectral_norm
 
 from . import ops
 from .celeba import _HipModule, _require_cuda, transformation_2D      # noqa: F401  (same STN warp in both scripts)
-from .engine import (Arena, ConvRec, DeviceSampler, ResidentStep, SideStream, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step, check_usable,
+from .engine import (FUSE_DRAWS, Arena, ConvRec, DeviceSampler, ResidentStep, SideStream, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step, check_usable,
                      parse_dtype)
 from .ops import ACT_LRELU, ACT_NONE, ACT_TANH, EG_F32, OUT_NCHW_F32
 from .trunk import Head, TrunkEngine
@@ -574,12 +574,16 @@ class DeviceInputs(DeviceSampler):
     def enqueue(self, tr: "MnistTrainer"):
         B = tr.B
         N, C, H, W = self.data.shape
-        ops.gather_u8_images(self.data, self.sample_indices(B, 1), None, tr.real, B, C, H, W, 2.0 / 255.0, -1.0)   # ToTensor + Normalize(.5,.5)
-        self.draw(ops.RNG_RANDINT, tr.labels, 0, tr.onehot.shape[1], 2)
-        ops.onehot(tr.labels, tr.onehot, B, tr.onehot.shape[1])
+        self.begin_draws()                              # image indices, labels (+ one-hot rows), z, code: one launch
+        idx = self.sample_indices(B, 1)
+        self.labels_onehot("labels", tr.onehot, tr.onehot.shape[1], 2, lab=tr.labels)
         self.draw(ops.RNG_NORMAL, tr.z, 0.0, 1.0, 3)
         self.draw(ops.RNG_UNIFORM, tr.code, -1.0, 1.0, 4)
-        self.tick()
+        self.end_draws()
+        # ToTensor + Normalize(.5,.5); the step counter ticks in the same launch (every draw of the iteration has read it)
+        ops.gather_u8_images(self.data, idx, None, tr.real, B, C, H, W, 2.0 / 255.0, -1.0, tick=self.step if FUSE_DRAWS else None)
+        if not FUSE_DRAWS:
+            self.tick()
 
 
 # ================================================================================================

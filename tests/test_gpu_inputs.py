@@ -212,6 +212,22 @@ def test_small_network_trainers_feed_themselves(family):
         assert torch.allclose(on, gains, atol=1e-6)
 
 
+@pytest.mark.parametrize("family", ["mnist", "dsprites", "colored"])
+def test_small_network_draws_in_one_launch_are_the_same_draws(family, monkeypatch):
+    """the iteration's draws as ONE launch (DeviceSampler.begin_draws / end_draws -> eg_rng_fill_multi, one-hot rows fused, MNIST's counter
+    tick inside the gather) against one launch per draw: the same losses, codes and images, step for step"""
+    runs = []
+    for fuse in (False, True):
+        monkeypatch.setattr(eg.engine, "FUSE_DRAWS", fuse)
+        monkeypatch.setattr(eg.mnist, "FUSE_DRAWS", fuse)
+        runs.append(_run_small(family, False))
+    (l0, d0, i0, _), (l1, d1, i1, _) = runs
+    assert int(i0.step.item()) == 4 and int(i1.step.item()) == 4
+    assert torch.equal(l0, l1)
+    for (c0, x0), (c1, x1) in zip(d0, d1):
+        assert torch.equal(c0, c1) and torch.equal(x0, x1)
+
+
 @pytest.mark.parametrize("hw", [(218, 178), (178, 218), (100, 64), (70, 200), (64, 64)])
 def test_resize_center_crop_matches_pil(hw):
     """f1 remainder: transforms.Resize(64) + CenterCrop(64) (celebA/EAD-GAN_celebA.py:194-196) on the device, bit for bit against PIL
