@@ -939,7 +939,12 @@ class DeviceInputs:
                                 (ops.RNG_BERNOULLI, self.flips, 0.5, 0.0, 2),               # RandomHorizontalFlip(p=0.5)
                                 (ops.RNG_NORMAL, tr.z, 0.0, 1.0, 3), (ops.RNG_UNIFORM, tr.code, -1.0, 1.0, 4),
                                 (ops.RNG_RANDINT, tr.labels, 0, tr.G.n_classes, 5, tr.onehot)], self.seed, self.step)
-            ops.gather_u8_images(self.data, self.idx, self.flips if self.flip else None, tr.real, B, C, H, W, 2.0 / 255.0, -1.0, tick=self.step)   # ToTensor + Normalize(.5,.5)
+            def gather():                               # ToTensor + Normalize(.5,.5)
+                ops.gather_u8_images(self.data, self.idx, self.flips if self.flip else None, tr.real, B, C, H, W, 2.0 / 255.0, -1.0, tick=self.step)
+            if INPUTS_ON_PREP and tr.side is not None:
+                tr._inputs_tail = gather                # the pipelined body runs it on its preparation lane, in front of the warp
+            else:
+                gather()
             return
         if self.sampling == "permutation":
             ops.rng_fill(ops.RNG_EPOCH_PERM, self.idx, N, 0, self.seed, self.step, 1)
@@ -969,6 +974,9 @@ BATCH_D12 = os.environ.get("EG_BATCH_D12", "0") != "0"
 # WITH branches on a second stream holds back later launches on the first, a one-chain graph does not; more HSA queues make it far worse,
 # profiles/r03_y_ab_hwq.txt).  Same bits (tests/test_gpu_celeba.py).  Single process only.
 MULTI_GRAPH = os.environ.get("EG_MULTI_GRAPH", "0") != "0"
+# the image gather and the affine warp at the head of the iteration on the preparation lane, beside the generator forward (which needs the
+# draws only), instead of in front of it on the main chain; same bits; EG_INPUTS_ON_PREP=0: on the main chain
+INPUTS_ON_PREP = os.environ.get("EG_INPUTS_ON_PREP", "1") != "0"
 LAZY_PATCHES = os.environ.get("EG_LAZY_PATCHES", "1") != "0"
 WGRAD_FIRST = os.environ.get("EG_WGRAD_FIRST", "1") != "0"     # D's lane chains: the weight-gradient GEMM before the bias-gradient sums
 # kernel hint of the generator's first layer (ONE 128-row tile x 128 column tiles, 4 K steps: 1 GFLOP): the register-staged kernel (1) runs it
@@ -1309,10 +1317,22 @@ class CelebATrainer:
                         evs[key] = side.mark()          # panels are new, gradients zeroed
                 side.defer_opt_after((tag,), fn)
 
-        self._inputs_head()
+        # the generator forward needs the draws only: the image gather (DeviceInputs) and the warp go to the preparation lane, in front of
+        # step 1's power iteration -- everything that reads them (step 2, step 3, the losses the warp launch zeroes) is behind the wait
+        # for that lane's event below
+        tail, self._inputs_tail = getattr(self, "_inputs_tail", None), None
+        on_prep = INPUTS_ON_PREP
+        if not on_prep:
+            if tail is not None:
+                tail()
+            self._inputs_head()
         # ---- 1) generator adversarial step (:334-345); D(gen) lives in tape slot 2 so that step 2's tapes can be prepared meanwhile ----
 
         def sn1(_ws):                                   # the power iterations only need D's weights: beside the generator forward
+            if on_prep:
+                if tail is not None:
+                    tail()
+                self._inputs_head()
             if BATCH_D12:
                 self._sn_d12()
                 de._im2col_tape(0, self.scaled)
