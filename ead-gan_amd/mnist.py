@@ -7,6 +7,7 @@ containers only (reference ``state_dict`` keys: ``l1.0.*``, ``conv_blocks.N.*``,
 from __future__ import annotations
 
 import argparse
+import os
 
 import numpy as np
 import torch
@@ -24,6 +25,10 @@ opt = argparse.Namespace(n_epochs=200, batch_size=128, lr=0.0001, b1=0.5, b2=0.9
                          img_size=32, channels=1, sample_interval=4000)          # argparse defaults, :35-48
 TRUNK = (16, 32, 64, 128)
 SLOPE = 0.2
+# the generator's two Upsample(2) + Conv2d(3, 1, 1) blocks (:81-82, 85-86) as transposed 4x4 / stride-2 convolutions with summed taps: 4 taps per
+# output pixel instead of 9 in the forward, the input gradient (no upsampled gradient + sum-pool) and the weight gradient (ops.up3_expand /
+# up3_contract; the same sums up to fp32 rounding of the tap sums).  EG_UP3_CONVT=0: the 3x3 convolution over the upsampled lattice
+UP3_AS_CONVT = os.environ.get("EG_UP3_CONVT", "1") != "0"
 
 
 def weights_init_normal(m):
@@ -55,8 +60,17 @@ class _GenEngine:
         self.cpad = ops.round_up(self.cin, 8)
         self.nl1 = 128 * s * s
         self.l1 = ConvRec(dtype, B, 1, 1, self.cpad, self.nl1, 1, 1, 0, device=dev, want_bwd=False, ws=ws)
-        self.c1 = ConvRec(dtype, B, s, s, 128, 128, 3, 1, 1, up=1, device=dev, ws=ws)
-        self.c2 = ConvRec(dtype, B, 2 * s, 2 * s, 128, 64, 3, 1, 1, up=1, device=dev, ws=ws)
+        self.up3 = UP3_AS_CONVT
+        if self.up3:
+            # Upsample(2) + Conv2d(3, 1, 1) as the transposed 4x4 / stride-2 convolution with summed taps (ops.up3_expand): conv view of
+            # ConvTranspose2d(Cin -> Cout, 4, 2, 1) = Conv2d(Cout -> Cin, 4, 2, 1) on the OUTPUT side, as in the dSprites / CelebA generators
+            self.c1 = ConvRec(dtype, B, 2 * s, 2 * s, 128, 128, 4, 2, 1, device=dev, ws=ws)
+            self.c2 = ConvRec(dtype, B, 4 * s, 4 * s, 64, 128, 4, 2, 1, device=dev, ws=ws)
+            self.w4 = [torch.empty(128, 128, 4, 4, device=dev), torch.empty(128, 64, 4, 4, device=dev)]      # effective masters [in][out][4][4]
+            self.dw4 = [torch.empty_like(w) for w in self.w4]
+        else:
+            self.c1 = ConvRec(dtype, B, s, s, 128, 128, 3, 1, 1, up=1, device=dev, ws=ws)
+            self.c2 = ConvRec(dtype, B, 2 * s, 2 * s, 128, 64, 3, 1, 1, up=1, device=dev, ws=ws)
         self.CH = gen.channels
         # last conv (64 -> channels): forward with the real N; input/weight gradients with the output side padded to 8 channels
         self.c3f = ConvRec(dtype, B, 4 * s, 4 * s, 64, self.CH, 3, 1, 1, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
@@ -78,7 +92,7 @@ class _GenEngine:
         self.dimg_z = torch.empty_like(self.img)
         self.p8 = e(B * (4 * s) ** 2, 8)
         self.da2, self.dz2 = torch.empty_like(self.a2), torch.empty_like(self.a2)
-        self.dup = e(B, 4 * s, 4 * s, 128)                            # gradient at an upsampled resolution (largest: 32x32x128)
+        self.dup = None if self.up3 else e(B, 4 * s, 4 * s, 128)      # gradient at an upsampled resolution (largest: 32x32x128)
         self.da1, self.dz1 = torch.empty_like(self.a1), torch.empty_like(self.a1)
         self.da0, self.dh = torch.empty_like(self.a0), torch.empty_like(self.h)
         for M, C in ((B * s * s, 128), (B * 4 * s * s, 128), (B * 16 * s * s, 64)):
@@ -96,7 +110,18 @@ class _GenEngine:
 
     def repack(self):
         self._repack_masters()
-        self.c3.pack(self.w3pad)                        # (reads the padded copy the batch above has just written: its own launch)
+        if self.up3:                                    # (plain launches: a batched method's body does not run inside a capture)
+            ops.up3_expand(self.gen.conv_blocks[2].weight, self.w4[0], 128, 128)
+            ops.up3_expand(self.gen.conv_blocks[6].weight, self.w4[1], 64, 128)
+        self._repack_derived()
+
+    @ops.batched_packs
+    def _repack_derived(self):
+        """panels packed from copies that ``_repack_masters`` has just written (their own launch behind it)"""
+        self.c3.pack(self.w3pad)
+        if self.up3:
+            self.c1.pack(self.w4[0])
+            self.c2.pack(self.w4[1])
 
     @ops.batched_packs
     def _repack_masters(self):
@@ -106,8 +131,9 @@ class _GenEngine:
         # NHWC row n' = hw*128 + c  <-  master row f = c*hw_count + hw  (the reference views the Linear output as [B,128,8,8])
         ops.pack_strided(dt, w, self.l1.wp_fwd, self.nl1, self.cin, self.l1.Kpad_fwd, 128, self.cin, hw * self.cin, 1)
         ops.pack_strided(EG_F32, b, self.bias_perm, self.nl1, 1, 1, 128, 1, hw, 0)
-        self.c1.pack(g.conv_blocks[2].weight)
-        self.c2.pack(g.conv_blocks[6].weight)
+        if not self.up3:
+            self.c1.pack(g.conv_blocks[2].weight)
+            self.c2.pack(g.conv_blocks[6].weight)
         self.c3f.pack(g.conv_blocks[9].weight)
         ops.pack_strided(EG_F32, g.conv_blocks[9].weight, self.w3pad, self.CH, 576, 576, 1, 576, 0, 1)
 
@@ -126,9 +152,11 @@ class _GenEngine:
             bn_train_forward(dt, x, y, M, C, mod, self.mean[i], self.invstd[i], ws.small, act, slope, sync, self.sync_scratch.stats[i])
         s = g.init_size
         bn(self.h, self.a0, cb[0], 0, B * s * s, 128, ACT_NONE)
-        ops.conv_fwd(self.c1.c, dt, self.a0, self.c1.wp_fwd, self.z1, ops.epilogue(bias=cb[2].bias))
+        up_conv = ops.conv_bwd_data if self.up3 else ops.conv_fwd      # (transposed convolution = backward-data of its conv view)
+        up_w = (lambda r: r.wp_bwd) if self.up3 else (lambda r: r.wp_fwd)
+        up_conv(self.c1.c, dt, self.a0, up_w(self.c1), self.z1, ops.epilogue(bias=cb[2].bias))
         bn(self.z1, self.a1, cb[3], 1, B * 4 * s * s, 128, ACT_LRELU, SLOPE)
-        ops.conv_fwd(self.c2.c, dt, self.a1, self.c2.wp_fwd, self.z2, ops.epilogue(bias=cb[6].bias))
+        up_conv(self.c2.c, dt, self.a1, up_w(self.c2), self.z2, ops.epilogue(bias=cb[6].bias))
         bn(self.z2, self.a2, cb[7], 2, B * 16 * s * s, 64, ACT_LRELU, SLOPE)
         ops.conv_fwd(self.c3f.c, dt, self.a2, self.c3f.wp_fwd, self.img, ops.epilogue(bias=cb[9].bias, act=ACT_TANH, out_mode=OUT_NCHW_F32))
         return self.img
@@ -167,24 +195,42 @@ class _GenEngine:
         bn_bwd(self.z2, self.da2, self.dz2, cb[7], 2, B * S * S, 64, ACT_LRELU, "conv_blocks.7")
 
         def c2_wgrad(wsw):
-            ns = ops.conv_wgrad(self.c2.c, dt, self.a1, self.dz2, wsw.slab, wsw.wgs_target)
-            ops.wgrad_reduce(wsw.slab, ns, 64, 64, 128, 9, gof("conv_blocks.6.weight"))
+            if self.up3:
+                ns = ops.conv_wgrad(self.c2.c, dt, self.dz2, self.a1, wsw.slab, 0)     # (one split count on a lane and on the main stream: same bits)
+                ops.wgrad_reduce(wsw.slab, ns, 128, 128, 64, 16, self.dw4[1], accumulate=False)
+                ops.up3_contract(self.dw4[1], gof("conv_blocks.6.weight"), 64, 128)
+            else:
+                ns = ops.conv_wgrad(self.c2.c, dt, self.a1, self.dz2, wsw.slab, wsw.wgs_target)
+                ops.wgrad_reduce(wsw.slab, ns, 64, 64, 128, 9, gof("conv_blocks.6.weight"))
             ops.bias_grad(dt, self.dz2, B * S * S, 64, wsw.small, gof("conv_blocks.6.bias"))
         wgrad_side(c2_wgrad, 1)
-        ops.conv_bwd_data(self.c2.c, dt, self.dz2, self.c2.wp_bwd, self.dup, None)
-        flush()
-        ops.sumpool2x2(dt, self.dup, self.da1, B, 2 * s, 2 * s, 128)
+        if self.up3:
+            ops.conv_fwd(self.c2.c, dt, self.dz2, self.c2.wp_fwd, self.da1, None)      # the input gradient at the low resolution: no sum-pool
+            flush()
+        else:
+            ops.conv_bwd_data(self.c2.c, dt, self.dz2, self.c2.wp_bwd, self.dup, None)
+            flush()
+            ops.sumpool2x2(dt, self.dup, self.da1, B, 2 * s, 2 * s, 128)
         # conv1 (128 -> 128 on the 2x-upsampled a0)
         bn_bwd(self.z1, self.da1, self.dz1, cb[3], 1, B * 4 * s * s, 128, ACT_LRELU, "conv_blocks.3")
 
         def c1_wgrad(wsw):
-            ns = ops.conv_wgrad(self.c1.c, dt, self.a0, self.dz1, wsw.slab, wsw.wgs_target)
-            ops.wgrad_reduce(wsw.slab, ns, 128, 128, 128, 9, gof("conv_blocks.2.weight"))
+            if self.up3:
+                ns = ops.conv_wgrad(self.c1.c, dt, self.dz1, self.a0, wsw.slab, 0)
+                ops.wgrad_reduce(wsw.slab, ns, 128, 128, 128, 16, self.dw4[0], accumulate=False)
+                ops.up3_contract(self.dw4[0], gof("conv_blocks.2.weight"), 128, 128)
+            else:
+                ns = ops.conv_wgrad(self.c1.c, dt, self.a0, self.dz1, wsw.slab, wsw.wgs_target)
+                ops.wgrad_reduce(wsw.slab, ns, 128, 128, 128, 9, gof("conv_blocks.2.weight"))
             ops.bias_grad(dt, self.dz1, B * 4 * s * s, 128, wsw.small, gof("conv_blocks.2.bias"))
         wgrad_side(c1_wgrad, 2)
-        ops.conv_bwd_data(self.c1.c, dt, self.dz1, self.c1.wp_bwd, self.dup, None)     # [B,16,16,128] in the front of dup
-        flush()
-        ops.sumpool2x2(dt, self.dup, self.da0, B, s, s, 128)
+        if self.up3:
+            ops.conv_fwd(self.c1.c, dt, self.dz1, self.c1.wp_fwd, self.da0, None)
+            flush()
+        else:
+            ops.conv_bwd_data(self.c1.c, dt, self.dz1, self.c1.wp_bwd, self.dup, None)     # [B,16,16,128] in the front of dup
+            flush()
+            ops.sumpool2x2(dt, self.dup, self.da0, B, s, s, 128)
         bn_bwd(self.h, self.da0, self.dh, cb[0], 0, B * s * s, 128, ACT_NONE, "conv_blocks.0")
         # l1: dW[f][k] = sum_b dh[b][n'(f)] * x[b][k]
         hw = s * s

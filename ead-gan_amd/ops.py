@@ -239,6 +239,16 @@ def sumpool2x2(dtype, x, y, B, H, W, C):
     lib().call("eg_sumpool2x2", dtype, _p(x), _p(y), B, H, W, C, _stream())
 
 
+def up3_expand(w3, w4t, Cout, Cin):
+    """effective ConvTranspose2d(4, 2, 1) master [Cin][Cout][4][4] of Upsample(2) + Conv2d(Cin -> Cout, 3, 1, 1) (MNIST/EAD-GAN_rpqmnxy.py:81-82)"""
+    lib().call("eg_up3_expand", _p(w3), _p(w4t), Cout, Cin, _stream())
+
+
+def up3_contract(dw4t, dw3, Cout, Cin, accumulate=True):
+    """the transposed convolution's weight gradient [Cin][Cout][4][4] back onto the 3x3 master's gradient [Cout][Cin][3][3]"""
+    lib().call("eg_up3_contract", _p(dw4t), _p(dw3), Cout, Cin, int(accumulate), _stream())
+
+
 def sn_partials():
     return lib().query("eg_sn_partials")
 

@@ -157,6 +157,12 @@ int eg_wgrad_reduce_perm(const float* slab, int nsplit, int n_slab, int n_rows, 
 int eg_gather_add(float* out, const float* src, int n, int div, int s_div, int s_mod, eg_stream_t s);
 /* y[B,H,W,C] = 2x2 sum-pool of x[B,2H,2W,C]  (backward of nn.Upsample(scale_factor=2), MNIST/EAD-GAN_rpqmnxy.py:81,85) */
 int eg_sumpool2x2(int dtype, const void* x, void* y, int B, int H, int W, int C, eg_stream_t s);
+/* nn.Upsample(scale_factor=2) + Conv2d(Cin -> Cout, 3, 1, 1) run as ConvTranspose2d(Cin -> Cout, 4, 2, 1) with summed taps
+ * (MNIST/EAD-GAN_rpqmnxy.py:81-82, 85-86): eg_up3_expand writes the effective master w4t[Cin][Cout][4][4] (W4[kh] = sum of the 3x3 taps
+ * t in [max(0, 2-kh), min(2, 3-kh)], rows and columns alike) from w3[Cout][Cin][3][3]; eg_up3_contract takes the weight gradient of the
+ * transposed convolution back through the transpose of that map: dw3 (+)= E^T dw4t E.  fp32 masters / gradients only. */
+int eg_up3_expand(const float* w3, float* w4t, int Cout, int Cin, eg_stream_t s);
+int eg_up3_contract(const float* dw4t, float* dw3, int Cout, int Cin, int accumulate, eg_stream_t s);
 /* spectral-norm variant (torch.nn.utils.spectral_norm backward, celebA/EAD-GAN_celebA.py:110-120):
  * G = sum slab ;  grad += G/sigma - (<G,W_orig>/sigma^2) u v^T.  gtmp: Cout*Cin*k*k floats,
  * partials: >= eg_sn_partials() floats. */

@@ -140,6 +140,49 @@ def test_conv_wgrad(case, dtype):
     torch.testing.assert_close(grad2.cpu(), want, rtol=rt * 2, atol=at * 8)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(3, 8, 16, 24), (2, 16, 128, 64), (4, 4, 128, 128), (2, 2, 8, 8)])
+def test_upsample_conv3_as_transposed_conv4(case, dtype):
+    """nn.Upsample(scale_factor=2) + Conv2d(Cin -> Cout, 3, 1, 1) (MNIST/EAD-GAN_rpqmnxy.py:81-82, 85-86) through eg_up3_expand + the
+    transposed 4x4 / stride-2 / pad-1 convolution: forward, input gradient (low resolution, no sum-pool) and weight gradient
+    (eg_up3_contract) against torch's upsample + conv2d and its autograd"""
+    B, H, Cin, Cout = case
+    g = torch.Generator().manual_seed(11)
+    x = rq(torch.randn(B, Cin, H, H, generator=g), dtype).requires_grad_(True)
+    w3 = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(Cout, generator=g)
+    y = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w3, b, 1, 1)
+    dy = rq(torch.randn(y.shape, generator=g), dtype)
+    y.backward(dy)
+    tdt = ops.torch_dtype(dtype)
+    w4 = torch.empty(Cin, Cout, 4, 4, device=DEV)
+    ops.up3_expand(w3.detach().to(DEV), w4, Cout, Cin)
+    torch.cuda.synchronize()
+    # the expansion against its definition, and the forward in torch through the expanded weight (exact identity up to rounding)
+    torch.testing.assert_close(F.conv_transpose2d(x.detach(), w4.cpu(), b, 2, 1), y.detach(), rtol=1e-5, atol=1e-5)
+    c = ops.make_conv(B, 2 * H, 2 * H, Cout, Cin, 4, 2, 1)           # conv view: input = the 2H x 2H output side
+    wpf = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=tdt)
+    wpb = torch.empty(ops.pack_bwd_elems(c, dtype), device=DEV, dtype=tdt)
+    ops.pack_conv(c, dtype, w4, wpf, wpb)
+    got = torch.empty(B, 2 * H, 2 * H, Cout, device=DEV, dtype=tdt)
+    ops.conv_bwd_data(c, dtype, nhwc(x.detach(), dtype), wpb, got, ops.epilogue(bias=b.to(DEV)))
+    dx = torch.empty(B, H, H, Cin, device=DEV, dtype=tdt)
+    ops.conv_fwd(c, dtype, nhwc(dy, dtype), wpf, dx, None)
+    slab = torch.empty(ops.conv_wgrad_ws_bytes(c, dtype) // 4, device=DEV)
+    ns = ops.conv_wgrad(c, dtype, nhwc(dy, dtype), nhwc(x.detach(), dtype), slab)
+    dw4 = torch.empty(Cin, Cout, 4, 4, device=DEV)
+    ops.wgrad_reduce(slab, ns, Cin, Cin, Cout, 16, dw4, accumulate=False)
+    dw3 = torch.ones(Cout, Cin, 3, 3, device=DEV)
+    ops.up3_contract(dw4, dw3, Cout, Cin)                            # accumulates
+    torch.cuda.synchronize()
+    # 16-bit: the packed taps are the ROUNDED tap sums (one rounding of w0 + w1 instead of two products): within the 16-bit bound
+    rt, at = tol(dtype, Cin * 9)
+    torch.testing.assert_close(nchw(got), y.detach(), rtol=rt, atol=at)
+    torch.testing.assert_close(nchw(dx), x.grad, rtol=rt, atol=tol(dtype, Cout * 9)[1])
+    rt, at = tol(dtype, B * 4 * H * H)
+    torch.testing.assert_close(dw3.cpu() - 1.0, w3.grad, rtol=rt, atol=at * 16)      # (sums of up to four 4x4 entries of ~2000-term sums each)
+
+
 # B, H (input), Cin, Cout: 4x4 / stride-2 / pad-1 layers with channel counts in multiples of 128 -> the parity-class weight-gradient
 # kernel (igemm_tn8.hip).  Output lattices 16x16 (bands of 4 rows per K step), 8x8 (one image per step), 4x4 (four images per step),
 # 32x32 (2 rows per step), 2x2 (16 images per step); several splits over m; both channel tilings > 1
