@@ -2048,7 +2048,13 @@ static void tn_plan(const eg_conv* c, int* nsplit, int* rps) {
     long long want = base >= target ? 1 : (target + base - 1) / base;
     long long cap = M / 256 > 0 ? M / 256 : 1;
     if (want > cap) want = cap;
-    static const int max_split = [] { const char* e = getenv("EG_TN_MAXSPLIT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 128; }();
+    // the cap binds where one output tile (x a tap or two) is all there is -- the image-side layers as GEMMs over patch rows, and there it IS
+    // the grid: 128 workgroups of a 32 x 64 tile keep ~1.5 MB in flight and stream the 100-134 MB of the small networks' image-side layers at
+    // ~1 TB/s; 512 of them: colored dSprites 3.08 -> 2.98 ms, dSprites 1.39 -> 1.38, MNIST neutral (profiles/r03_zv_tn_maxsplit_small.txt).
+    // Big tiles (CelebA's 128-channel image-side layer, on a lane beside the main chain's GEMMs) keep 128: more took CUs from the main chain
+    // (5.50 -> 5.65 ms at 512, profiles/r01_timeline_notes.md item 14).  EG_TN_MAXSPLIT overrides both.
+    static const int max_split_env = [] { const char* e = getenv("EG_TN_MAXSPLIT"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    const int max_split = max_split_env ? max_split_env : (bnt * bct <= 64 * 64 ? 512 : 128);
     if (want > max_split) want = max_split;
     int r = round_up((int)((M + want - 1) / want), 32);
     *rps = r;

@@ -43,9 +43,15 @@ struct ImgMfmaParams {
     float stat_slope;
 };
 
-template <typename T, bool STAT>
-__global__ __launch_bounds__(256, STAT ? 2 : EG_IMG_CONV_OCC) void conv_img_mfma_kernel(const ImgMfmaParams p, int ntiles) {
-    constexpr int N = 128, XS = 72, OS = N + 8;          // LDS row pitches in elements: 66 used columns (x = -1 .. 64); 16-byte aligned pixel rows
+// N = 128 (CelebA), 64 or 32 (the first trunk layer of the dSprites networks, dSprites/rp.py:95-97, rp_color.py:95-97): output channels
+// workgroups per CU: the narrow instantiations hold a 4 / 2-tile weight panel in registers instead of 8 tiles -- more workgroups in flight
+constexpr int img_conv_occ(int N) { return N == 128 ? EG_IMG_CONV_OCC : (N == 64 ? 4 : 6); }
+template <typename T, bool STAT, int N = 128>
+__global__ __launch_bounds__(256, STAT ? 2 : img_conv_occ(N)) void conv_img_mfma_kernel(const ImgMfmaParams p, int ntiles) {
+    static_assert(N == 128 || N == 64 || N == 32, "column tiles of 16, whole 64-byte chunks per pixel row");
+    static_assert(!STAT || N == 128, "the statistics epilogue is laid out for 128 channels");
+    constexpr int NJ = N / 16;                            // column tiles of 16 channels
+    constexpr int XS = 72, OS = N + 8;                    // LDS row pitches in elements: 66 used columns (x = -1 .. 64); 16-byte aligned pixel rows
     __shared__ __attribute__((aligned(16))) unsigned short s_in[4][6][XS];
     __shared__ __attribute__((aligned(16))) unsigned short s_out[4][16][OS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -55,11 +61,11 @@ __global__ __launch_bounds__(256, STAT ? 2 : EG_IMG_CONV_OCC) void conv_img_mfma
     const T* __restrict__ wp = reinterpret_cast<const T*>(p.wp);
 
     // weight fragments, loaded once per workgroup: column tile j, k half s -> panel rows j*16 + frow, columns s*32 + fq*8 .. +7
-    uint4 bf[2][8];
+    uint4 bf[2][NJ];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bf[s][j] = *reinterpret_cast<const uint4*>(wp + (size_t)(j * 16 + frow) * 64 + s * 32 + fq * 8);
+        for (int j = 0; j < NJ; ++j) bf[s][j] = *reinterpret_cast<const uint4*>(wp + (size_t)(j * 16 + frow) * 64 + s * 32 + fq * 8);
     __shared__ __attribute__((aligned(16))) float s_bias[N];
     __shared__ __attribute__((aligned(16))) float s_red[STAT ? 4 * 2 * N : 4];      // per wave: the two sums of its 16 pixels, per channel
     if (tid < N) s_bias[tid] = p.bias ? p.bias[tid] : 0.f;      // (published by the loop's first barrier)
@@ -134,13 +140,13 @@ __global__ __launch_bounds__(256, STAT ? 2 : EG_IMG_CONV_OCC) void conv_img_mfma
         const uint2 a00 = ld8(fq >> 1, r0), a01 = ld8(fq >> 1, r0 + 1);
         const uint2 a10 = ld8(2 + (fq >> 1), r0), a11 = ld8(2 + (fq >> 1), r0 + 1);
         const uint4 a0 = make_uint4(a00.x, a00.y, a01.x, a01.y), a1 = make_uint4(a10.x, a10.y, a11.x, a11.y);
-        f32x4 acc[8];
+        f32x4 acc[NJ];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) mfma_step<T>(a0, bf[0][j], acc[j]);
+        for (int j = 0; j < NJ; ++j) mfma_step<T>(a0, bf[0][j], acc[j]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) mfma_step<T>(a1, bf[1][j], acc[j]);
+        for (int j = 0; j < NJ; ++j) mfma_step<T>(a1, bf[1][j], acc[j]);
         // epilogue: acc[j][r] = C[pixel frow][channel j*16 + fq*4 + r]; the arithmetic of the NT kernels' epilogue
         const int ib = tile / tpi, rem_t = tile - ib * tpi;
         const int tape = ib / p.B;
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256, STAT ? 2 : EG_IMG_CONV_OCC) void conv_img_mfma
         const float inv_sigma = p.sigma ? 1.f / p.sigma[tape] : 1.f;
         const size_t pix0 = ((size_t)ib * OH + oy0 + ry) * OW + gx * 32 + (wave & 1) * 16;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             T h[4];
             const float4 bv = *reinterpret_cast<const float4*>(&s_bias[j * 16 + fq * 4]);
             const float bj[4] = {bv.x, bv.y, bv.z, bv.w};
@@ -196,9 +202,10 @@ __global__ __launch_bounds__(256, STAT ? 2 : EG_IMG_CONV_OCC) void conv_img_mfma
             const float t = ((s_red[(0 * 2 + which) * N + n] + s_red[(1 * 2 + which) * N + n]) + s_red[(2 * 2 + which) * N + n]) + s_red[(3 * 2 + which) * N + n];
             p.stat_out[((size_t)which * N + n) * ntiles + tile] = t;
         }
+        constexpr int CPR = N / 8, RPI = 64 / CPR;       // 16-byte chunks per pixel row; pixel rows one store instruction covers
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = it * 4 + (lane >> 4), chunk = lane & 15;
+        for (int it = 0; it < 16 / RPI; ++it) {
+            const int row = it * RPI + lane / CPR, chunk = lane % CPR;
             const uint4 v = *reinterpret_cast<const uint4*>(&s_out[wave][row][chunk * 8]);
             *reinterpret_cast<uint4*>(out + (pix0 + row) * N + chunk * 8) = v;
         }
@@ -209,18 +216,19 @@ __global__ __launch_bounds__(256, STAT ? 2 : EG_IMG_CONV_OCC) void conv_img_mfma
 extern "C" int eg_conv_img_mfma_stat_blocks(int B, int H, int W, int ntapes) { return (H / 4) * (W / 64) * B * ntapes; }
 
 extern "C" int eg_conv_img_mfma_ok(int dtype, int C, int H, int W, int N, int k, int stride, int pad) {
-    return dtype != EG_F32 && C >= 1 && C <= 4 && N == 128 && k == 4 && stride == 2 && pad == 1 && H >= 4 && (H % 4) == 0 && (W % 64) == 0;
+    return dtype != EG_F32 && C >= 1 && C <= 4 && (N == 128 || N == 64 || N == 32) && k == 4 && stride == 2 && pad == 1 && H >= 4 && (H % 4) == 0 && (W % 64) == 0;
 }
 
-extern "C" int eg_conv_img_mfma(int dtype, const float* img0, const float* img1, const float* img2, const float* gate0, const float* gate1,
-                                const float* gate2, int ntapes, const void* wp, void* out, int B, int C, int H, int W, const eg_epilogue* ep,
-                                int gate_act, float gate_slope, eg_stream_t s) {
+extern "C" int eg_conv_img_mfma_n(int dtype, const float* img0, const float* img1, const float* img2, const float* gate0, const float* gate1,
+                                  const float* gate2, int ntapes, const void* wp, void* out, int B, int C, int H, int W, int N, const eg_epilogue* ep,
+                                  int gate_act, float gate_slope, eg_stream_t s) {
     EG_REQUIRE(img0 && wp && out && ntapes >= 1 && ntapes <= 3 && B > 0, "eg_conv_img_mfma: bad argument");
-    EG_REQUIRE(eg_conv_img_mfma_ok(dtype, C, H, W, 128, 4, 2, 1), "eg_conv_img_mfma: 16-bit types, C <= 4, H %% 4 == 0, W %% 64 == 0 only (use eg_im2col_img + eg_conv_fwd)");
+    EG_REQUIRE(eg_conv_img_mfma_ok(dtype, C, H, W, N, 4, 2, 1), "eg_conv_img_mfma: 16-bit types, C <= 4, N = 32 / 64 / 128, H %% 4 == 0, W %% 64 == 0 only (use eg_im2col_img + eg_conv_fwd)");
     EG_REQUIRE((ntapes < 2 || img1) && (ntapes < 3 || img2), "eg_conv_img_mfma: one image pointer per tape");
     EG_REQUIRE(!ep || (!ep->mask && ep->out_mode == EG_OUT_NHWC && ep->bias_mod == 0 && (ep->stat_mode == EG_STAT_NONE || ep->stat_mode == EG_STAT_BN_BWD)),
                "eg_conv_img_mfma: unsupported epilogue field");
     const bool stat = ep && ep->stat_mode == EG_STAT_BN_BWD;
+    EG_REQUIRE(!stat || N == 128, "eg_conv_img_mfma: EG_STAT_BN_BWD with 128 output channels only");
     EG_REQUIRE(!stat || (ep->stat_out && ep->stat_aux && ep->stat_p0 && ep->stat_p1 && ep->stat_p2 && ep->stat_p3), "eg_conv_img_mfma: EG_STAT_BN_BWD needs stat_out, stat_aux (z) and stat_p0..p3");
     ImgMfmaParams p;
     memset(&p, 0, sizeof(p));
@@ -238,15 +246,30 @@ extern "C" int eg_conv_img_mfma(int dtype, const float* img0, const float* img1,
     }
     const int ntiles = (H / 4) * (W / 64) * B * ntapes;  // 2 output rows x 32 columns each
     static const int wgs = [] { const char* e = getenv("EG_IMG_CONV_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256 * EG_IMG_CONV_OCC; }();
-    const dim3 grid(ntiles < wgs ? ntiles : wgs);         // persistent: two workgroups per CU (181 registers) walk the tiles with the weight panel in registers
+    const int wgs_n = N == 128 ? wgs : 256 * img_conv_occ(N);
+    const dim3 grid(ntiles < wgs_n ? ntiles : wgs_n);     // persistent: a few workgroups per CU walk the tiles with the weight panel in registers
     if (stat) {
         const dim3 gs(ntiles < 512 ? ntiles : 512);      // two workgroups per CU: the sums take the registers
         if (dtype == EG_F16) hipLaunchKernelGGL((conv_img_mfma_kernel<f16_t, true>), gs, dim3(256), 0, (hipStream_t)s, p, ntiles);
         else hipLaunchKernelGGL((conv_img_mfma_kernel<bf16_t, true>), gs, dim3(256), 0, (hipStream_t)s, p, ntiles);
-    } else if (dtype == EG_F16) hipLaunchKernelGGL((conv_img_mfma_kernel<f16_t, false>), grid, dim3(256), 0, (hipStream_t)s, p, ntiles);
-    else hipLaunchKernelGGL((conv_img_mfma_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)s, p, ntiles);
+    } else if (N == 128) {
+        if (dtype == EG_F16) hipLaunchKernelGGL((conv_img_mfma_kernel<f16_t, false>), grid, dim3(256), 0, (hipStream_t)s, p, ntiles);
+        else hipLaunchKernelGGL((conv_img_mfma_kernel<bf16_t, false>), grid, dim3(256), 0, (hipStream_t)s, p, ntiles);
+    } else if (N == 64) {
+        if (dtype == EG_F16) hipLaunchKernelGGL((conv_img_mfma_kernel<f16_t, false, 64>), grid, dim3(256), 0, (hipStream_t)s, p, ntiles);
+        else hipLaunchKernelGGL((conv_img_mfma_kernel<bf16_t, false, 64>), grid, dim3(256), 0, (hipStream_t)s, p, ntiles);
+    } else {
+        if (dtype == EG_F16) hipLaunchKernelGGL((conv_img_mfma_kernel<f16_t, false, 32>), grid, dim3(256), 0, (hipStream_t)s, p, ntiles);
+        else hipLaunchKernelGGL((conv_img_mfma_kernel<bf16_t, false, 32>), grid, dim3(256), 0, (hipStream_t)s, p, ntiles);
+    }
     EG_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int eg_conv_img_mfma(int dtype, const float* img0, const float* img1, const float* img2, const float* gate0, const float* gate1,
+                                const float* gate2, int ntapes, const void* wp, void* out, int B, int C, int H, int W, const eg_epilogue* ep,
+                                int gate_act, float gate_slope, eg_stream_t s) {
+    return eg_conv_img_mfma_n(dtype, img0, img1, img2, gate0, gate1, gate2, ntapes, wp, out, B, C, H, W, 128, ep, gate_act, gate_slope, s);
 }
 
 // ------------------------------------------------------------------------------------------------

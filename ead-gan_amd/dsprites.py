@@ -17,7 +17,7 @@ from . import ops
 from .celeba import FUSE_STATS, IMG_GEMM, _HipModule, _require_cuda, transformation_2D      # noqa: F401
 from .engine import Arena, ConvRec, DeviceSampler, ResidentStep, SideStream, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step, check_usable, parse_dtype
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, EG_F32, OUT_NCHW_F32
-from .trunk import Head, TrunkEngine
+from .trunk import IMG_DIRECT, Head, TrunkEngine
 
 opt = argparse.Namespace(n_epochs=100, batch_size=128, lr=0.0001, b1=0.5, b2=0.999, n_cpu=8, latent_dim=200, code_dim=4, n_classes=3,
                          img_size=64, channels=1, sample_interval=1000)           # argparse defaults rp.py:40-51
@@ -68,8 +68,12 @@ class _PxyEngine:
 
     def forward(self, img):
         dt, B, cb = self.dtype, self.B, self.mod.conv_block
-        ops.im2col_img(dt, img, self.patches, B, self.C, self.S, self.S, 4, 2, 1, self.kp)
-        ops.conv_fwd(self.l0.c, dt, self.patches, self.l0.wp_fwd, self.a[0], ops.epilogue(bias=cb[0].bias, act=ACT_LRELU, slope=0.1))
+        ep0 = ops.epilogue(bias=cb[0].bias, act=ACT_LRELU, slope=0.1)
+        if IMG_DIRECT and self.l0.Kpad_fwd == 64 and ops.conv_img_mfma_ok(dt, self.C, self.S, self.S, TRUNK[0], 4, 2, 1):
+            ops.conv_img_mfma(dt, [img], self.l0.wp_fwd, self.a[0], B, self.C, self.S, self.S, ep0, N=TRUNK[0])      # no patch rows (frozen: no weight gradient)
+        else:
+            ops.im2col_img(dt, img, self.patches, B, self.C, self.S, self.S, 4, 2, 1, self.kp)
+            ops.conv_fwd(self.l0.c, dt, self.patches, self.l0.wp_fwd, self.a[0], ep0)
         for i in range(3):
             ops.conv_fwd(self.mid[i].c, dt, self.a[i], self.mid[i].wp_fwd, self.a[i + 1], ops.epilogue(bias=cb[2 * (i + 1)].bias, act=ACT_LRELU, slope=0.1))
         ops.dense_small_fwd(dt, self.a[3], self.head.wp_fwd, self.mod.fc1.bias, self.out, B, 16 * TRUNK[3], self.head.Kpad_fwd, self.nout, self.ws.small)
@@ -759,7 +763,7 @@ class DspritesTrainer(ResidentStep):
         de.repack()
         # ---- joint step (:424-482): the generator's adversarial term needs the UPDATED discriminator ----
         main.wait_event(e_gen2)
-        g_fake = de.forward([gen2])["fc2"]
+        g_fake = de.forward([gen2], patches=False)["fc2"]             # (input gradient only: no weight gradient, no patch rows)
         ops.loss_bce_sigmoid(g_fake, 1, 0, B, 1.0, 1.0, L[1:2], self.dout_d[:B])
         dimg_d = de.backward(0, 1, {"fc2": self.dout_d[:B]}, da.grad, need_wgrad=False, need_dimg=True)
         main.wait_event(e_dimg)
@@ -798,7 +802,7 @@ class DspritesTrainer(ResidentStep):
         self._transform(self.code2, self.trans2)
         eo = ee.forward([gen, self.align, self.trans2])
         cat, cont = eo["cat_layer.0"], eo["cont_layer.0"]
-        g_fake = de.forward([gen])["fc2"]
+        g_fake = de.forward([gen], patches=False)["fc2"]
         ops.loss_bce_sigmoid(g_fake, 1, 0, B, 1.0, 1.0, L[1:2], self.dout_d[:B])
         dimg_d = de.backward(0, 1, {"fc2": self.dout_d[:B]}, da.grad, need_wgrad=False, need_dimg=True)
         ops.fill_f32(self.d_cat)

@@ -307,11 +307,11 @@ def conv_img_mfma_stat_blocks(B, H, W, ntapes=1) -> int:
     return lib().query("eg_conv_img_mfma_stat_blocks", B, H, W, ntapes)
 
 
-def conv_img_mfma(dtype, imgs, wp, out, B, C, H, W, ep=None, gates=None, gate_act=ACT_NONE, gate_slope=0.0):
-    """Conv2d(C -> 128, 4, 2, 1) of up to three fp32 NCHW image tensors (tapes) straight on the MFMA units, no patch rows in HBM"""
+def conv_img_mfma(dtype, imgs, wp, out, B, C, H, W, ep=None, gates=None, gate_act=ACT_NONE, gate_slope=0.0, N=128):
+    """Conv2d(C -> N = 128 / 64 / 32, 4, 2, 1) of up to three fp32 NCHW image tensors (tapes) straight on the MFMA units, no patch rows in HBM"""
     im = [_p(t) for t in imgs] + [None] * (3 - len(imgs))
     ga = [_p(t) for t in (gates or [])] + [None] * (3 - len(gates or []))
-    lib().call("eg_conv_img_mfma", dtype, im[0], im[1], im[2], ga[0], ga[1], ga[2], len(imgs), _p(wp), _p(out), B, C, H, W,
+    lib().call("eg_conv_img_mfma_n", dtype, im[0], im[1], im[2], ga[0], ga[1], ga[2], len(imgs), _p(wp), _p(out), B, C, H, W, N,
                ctypes.byref(ep) if ep is not None else None, gate_act, gate_slope, _stream())
 
 

@@ -19,6 +19,10 @@ from .ops import ACT_LRELU, ACT_NONE, EG_F32, OUT_NCHW_F32
 
 IMG_GEMM = os.environ.get("EG_IMG_GEMM", "1") == "1"     # as in celeba.py
 FUSE_STATS = os.environ.get("EG_FUSE_STATS", "1") != "0"  # as in celeba.py
+# the first layer straight from the fp32 images (ops.conv_img_mfma: 4x4 / stride-2 first layers with 32 / 64 / 128 channels, 16-bit types) instead
+# of patch rows + a K = 64 GEMM over them; the patch rows are then only the weight gradient's operand (``forward(..., patches=False)`` skips
+# them where no weight gradient follows).  Same bits.  EG_IMG_DIRECT=0: patch rows + GEMM
+IMG_DIRECT = os.environ.get("EG_IMG_DIRECT", "1") != "0"
 
 SN_EPS = 1e-12
 
@@ -139,6 +143,9 @@ class TrunkEngine:
         ws.need_small(ops.sn_multi_ws_floats(self._sn_arrays[0]))
         self.sn_counters = torch.zeros(16, device=dev, dtype=torch.int32)       # arrival counters of the two-launch power iteration
         self.imgs = [None] * NT
+        self.patch_ok = [False] * NT
+        self.img_direct = (IMG_DIRECT and NT <= 3 and self.l0p.Kpad_fwd == 64 and self.kp <= 64
+                           and ops.conv_img_mfma_ok(dtype, in_ch, size, size, self.W[0], k, 2, pad))
         self.repack()
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -181,14 +188,17 @@ class TrunkEngine:
             return self._sl(self.patches, t0)
         return self._sl(self.y[i - 1] if self.bns[i - 1] is not None else self.a[i - 1], t0)
 
-    def _fwd_pass(self, t0, T, training=True):
+    def _ep(self, i, t0):
+        return ops.epilogue(bias=self.convs[i].bias, sigma=self.sigma[i][t0:], sigma_rows=self.rows(i), act=ACT_LRELU, slope=self.slope)
+
+    def _fwd_pass(self, t0, T, training=True, skip0=False):
         dt, B = self.dtype, self.B
         g = self.geo[T]
         for i in range(self.L):
             geo = g["l0p"] if i == 0 else g["mid"][i - 1]
             wp = self.l0p.wp_fwd if i == 0 else self.mid[i - 1].wp_fwd
-            ops.conv_fwd(geo, dt, self._inp(i, t0), wp, self._sl(self.a[i], t0),
-                         ops.epilogue(bias=self.convs[i].bias, sigma=self.sigma[i][t0:], sigma_rows=self.rows(i), act=ACT_LRELU, slope=self.slope))
+            if not (i == 0 and skip0):                  # (layer 0 of all tapes came from the images in one launch)
+                ops.conv_fwd(geo, dt, self._inp(i, t0), wp, self._sl(self.a[i], t0), self._ep(i, t0))
             bn = self.bns[i]
             if bn is not None:
                 assert T == 1
@@ -214,8 +224,10 @@ class TrunkEngine:
             else:
                 ops.dense_small_fwd(dt, x, wp, h.module.bias, out, T * B, self.K, kpad, h.N, self.ws.small)
 
-    def forward(self, imgs, t0=0, training=True):
-        """len(imgs) forwards as tapes t0.. (power iterations in list order).  Returns {head name: [len(imgs)*B, N]} views."""
+    def forward(self, imgs, t0=0, training=True, patches=True):
+        """len(imgs) forwards as tapes t0.. (power iterations in list order).  Returns {head name: [len(imgs)*B, N]} views.
+        ``patches=False``: no weight gradient will be asked for these tapes -- their patch rows are not built where the first layer reads the
+        images themselves (``img_direct``)."""
         dt, B = self.dtype, self.B
         T = len(imgs)
         assert 1 <= T and t0 + T <= self.NT
@@ -235,12 +247,20 @@ class TrunkEngine:
                     if h.sn:
                         self.hu[h.name][t].copy_(h.module.weight_u)
                         self.hv[h.name][t].copy_(h.module.weight_v)
-            ops.im2col_img(dt, img, self.patches[t * npix:(t + 1) * npix], B, self.in_ch, self.S, self.S, self.k, 2, 1, self.kp)
+            if not self.img_direct:
+                ops.im2col_img(dt, img, self.patches[t * npix:(t + 1) * npix], B, self.in_ch, self.S, self.S, self.k, 2, 1, self.kp)
+                self.patch_ok[t] = True
+        if self.img_direct:
+            ops.conv_img_mfma(dt, list(imgs), self.l0p.wp_fwd, self._sl(self.a[0], t0), B, self.in_ch, self.S, self.S, self._ep(0, t0), N=self.W[0])
+            for kk, img in enumerate(imgs):             # the weight gradient's operand, behind the launch the next layer waits for
+                if patches:
+                    ops.im2col_img(dt, img, self.patches[(t0 + kk) * npix:(t0 + kk + 1) * npix], B, self.in_ch, self.S, self.S, self.k, 2, 1, self.kp)
+                self.patch_ok[t0 + kk] = bool(patches)
         if self.has_bn:
             for kk in range(T):
-                self._fwd_pass(t0 + kk, 1, training)
+                self._fwd_pass(t0 + kk, 1, training, self.img_direct)
         else:
-            self._fwd_pass(t0, T, training)
+            self._fwd_pass(t0, T, training, self.img_direct)
         return {h.name: self.outs[h.name][t0 * B:(t0 + T) * B] for h in self.heads if h.compute}
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -334,6 +354,8 @@ class TrunkEngine:
                                 ws.sums, ws.small, ACT_LRELU, self.slope, self.sigma[i][t0:t0 + 1])
             geo = g["l0p"] if i == 0 else g["mid"][i - 1]
             if need_wgrad:
+                assert i > 0 or all(self.patch_ok[t0:t0 + T]), "forward(..., patches=False) built no patch rows for these tapes"
+
                 def layer_wgrad(wsw, i=i, geo=geo, nm=self.conv_names[i], fused=fused):
                     if fused[0]:
                         tiles_m = fused[0] // 4         # row blocks (128 lattice rows) per sub-pixel phase of the launch that produced dzs_i

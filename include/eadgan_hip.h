@@ -224,6 +224,11 @@ int eg_conv_img_mfma_stat_blocks(int B, int H, int W, int ntapes);
 int eg_conv_img_mfma(int dtype, const float* img0, const float* img1, const float* img2, const float* gate0, const float* gate1,
                      const float* gate2, int ntapes, const void* wp, void* out, int B, int C, int H, int W, const eg_epilogue* ep,
                      int gate_act, float gate_slope, eg_stream_t s);
+/* ... with N = 32, 64 or 128 output channels (wp: the [N][64] panel; out [ntapes*B][H/2][W/2][N]): the first trunk layer of the dSprites
+ * networks, Conv2d(C -> 32, 4, 2, 1) (dSprites/rp.py:95-97, 165-167; rp_color.py likewise).  EG_STAT_BN_BWD: N = 128 only. */
+int eg_conv_img_mfma_n(int dtype, const float* img0, const float* img1, const float* img2, const float* gate0, const float* gate1,
+                       const float* gate2, int ntapes, const void* wp, void* out, int B, int C, int H, int W, int N, const eg_epilogue* ep,
+                       int gate_act, float gate_slope, eg_stream_t s);
 /* ConvTranspose2d(128 -> C <= 3, 4, 2, 1) from 16-bit NHWC activations a [B][Hin][Win][128] to an fp32 NCHW image [B][C][2 Hin][2 Win] in ONE
  * launch (the GEMM's columns stay in LDS): out = act(bias + transposed convolution); wp = the [16 * C][128] panel (row t * C + c) of
  * eg_pack_strided.  The Generator's last layer + Tanh (celebA.py:90-91) and the backward-to-image of the first Discriminator layer (:110).

@@ -60,6 +60,38 @@ def test_first_discriminator_layer_without_patch_rows(T, B, C, dtype):
 
 
 @pytest.mark.parametrize("dtype", [1, 2])
+@pytest.mark.parametrize("T,B,C,N", [(1, 8, 1, 32), (3, 4, 3, 32), (2, 16, 3, 64), (1, 128, 1, 32), (2, 6, 4, 64)])
+def test_first_trunk_layer_of_the_dsprites_networks_without_patch_rows(T, B, C, N, dtype):
+    """Conv2d(C -> 32, 4, 2, 1) + LeakyReLU of the dSprites / colored dSprites trunks (dSprites/rp.py:95-97; 64 channels: the same kernel's other
+    instantiation) straight from the fp32 images: bit-identical to eg_im2col_img + the K = 64 GEMM over patch rows"""
+    S = 64
+    g = torch.Generator().manual_seed(7)
+    imgs = [(torch.rand(B, C, S, S, generator=g) * 2 - 1).to(DEV) for _ in range(T)]
+    w = (torch.randn(N, C, 4, 4, generator=g) * 0.1).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV) * 0.1
+    sigma = (torch.arange(T, dtype=torch.float32) * 0.3 + 0.9).to(DEV)
+    tdt = ops.torch_dtype(dtype)
+    wp = torch.empty(N * 64, device=DEV, dtype=tdt)
+    ops.pack_strided(dtype, w, wp, N, C * 16, 64, 1, C * 16, 0, 1)
+    kw = dict(bias=bias, sigma=sigma, sigma_rows=B * (S // 2) ** 2, act=ops.ACT_LRELU, slope=0.2)
+    npix = B * (S // 2) ** 2
+    patches = torch.empty(T * npix, 64, device=DEV, dtype=tdt)
+    for t, im in enumerate(imgs):
+        ops.im2col_img(dtype, im, patches[t * npix:(t + 1) * npix], B, C, S, S, 4, 2, 1, 64)
+    want = torch.empty(T * B, S // 2, S // 2, N, device=DEV, dtype=tdt)
+    ops.conv_fwd(ops.make_conv(T * B, S // 2, S // 2, 64, N, 1, 1, 0), dtype, patches, wp, want, ops.epilogue(**kw))
+    assert ops.conv_img_mfma_ok(dtype, C, S, S, N, 4, 2, 1)
+    got = torch.full_like(want, 7.0)
+    ops.conv_img_mfma(dtype, imgs, wp, got, B, C, S, S, ops.epilogue(**kw), N=N)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    rq = lambda x: x.to(tdt).float()
+    for t in range(T):
+        ref = F.leaky_relu(F.conv2d(rq(imgs[t]), rq(w), None, 2, 1) / sigma[t] + bias[None, :, None, None], 0.2).permute(0, 2, 3, 1)
+        torch.testing.assert_close(got[t * B:(t + 1) * B].float(), ref, rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", [1, 2])
 def test_generator_last_layer_input_gradient_without_patch_rows(dtype):
     """d(loss)/d(a) of ConvTranspose2d(128 -> 3, 4, 2, 1) + Tanh == Conv2d(3 -> 128, 4, 2, 1) of dimg * (1 - img^2) with the layer's weights"""
     B, C, S = 16, 3, 64
@@ -84,7 +116,8 @@ def test_generator_last_layer_input_gradient_without_patch_rows(dtype):
 def test_other_shapes_are_refused():
     assert not ops.conv_img_mfma_ok(0, 3, 64, 64, 128, 4, 2, 1)          # fp32
     assert not ops.conv_img_mfma_ok(1, 3, 32, 32, 128, 4, 2, 1)          # 32-pixel rows
-    assert not ops.conv_img_mfma_ok(1, 3, 64, 64, 64, 4, 2, 1)           # 64 output channels
+    assert not ops.conv_img_mfma_ok(1, 3, 64, 64, 48, 4, 2, 1)           # 48 output channels (32, 64 and 128 run)
+    assert not ops.conv_img_mfma_ok(1, 3, 64, 64, 32, 3, 2, 1)           # 3x3 filters
 
 
 @pytest.mark.parametrize("dtype", [1, 2])
