@@ -572,16 +572,18 @@ __global__ __launch_bounds__(256) void affine_reg_rpqmnxy_kernel(const float* __
     __shared__ float out7[8], dout7[8], dx6[8];
     __shared__ float sm[16];
     const int b = blockIdx.x, j = threadIdx.x;
-    if (j == 0) {
-        Dual<14> rc[7], tc[7], flat[6];
+    // forward-mode Jacobian, one derivative component per lane (Dual<1> on 14 lanes instead of Dual<14> on one: the same arithmetic per
+    // component, 1/14 of the serial chain every other thread of the workgroup waits for; 110 -> see profiles/r03_zx_mnist_affine.txt)
+    if (j < 14) {
+        Dual<1> rc[7], tc[7], flat[6];
         for (int i = 0; i < 7; ++i) {
-            rc[i] = dvar<14>(o_real[(size_t)b * ld + c0 + i], i);
-            tc[i] = dvar<14>(o_trans[(size_t)b * ld + c0 + i], 7 + i);
+            rc[i].v = o_real[(size_t)b * ld + c0 + i]; rc[i].d[0] = j == i ? 1.f : 0.f;
+            tc[i].v = o_trans[(size_t)b * ld + c0 + i]; tc[i].d[0] = j == 7 + i ? 1.f : 0.f;
         }
-        relative_rpqmnxy<Dual<14>>(rc, tc, flat);
+        relative_rpqmnxy<Dual<1>>(rc, tc, flat);
         for (int i = 0; i < 6; ++i) {
-            h[0][i] = flat[i].v;
-            for (int q = 0; q < 14; ++q) jac[i][q] = flat[i].d[q];
+            if (j == 0) h[0][i] = flat[i].v;
+            jac[i][j] = flat[i].d[0];
         }
     }
     __syncthreads();
