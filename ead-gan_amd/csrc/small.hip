@@ -779,3 +779,90 @@ extern "C" int eg_col2im_img(int dtype, const void* cols, int B, int C, int Hin,
     EG_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution onto ONE output channel from 64 input channels -- the MNIST generator's last
+// layer, Conv2d(64, 1, 3, 1, 1) (MNIST/EAD-GAN_rpqmnxy.py:88):   S[t][c] = sum_{b,y,x} dy[b][y][x] * X[b][y + ty - 1][x + tx - 1][c]
+// As a GEMM this is an N = 1 (padded to 8) x K = 9 * 64 output over M = B * H * W rows: the per-tap kernel streamed the 67 MB activation nine
+// times for 0.3 GFLOP (152 us at B = 256).  Here lane = input channel: a wave walks image rows, every pixel's 64 channels are ONE coalesced
+// load, and the nine products go to nine per-lane accumulators with dy broadcast from a zero-haloed LDS copy of the tile's gradient
+// rows -- the activation is read once.  dy passes through T like the padded copy the GEMM path multiplied (same operands, fp32 sums).
+// Slab layout of the per-tap kernel with N = 1: slab[split][t][c]; eg_wgrad_reduce(slab, nsplit, 1, 1, 64, 9, grad) finishes it.
+// ------------------------------------------------------------------------------------------------
+#define EG_C1_ROWS 8            // image rows per work unit (two per wave)
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_c1_kernel(const T* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int B, int H, int W,
+                                                       int units) {
+    constexpr int C = 64, RB = EG_C1_ROWS;
+    extern __shared__ float s_c1[];                      // [RB + 2][W + 2] gradient rows with a zero halo, then [4][9][C] wave sums
+    float* s_dy = s_c1;
+    float* s_acc = s_c1 + (RB + 2) * (W + 2);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ub = H / RB;                               // units per image
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+        const int b = u / ub, y0 = (u - b * ub) * RB;
+        __syncthreads();                                 // the previous unit's rows have been read
+        for (int i = tid; i < (RB + 2) * (W + 2); i += 256) {
+            const int r = i / (W + 2), cx = i - r * (W + 2);
+            const int y = y0 - 1 + r, xx = cx - 1;
+            float v = 0.f;
+            if (y >= 0 && y < H && xx >= 0 && xx < W) {
+                T h;
+                Elt<T>::st(&h, dy[((size_t)b * H + y) * W + xx]);
+                v = Elt<T>::ld(&h);
+            }
+            s_dy[i] = v;
+        }
+        __syncthreads();
+        // input pixel (iy, ix) meets output pixel (iy - ty + 1, ix - tx + 1) under tap (ty, tx): s_dy row (iy - y0) + 2 - ty, column ix + 2 - tx
+        for (int rr = 0; rr < RB / 4; ++rr) {
+            const int ly = wave * (RB / 4) + rr, iy = y0 + ly;
+            const T* __restrict__ xr = x + (((size_t)b * H + iy) * W) * C + lane;
+            for (int ix0 = 0; ix0 < W; ix0 += 8) {
+                float xv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[j] = Elt<T>::ld(xr + (size_t)(ix0 + j) * C);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ix = ix0 + j;
+#pragma unroll
+                    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+                        for (int tx = 0; tx < 3; ++tx) acc[ty * 3 + tx] = fmaf(xv[j], s_dy[(ly + 2 - ty) * (W + 2) + ix + 2 - tx], acc[ty * 3 + tx]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s_acc[(wave * 9 + t) * C + lane] = acc[t];
+    __syncthreads();
+    for (int i = tid; i < 9 * C; i += 256)
+        slab[(size_t)blockIdx.x * 9 * C + i] = ((s_acc[i] + s_acc[9 * C + i]) + s_acc[2 * 9 * C + i]) + s_acc[3 * 9 * C + i];
+}
+
+extern "C" int eg_wgrad_c1_ok(int dtype, int C, int H, int W, int Cout, int k, int stride, int pad) {
+    (void)dtype;
+    return C == 64 && Cout == 1 && k == 3 && stride == 1 && pad == 1 && H >= EG_C1_ROWS && (H % EG_C1_ROWS) == 0 && W >= 8 && (W % 8) == 0 && W <= 128;
+}
+/* workgroups (= slabs) eg_wgrad_c1 launches for B images: the caller's slab holds that many x 9 x 64 floats */
+extern "C" int eg_wgrad_c1_splits(int B, int H) {
+    const long long units = (long long)B * (H / EG_C1_ROWS);
+    return (int)(units < 1024 ? units : 1024);
+}
+extern "C" int eg_wgrad_c1(int dtype, const void* x, const float* dy, float* slab, int B, int H, int W, int C, int* nsplit_out, eg_stream_t s) {
+    EG_REQUIRE(x && dy && slab && nsplit_out && B > 0, "eg_wgrad_c1: bad argument");
+    EG_REQUIRE(eg_wgrad_c1_ok(dtype, C, H, W, 1, 3, 1, 1), "eg_wgrad_c1: 64 input channels, one output channel, 3x3 / stride 1 / pad 1, H %% 8 == 0, W %% 8 == 0 only");
+    EG_REQUIRE(dtype == EG_F32 || dtype == EG_BF16 || dtype == EG_F16, "dtype must be EG_F32, EG_BF16 or EG_F16");
+    const int units = B * (H / EG_C1_ROWS), grid = eg_wgrad_c1_splits(B, H);
+    const size_t lds = ((size_t)(EG_C1_ROWS + 2) * (W + 2) + 4 * 9 * 64) * sizeof(float);
+    hipStream_t st = (hipStream_t)s;
+    if (dtype == EG_F32) hipLaunchKernelGGL(wgrad_c1_kernel<float>, dim3(grid), dim3(256), lds, st, (const float*)x, dy, slab, B, H, W, units);
+    else if (dtype == EG_F16) hipLaunchKernelGGL(wgrad_c1_kernel<f16_t>, dim3(grid), dim3(256), lds, st, (const f16_t*)x, dy, slab, B, H, W, units);
+    else hipLaunchKernelGGL(wgrad_c1_kernel<bf16_t>, dim3(grid), dim3(256), lds, st, (const bf16_t*)x, dy, slab, B, H, W, units);
+    *nsplit_out = grid;
+    EG_LAUNCH_CHECK();
+    return 0;
+}

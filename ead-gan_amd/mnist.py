@@ -29,6 +29,9 @@ SLOPE = 0.2
 # output pixel instead of 9 in the forward, the input gradient (no upsampled gradient + sum-pool) and the weight gradient (ops.up3_expand /
 # up3_contract; the same sums up to fp32 rounding of the tap sums).  EG_UP3_CONVT=0: the 3x3 convolution over the upsampled lattice
 UP3_AS_CONVT = os.environ.get("EG_UP3_CONVT", "1") != "0"
+# the last layer's weight gradient (Conv2d(64, 1, 3, 1, 1), :88) by the kernel that reads the activation once (ops.wgrad_c1) instead of the
+# per-tap GEMM over the output padded to 8 channels (nine passes over 67 MB at B = 256); EG_C1_DIRECT=0: the GEMM
+C1_DIRECT = os.environ.get("EG_C1_DIRECT", "1") != "0"
 
 
 def weights_init_normal(m):
@@ -76,6 +79,9 @@ class _GenEngine:
         self.c3f = ConvRec(dtype, B, 4 * s, 4 * s, 64, self.CH, 3, 1, 1, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
         self.c3 = ConvRec(dtype, B, 4 * s, 4 * s, 64, 8, 3, 1, 1, device=dev, want_fwd=False, ws=ws)
         self.w3pad = torch.zeros(8, 64, 3, 3, device=dev, dtype=torch.float32)
+        self.c1_direct = C1_DIRECT and ops.wgrad_c1_ok(dtype, 64, 4 * s, 4 * s, self.CH, 3, 1, 1)
+        if self.c1_direct:
+            ws.need_slab(ops.wgrad_c1_splits(B, 4 * s) * 9 * 64 * 4)
         e = lambda *shape, dt=tdt: torch.empty(shape, device=dev, dtype=dt)
         f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)
         self.inp = e(B, self.cpad)
@@ -182,6 +188,10 @@ class _GenEngine:
         ops.cast_pad(dt, self.dimg_z, self.p8, B * S * S, self.CH, 8)          # [M][1] fp32 (== NCHW with C=1) -> [M][8]
 
         def c3_wgrad(wsw):
+            if self.c1_direct:                          # the activation read once (lane = channel) instead of nine per-tap GEMM passes
+                ns = ops.wgrad_c1(dt, self.a2, self.dimg_z, wsw.slab, B, S, S, 64)
+                ops.wgrad_reduce(wsw.slab, ns, 1, 1, 64, 9, gof("conv_blocks.9.weight"))
+                return
             ns = ops.conv_wgrad(self.c3.c, dt, self.a2, self.p8, wsw.slab, wsw.wgs_target)
             ops.wgrad_reduce(wsw.slab, ns, 8, self.CH, 64, 9, gof("conv_blocks.9.weight"))
         wgrad_side(c3_wgrad, 0)

@@ -239,6 +239,21 @@ def sumpool2x2(dtype, x, y, B, H, W, C):
     lib().call("eg_sumpool2x2", dtype, _p(x), _p(y), B, H, W, C, _stream())
 
 
+def wgrad_c1_ok(dtype, C, H, W, Cout, k, stride, pad) -> bool:
+    return bool(lib().query("eg_wgrad_c1_ok", dtype, C, H, W, Cout, k, stride, pad))
+
+
+def wgrad_c1_splits(B, H) -> int:
+    return lib().query("eg_wgrad_c1_splits", B, H)
+
+
+def wgrad_c1(dtype, x, dy, slab, B, H, W, C) -> int:
+    """weight gradient of Conv2d(64, 1, 3, 1, 1) with the activation read once -> number of slabs [split][9][64] in ``slab``"""
+    ns = ctypes.c_int(0)
+    lib().call("eg_wgrad_c1", dtype, _p(x), _p(dy), _p(slab), B, H, W, C, ctypes.byref(ns), _stream())
+    return ns.value
+
+
 def up3_expand(w3, w4t, Cout, Cin):
     """effective ConvTranspose2d(4, 2, 1) master [Cin][Cout][4][4] of Upsample(2) + Conv2d(Cin -> Cout, 3, 1, 1) (MNIST/EAD-GAN_rpqmnxy.py:81-82)"""
     lib().call("eg_up3_expand", _p(w3), _p(w4t), Cout, Cin, _stream())

@@ -157,6 +157,13 @@ int eg_wgrad_reduce_perm(const float* slab, int nsplit, int n_slab, int n_rows, 
 int eg_gather_add(float* out, const float* src, int n, int div, int s_div, int s_mod, eg_stream_t s);
 /* y[B,H,W,C] = 2x2 sum-pool of x[B,2H,2W,C]  (backward of nn.Upsample(scale_factor=2), MNIST/EAD-GAN_rpqmnxy.py:81,85) */
 int eg_sumpool2x2(int dtype, const void* x, void* y, int B, int H, int W, int C, eg_stream_t s);
+/* weight gradient of Conv2d(64, 1, 3, 1, 1) -- the MNIST generator's last layer (MNIST/EAD-GAN_rpqmnxy.py:88) -- with the activation read ONCE
+ * (lane = input channel, nine per-lane accumulators, dy [B][H][W] fp32 broadcast from LDS after a pass through the compute dtype): x
+ * [B][H][W][64] dtype T; writes slab[split][9][64] for eg_wgrad_reduce(slab, *nsplit_out, 1, 1, 64, 9, grad); the slab must hold
+ * eg_wgrad_c1_splits(B, H) * 576 floats.  Replaces eg_cast_pad + the per-tap eg_conv_wgrad over the output padded to 8 channels. */
+int eg_wgrad_c1_ok(int dtype, int C, int H, int W, int Cout, int k, int stride, int pad);
+int eg_wgrad_c1_splits(int B, int H);
+int eg_wgrad_c1(int dtype, const void* x, const float* dy, float* slab, int B, int H, int W, int C, int* nsplit_out, eg_stream_t s);
 /* nn.Upsample(scale_factor=2) + Conv2d(Cin -> Cout, 3, 1, 1) run as ConvTranspose2d(Cin -> Cout, 4, 2, 1) with summed taps
  * (MNIST/EAD-GAN_rpqmnxy.py:81-82, 85-86): eg_up3_expand writes the effective master w4t[Cin][Cout][4][4] (W4[kh] = sum of the 3x3 taps
  * t in [max(0, 2-kh), min(2, 3-kh)], rows and columns alike) from w3[Cout][Cin][3][3]; eg_up3_contract takes the weight gradient of the

@@ -183,6 +183,41 @@ def test_upsample_conv3_as_transposed_conv4(case, dtype):
     torch.testing.assert_close(dw3.cpu() - 1.0, w3.grad, rtol=rt, atol=at * 16)      # (sums of up to four 4x4 entries of ~2000-term sums each)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H", [(3, 32), (300, 32), (2, 8), (1, 16)])
+def test_single_output_channel_weight_gradient_reads_the_activation_once(B, H, dtype):
+    """eg_wgrad_c1 (weight gradient of Conv2d(64, 1, 3, 1, 1), MNIST/EAD-GAN_rpqmnxy.py:88) against torch's autograd on the operands as the
+    kernel sees them (x and dy rounded through the compute dtype) and against the per-tap GEMM path it replaces; more units than workgroups
+    at B = 300 (several units per workgroup)"""
+    g = torch.Generator().manual_seed(21)
+    x = rq(torch.randn(B, 64, H, H, generator=g), dtype)
+    w = (torch.randn(1, 64, 3, 3, generator=g) * 0.1).requires_grad_(True)
+    dy32 = torch.randn(B, 1, H, H, generator=g)
+    dy = rq(dy32, dtype)
+    F.conv2d(x, w, None, 1, 1).backward(dy)
+    assert ops.wgrad_c1_ok(dtype, 64, H, H, 1, 3, 1, 1)
+    slab = torch.empty(ops.wgrad_c1_splits(B, H) * 9 * 64, device=DEV)
+    xd = nhwc(x, dtype)
+    ns = ops.wgrad_c1(dtype, xd, dy32.to(DEV), slab, B, H, H, 64)
+    assert ns == ops.wgrad_c1_splits(B, H)
+    grad = torch.ones(1, 64, 3, 3, device=DEV)
+    ops.wgrad_reduce(slab, ns, 1, 1, 64, 9, grad)
+    # the GEMM path: output gradient padded to 8 channels, per-tap kernel
+    c = ops.make_conv(B, H, H, 64, 8, 3, 1, 1)
+    p8 = torch.empty(B * H * H, 8, device=DEV, dtype=ops.torch_dtype(dtype))
+    ops.cast_pad(dtype, dy32.to(DEV), p8, B * H * H, 1, 8)
+    slab2 = torch.empty(ops.conv_wgrad_ws_bytes(c, dtype) // 4, device=DEV)
+    ns2 = ops.conv_wgrad(c, dtype, xd, p8, slab2)
+    grad2 = torch.ones(1, 64, 3, 3, device=DEV)
+    ops.wgrad_reduce(slab2, ns2, 8, 1, 64, 9, grad2)
+    torch.cuda.synchronize()
+    rt, at = tol(dtype, B * H * H)
+    at = max(at * 4, 2e-5 * math.sqrt(B * H * H))      # entries are sums of B*H*H products of O(1): rounding of the running sum grows with it
+    torch.testing.assert_close(grad.cpu() - 1.0, w.grad, rtol=rt, atol=at)
+    torch.testing.assert_close(grad.cpu(), grad2.cpu(), rtol=rt, atol=at)
+    assert not ops.wgrad_c1_ok(dtype, 32, H, H, 1, 3, 1, 1) and not ops.wgrad_c1_ok(dtype, 64, H, H, 3, 3, 1, 1) and not ops.wgrad_c1_ok(dtype, 64, H, H, 1, 4, 2, 1)
+
+
 # B, H (input), Cin, Cout: 4x4 / stride-2 / pad-1 layers with channel counts in multiples of 128 -> the parity-class weight-gradient
 # kernel (igemm_tn8.hip).  Output lattices 16x16 (bands of 4 rows per K step), 8x8 (one image per step), 4x4 (four images per step),
 # 32x32 (2 rows per step), 2x2 (16 images per step); several splits over m; both channel tilings > 1
