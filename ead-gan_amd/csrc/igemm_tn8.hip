@@ -38,7 +38,8 @@ __device__ __forceinline__ void tn8_wait(int n) {        // vmcnt(n) lgkmcnt(0) 
     }
 }
 
-// CH: channels per tile on both sides (128: the CelebA layers; 64: the dSprites networks) = 16-bit elements per LDS row
+// CH: channels per tile on both sides (128: the CelebA layers; 64: the dSprites generators; 32: the first trunk layers of the dSprites networks,
+// whose 64 x 32 tile of P is four DMA pieces: waves 0..3 issue one each) = 16-bit elements per LDS row
 template <typename T, int CH>
 __global__ __launch_bounds__(512) void igemm_tn8_kernel(const Tn8Params p) {
     constexpr int ROWB = CH * 2;                         // bytes per LDS row (a K row of P, a patch pixel of X)
@@ -46,7 +47,8 @@ __global__ __launch_bounds__(512) void igemm_tn8_kernel(const Tn8Params p) {
     constexpr int CPR = ROWB / 16;                       // 16-byte chunks per row
     constexpr int NBLK = ROWB / 32;                      // 32-byte (16-channel) blocks per row: the swizzle unit
     constexpr int NI = CH / 32, NJ = CH / 16;            // MFMA tiles per wave: output channels (half of CH) x input channels
-    constexpr int NPP_P = 64 / RPP / 8;                  // P pieces per wave and K step
+    constexpr int NPP_P = (64 / RPP + 7) / 8;            // P pieces per wave and K step
+    constexpr int PW_P = 64 / RPP < 8 ? 64 / RPP : 8;    // waves that issue P pieces
     constexpr int STAGE_P = 64 * ROWB, STAGE_X = EG_TN8_XSLOTS * ROWB, STAGE = STAGE_P + STAGE_X;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(512) void igemm_tn8_kernel(const Tn8Params p) {
         const int m0s = mbeg + (s << 6);
         const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)stage * STAGE);
         const unsigned soffP = (unsigned)m0s * (unsigned)p.N * 2u;
-        eg_bufdma1f<0>(srdP, vP[0], soffP, base);
+        if (PW_P == 8 || wave < PW_P) eg_bufdma1f<0>(srdP, vP[0], soffP, base);
         if constexpr (NPP_P > 1) eg_bufdma1f<0x2000>(srdP, vP[NPP_P - 1], soffP, base);
         const int b_s = m0s >> (p.lOH + p.lOW);
         const int oy_s = p.nimg == 1 ? ((m0s >> p.lOW) & OHm) : 0;
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(512) void igemm_tn8_kernel(const Tn8Params p) {
     };
 
     // ring: K step s lives in stage s % 3; steps s + 1 and s + 2 are in flight while step s is multiplied
-    int per = NPP_P;                                     // pieces this wave issues per K step
+    int per = (PW_P == 8 || wave < PW_P) ? NPP_P : 0;    // pieces this wave issues per K step
     for (int j = 0; j < p.npp; ++j) per += (wave + 8 * j) * RPP < p.npix;
     if (nk > 0) issue(0, 0);
     if (nk > 1) issue(1, 1);
@@ -208,7 +210,9 @@ __global__ __launch_bounds__(512) void igemm_tn8_kernel(const Tn8Params p) {
 bool eg_tn8_plan(const eg_conv* c, int dtype, Tn8Params& p, int* nsplit, int wgs_target) {
     static const bool enabled = [] { const char* e = getenv("EG_TN8"); return !(e && atoi(e) == 0); }();
     if (!enabled || dtype == EG_F32 || c->k != 4 || c->stride != 2 || c->pad != 1 || c->up != 0) return false;
-    const int ch = ((c->Cin % 128) == 0 && (c->Cout % 128) == 0) ? 128 : (((c->Cin % 64) == 0 && (c->Cout % 64) == 0) ? 64 : 0);
+    static const bool ch32 = [] { const char* e = getenv("EG_TN8_CH32"); return !(e && atoi(e) == 0); }();
+    const int ch = ((c->Cin % 128) == 0 && (c->Cout % 128) == 0) ? 128 : (((c->Cin % 64) == 0 && (c->Cout % 64) == 0) ? 64
+                   : ((ch32 && (c->Cin % 32) == 0 && (c->Cout % 32) == 0) ? 32 : 0));
     if (ch == 0 || (c->H & 1) || (c->W & 1)) return false;
     const int OH = c->H / 2, OW = c->W / 2;
     const int lOH = ilog2_exact(OH), lOW = ilog2_exact(OW);
@@ -222,9 +226,9 @@ bool eg_tn8_plan(const eg_conv* c, int dtype, Tn8Params& p, int* nsplit, int wgs
     else { p.nimg = 64 / (OH * OW); p.OHt = OH; }
     p.PH = p.OHt + 1; p.PW = OW + 1;
     p.npix = p.nimg * p.PH * p.PW;
-    if (p.npix > EG_TN8_XSLOTS) return false;
     p.ch = ch;
     const int rpp = 1024 / (ch * 2);                    // patch pixels per DMA piece
+    if ((p.npix + rpp - 1) / rpp * rpp > EG_TN8_XSLOTS) return false;      // (whole pieces land in the stage)
     p.npp = ((p.npix + rpp - 1) / rpp + 7) / 8;
     if (p.npp > 5) return false;
     p.inv_pw = (1u << 20) / (unsigned)p.PW + 1;
@@ -260,7 +264,8 @@ static void launch_tn8_ch(const Tn8Params& p, int nsplit, hipStream_t st) {
 
 template <typename T>
 void eg_launch_tn8(const Tn8Params& p, int nsplit, hipStream_t st) {
-    if (p.ch == 64) launch_tn8_ch<T, 64>(p, nsplit, st);
+    if (p.ch == 32) launch_tn8_ch<T, 32>(p, nsplit, st);
+    else if (p.ch == 64) launch_tn8_ch<T, 64>(p, nsplit, st);
     else launch_tn8_ch<T, 128>(p, nsplit, st);
 }
 template void eg_launch_tn8<bf16_t>(const Tn8Params&, int, hipStream_t);

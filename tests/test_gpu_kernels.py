@@ -223,7 +223,9 @@ def test_single_output_channel_weight_gradient_reads_the_activation_once(B, H, d
 # 32x32 (2 rows per step), 2x2 (16 images per step); several splits over m; both channel tilings > 1
 TN8_CASES = [(8, 32, 128, 256), (12, 16, 256, 128), (16, 8, 128, 128), (4, 64, 128, 128), (64, 4, 256, 256), (5 * 4, 16, 128, 128),
              # 64-channel tiles (the dSprites networks' layers; 192 = 3 tiles of 64)
-             (8, 64, 64, 64), (16, 32, 64, 64), (16, 16, 64, 192), (32, 8, 64, 64), (24, 8, 192, 64)]
+             (8, 64, 64, 64), (16, 32, 64, 64), (16, 16, 64, 192), (32, 8, 64, 64), (24, 8, 192, 64),
+             # 32-channel tiles (first trunk layers of the dSprites networks: 32 -> 32 at 32x32 inputs, 32 -> 64 at 16x16; P tile = four DMA pieces)
+             (8, 32, 32, 32), (16, 16, 32, 64), (12, 64, 32, 32), (16, 8, 96, 32), (32, 16, 32, 32)]
 
 
 @pytest.mark.parametrize("dtype", [1, 2])
