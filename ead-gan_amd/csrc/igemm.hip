@@ -2604,26 +2604,37 @@ extern "C" int eg_bias_grad_sn(int dtype, const void* dzs, const void* a, const 
 // ---- the same sums from the epilogue of the convolution that produced dzs (eg_epilogue.stat_mode = EG_STAT_SN_BIAS) -----------------
 // stat: [N][nrb] column sums, then [nrb][tiles_n] tile dots.  gb[n] += sum_rb sigma[tape(rb)] * stat[n][rb] (one wave per n, contiguous
 // reads); coef[t] = sum of the dots of tape t's row blocks (waves N .. N + ntapes - 1).  tape(rb) = (rb % tiles_m) / tiles_per_tape.
+// WIDE: one 256-thread workgroup per sum instead of one wave (>= 1024 row blocks: the small networks' 32 / 64-channel layers at B = 128 .. 512
+// have up to 12288 of them; one wave walked 192 partials per lane with an integer division each: 25 us per launch in the colored dSprites step);
+// fewer row blocks keep the wave form and its bits
+template <bool WIDE>
 __global__ void colsum_sn_final_t_kernel(const float* __restrict__ stat, int nrb, int N, int tiles_m, int tiles_per_tape, int tiles_n, int ntapes,
                                          const float* __restrict__ sigma, float* __restrict__ gb, float* __restrict__ coef) {
-    const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    __shared__ float sh[4];
+    const int lane = WIDE ? threadIdx.x : threadIdx.x & 63, step = WIDE ? 256 : 64;
+    const int j = WIDE ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    float acc = 0.f;
     if (j < N) {
         const float* __restrict__ a = stat + (size_t)j * nrb;
-        float acc = 0.f;
-        for (int r = lane; r < nrb; r += 64) acc += a[r] * sigma[(r % tiles_m) / tiles_per_tape];
-        acc = wave_sum(acc);
-        if (lane == 0) gb[j] += acc;
+        for (int r = lane; r < nrb; r += step) acc += a[r] * sigma[(r % tiles_m) / tiles_per_tape];
     } else if (j < N + ntapes) {
         const int t = j - N;
         const float* __restrict__ dots = stat + (size_t)N * nrb;
-        float acc = 0.f;
-        for (int r = lane; r < nrb; r += 64)
+        for (int r = lane; r < nrb; r += step)
             if ((r % tiles_m) / tiles_per_tape == t)
                 for (int q = 0; q < tiles_n; ++q) acc += dots[(size_t)r * tiles_n + q];
-        acc = wave_sum(acc);
-        if (lane == 0) coef[t] = acc;
+    } else if (!WIDE) {
+        return;
     }
+    acc = wave_sum(acc);
+    if (WIDE) {
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        acc = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    }
+    if (lane != 0) return;
+    if (j < N) gb[j] += acc;
+    else if (j < N + ntapes) coef[j - N] = acc;
 }
 
 extern "C" int eg_bias_grad_sn_fused(const float* stat, int nrb, int N, int tiles_m, int tiles_per_tape, int ntapes, const float* sigma, float* gb,
@@ -2631,8 +2642,12 @@ extern "C" int eg_bias_grad_sn_fused(const float* stat, int nrb, int N, int tile
     EG_REQUIRE(stat && sigma && gb && coef && nrb > 0 && N > 0 && ((N % 128) == 0 || N == 64 || N == 32) && tiles_m > 0 && (nrb % tiles_m) == 0 &&
                tiles_per_tape > 0 && ntapes > 0 && ntapes <= 4 && tiles_per_tape * ntapes == tiles_m, "eg_bias_grad_sn_fused: bad argument");
     // (column tiles of the producing launch: 128 wide for the 8-wave kernels, the whole row for the register-staged kernel's N = 32 / 64)
-    hipLaunchKernelGGL(colsum_sn_final_t_kernel, dim3(cdiv(N + ntapes, 4)), dim3(256), 0, (hipStream_t)s, stat, nrb, N, tiles_m, tiles_per_tape,
-                       N >= 128 ? N / 128 : 1, ntapes, sigma, gb, coef);
+    if (nrb >= 1024)
+        hipLaunchKernelGGL(colsum_sn_final_t_kernel<true>, dim3(N + ntapes), dim3(256), 0, (hipStream_t)s, stat, nrb, N, tiles_m, tiles_per_tape,
+                           N >= 128 ? N / 128 : 1, ntapes, sigma, gb, coef);
+    else
+        hipLaunchKernelGGL(colsum_sn_final_t_kernel<false>, dim3(cdiv(N + ntapes, 4)), dim3(256), 0, (hipStream_t)s, stat, nrb, N, tiles_m, tiles_per_tape,
+                           N >= 128 ? N / 128 : 1, ntapes, sigma, gb, coef);
     EG_LAUNCH_CHECK();
     return 0;
 }

@@ -176,24 +176,37 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// WIDE: one 256-thread workgroup per channel instead of one wave (launches with >= 1024 row blocks: the small networks at B = 128 .. 512 have
+// 1024-12288 of them and 32-64 channels -- 16 waves walking 4096 partials each took 18-25 us on the main chain; few row blocks keep the wave
+// form and its bits)
+__device__ __forceinline__ double block4_sum_f64(double v, double* sh) {
+    v = wave_sum_f64(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double t = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    __syncthreads();
+    return t;
+}
+template <bool WIDE>
 __global__ void bn_stats_final_eq_kernel(const float* __restrict__ stat, int nrb, int C, int cnt, int M, float eps, float momentum,
                                          float* running_mean, float* running_var, long long* nbt, float* save_mean, float* save_invstd,
                                          const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ coef) {
-    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+    __shared__ double sh[4];
+    const int c = WIDE ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = WIDE ? threadIdx.x : threadIdx.x & 63, step = WIDE ? 256 : 64;
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
     if (c >= C) return;
     const float* __restrict__ mb = stat + (size_t)c * nrb;
     const float* __restrict__ qb = stat + ((size_t)C + c) * nrb;
     double sm = 0.0;
-    for (int r = lane; r < nrb; r += 64) sm += (double)mb[r];
-    const double mean = wave_sum_f64(sm) / (double)nrb;
+    for (int r = lane; r < nrb; r += step) sm += (double)mb[r];
+    const double mean = (WIDE ? block4_sum_f64(sm, sh) : wave_sum_f64(sm)) / (double)nrb;
     double m2 = 0.0;
-    for (int r = lane; r < nrb; r += 64) {
+    for (int r = lane; r < nrb; r += step) {
         const double d = (double)mb[r] - mean;
         m2 += (double)qb[r] + (double)cnt * d * d;
     }
-    m2 = wave_sum_f64(m2);
+    m2 = WIDE ? block4_sum_f64(m2, sh) : wave_sum_f64(m2);
     if (lane != 0) return;
     const double var = m2 / (double)M;
     save_mean[c] = (float)mean;
@@ -207,6 +220,7 @@ __global__ void bn_stats_final_eq_kernel(const float* __restrict__ stat, int nrb
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
     }
 }
+#define EG_FINAL_WIDE_NRB 1024
 
 extern "C" int eg_bn_fwd_train_fused(int dtype, const void* x, void* y, int M, int C, const float* stat, int nrb, int rows_per_block,
                                      const float* gamma, const float* beta, float eps, float momentum, float* running_mean, float* running_var,
@@ -217,8 +231,12 @@ extern "C" int eg_bn_fwd_train_fused(int dtype, const void* x, void* y, int M, i
     EG_REQUIRE(C % (dtype == EG_F32 ? 4 : 8) == 0, "eg_bn_fwd_train_fused: C must be a multiple of the 16-byte vector width");
     hipStream_t st = (hipStream_t)s;
     float* coef = ws;                                   // 2*C floats
-    hipLaunchKernelGGL(bn_stats_final_eq_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, stat, nrb, C, rows_per_block, M, eps, momentum, running_mean,
-                       running_var, num_batches_tracked, save_mean, save_invstd, gamma, beta, coef);
+    if (nrb >= EG_FINAL_WIDE_NRB)
+        hipLaunchKernelGGL(bn_stats_final_eq_kernel<true>, dim3(C), dim3(256), 0, st, stat, nrb, C, rows_per_block, M, eps, momentum, running_mean,
+                           running_var, num_batches_tracked, save_mean, save_invstd, gamma, beta, coef);
+    else
+        hipLaunchKernelGGL(bn_stats_final_eq_kernel<false>, dim3(cdiv(C, 4)), dim3(256), 0, st, stat, nrb, C, rows_per_block, M, eps, momentum, running_mean,
+                           running_var, num_batches_tracked, save_mean, save_invstd, gamma, beta, coef);
     const int cpr = C / (dtype == EG_F32 ? 4 : 8);
     const int blocks = bn_apply_blocks((size_t)M, cpr);
     if (dtype == EG_F32) hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)x, (float*)y, (size_t)M, C, coef, act, slope);
@@ -520,18 +538,26 @@ extern "C" int eg_bn_bwd_from_sums(int dtype, const void* z, const void* da, voi
 }
 
 // the two sums from the epilogue of the convolution that produced dy (EG_STAT_BN_BWD), stat = [2][C][nrb]: one wave per channel
+template <bool WIDE>       // (WIDE: a workgroup per channel, as bn_stats_final_eq_kernel)
 __global__ void bn_bwd_final_t_kernel(const float* __restrict__ stat, int nrb, int C, float* sums, float* dgamma, float* dbeta,
                                       const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
                                       const float* __restrict__ invstd, int M, float* __restrict__ coef) {
-    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
+    __shared__ float sh[2][4];
+    const int c = WIDE ? blockIdx.x : blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = WIDE ? threadIdx.x : threadIdx.x & 63, step = WIDE ? 256 : 64;
     if (c >= C) return;
     const float* __restrict__ a = stat + (size_t)c * nrb;
     const float* __restrict__ b = stat + ((size_t)C + c) * nrb;
     float s1 = 0.f, s2 = 0.f;
-    for (int r = lane; r < nrb; r += 64) { s1 += a[r]; s2 += b[r]; }
+    for (int r = lane; r < nrb; r += step) { s1 += a[r]; s2 += b[r]; }
     s1 = wave_sum(s1);
     s2 = wave_sum(s2);
+    if (WIDE) {
+        if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s1; sh[1][threadIdx.x >> 6] = s2; }
+        __syncthreads();
+        s1 = ((sh[0][0] + sh[0][1]) + sh[0][2]) + sh[0][3];
+        s2 = ((sh[1][0] + sh[1][1]) + sh[1][2]) + sh[1][3];
+    }
     if (lane != 0) return;
     sums[c] = s1;
     sums[C + c] = s2;
@@ -552,7 +578,10 @@ extern "C" int eg_bn_bwd_fused(int dtype, const void* z, const void* dy, void* d
     EG_REQUIRE(C % (dtype == EG_F32 ? 4 : 8) == 0, "eg_bn_bwd_fused: C must be a multiple of the 16-byte vector width");
     hipStream_t st = (hipStream_t)s;
     float* coef = ws;                                   // 5*C floats
-    hipLaunchKernelGGL(bn_bwd_final_t_kernel, dim3(cdiv(C, 4)), dim3(256), 0, st, stat, nrb, C, sums, dgamma, dbeta, gamma, beta, save_mean, save_invstd, M, coef);
+    if (nrb >= EG_FINAL_WIDE_NRB)
+        hipLaunchKernelGGL(bn_bwd_final_t_kernel<true>, dim3(C), dim3(256), 0, st, stat, nrb, C, sums, dgamma, dbeta, gamma, beta, save_mean, save_invstd, M, coef);
+    else
+        hipLaunchKernelGGL(bn_bwd_final_t_kernel<false>, dim3(cdiv(C, 4)), dim3(256), 0, st, stat, nrb, C, sums, dgamma, dbeta, gamma, beta, save_mean, save_invstd, M, coef);
     const int cpr = C / (dtype == EG_F32 ? 4 : 8);
     const int blocks = bn_apply_blocks((size_t)M, cpr);
     // dy already carries the activation gradient (act = NONE here)

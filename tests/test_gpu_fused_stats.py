@@ -32,7 +32,7 @@ def _splitk_ws():
 
 
 @pytest.mark.parametrize("dtype", [1, 2])
-@pytest.mark.parametrize("B,splitk", [(64, 0), (64, 1), (128, 0)])
+@pytest.mark.parametrize("B,splitk", [(64, 0), (64, 1), (128, 0), (512, 0)])      # (512: >= 1024 row blocks -> a workgroup per channel finishes the sums)
 @pytest.mark.parametrize("Ci,Co", [(256, 128), (64, 64), (64, 32)])
 def test_batchnorm_forward_statistics_from_the_transposed_convolution(B, splitk, dtype, Ci, Co):
     """ConvTranspose2d(Ci -> Co, 4, 2, 1) + BatchNorm2d + ReLU: statistics from the 4-phase backward-data launch (with and without K
@@ -141,12 +141,12 @@ def test_batchnorm_backward_sums_from_the_producing_convolution(dtype, Ci, Co):
 
 
 @pytest.mark.parametrize("dtype", [1, 2])
-@pytest.mark.parametrize("T", [1, 2, 3])
+@pytest.mark.parametrize("T,B", [(1, 64), (2, 64), (3, 64), (3, 256)])             # (3 x 256 images: 1536 row blocks -> a workgroup per sum)
 @pytest.mark.parametrize("Ci,Co", [(128, 256), (64, 64), (32, 64)])
-def test_spectral_norm_bias_gradient_and_coefficient_from_the_backward_data_launch(T, dtype, Ci, Co):
+def test_spectral_norm_bias_gradient_and_coefficient_from_the_backward_data_launch(T, B, dtype, Ci, Co):
     """dzs of a spectrally normalised LeakyReLU layer (T tapes batched along M) from conv_bwd_data with the fused mask: per-tape column sums
     and <dzs, z - bias> from the epilogue == eg_bias_grad_sn on the stored tensor"""
-    B, H = 64, 16                                          # layer below: [T*B,16,16,Ci]; this launch: dY [T*B,8,8,Co] -> dX [T*B,16,16,Ci]
+    H = 16                                                 # layer below: [T*B,16,16,Ci]; this launch: dY [T*B,8,8,Co] -> dX [T*B,16,16,Ci]
     c = ops.make_conv(T * B, H, H, Ci, Co, 4, 2, 1)
     tdt = ops.torch_dtype(dtype)
     dyy = _rand((T * B, H // 2, H // 2, Co), dtype, 21)
