@@ -403,3 +403,152 @@ extern "C" int eg_convt_img_mfma(int dtype, const void* a, const void* wp, const
     EG_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+//   wgrad_img : weight gradient of the image-side 4x4 / stride-2 / pad-1 layers of the dSprites networks WITHOUT patch rows in HBM
+//               S[n][c*16 + ky*4 + kx] = sum_{b,oy,ox} P[(b, oy, ox)][n] * img[b][c][2 oy - 1 + ky][2 ox - 1 + kx]
+//               * Conv2d(C -> 32, 4, 2, 1), the first trunk layer (dSprites/rp.py:95-97, 165-167): P = d(loss)/d(pre-activation), N = 32
+//               * ConvTranspose2d(64 -> C, 4, 2, 1), the generator's last layer (:139-140): img = d(loss)/d(image pre-activation), P = the
+//                 layer's input activation, N = 64 (conv view: same sum)
+// Before: eg_im2col_img wrote the patch rows [B*1024][16 C] to HBM (67 MB per tape at B = 512, C = 3; 39 us on the main chain) and the per-tap
+// TN GEMM read them back beside P.  Here a workgroup takes 4 output rows x 32 columns of one image, stages the 10 fp32 image rows they
+// touch in LDS as 16-bit values, expands them to patch rows IN LDS, copies the 128 rows of P beside them and multiplies with both operands read
+// transposed (ds_read_b64_tr_b16), one K = 32 step (= one output row) per wave; workgroups walk the tiles and write one fp32 slab each in the
+// per-tap kernel's layout (slab[split][n][16 C]) for the same slab reductions.  64 x 64 images only.
+// ------------------------------------------------------------------------------------------------
+struct ImgWgradParams {
+    const float* img[4];      // per tape: [B][C][64][64] fp32
+    const void* P;            // [ntapes * B * 1024][N] dtype T (tape-major rows)
+    float* slab;              // [gridDim.x][N][16 * C]
+    int B, C, ntiles;         // tiles of 128 output pixels over all tapes
+};
+
+template <typename T, int N>
+__global__ __launch_bounds__(256) void wgrad_img_kernel(const ImgWgradParams p) {
+    constexpr int H = 64, W = 64, OW = 32, XS = 72;      // image size; LDS pitch of an image row (x = -1 .. 64 at columns 0 .. 65)
+    constexpr int PP = N + 8, PX = 72;                   // LDS pitches (elements) of a P row and of a patch row (64 columns used)
+    constexpr int NI = N / 16;
+    __shared__ __attribute__((aligned(16))) unsigned short s_in[4][10][XS];
+    __shared__ __attribute__((aligned(16))) unsigned short s_p[128 * PP];
+    __shared__ __attribute__((aligned(16))) unsigned short s_x[128 * PX];
+    __shared__ float s_red[4][N][16];                    // one column tile at a time
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, pc = li & 3;
+    const int kc = p.C * 16, nj = p.C;                   // patch columns, column tiles of 16
+    const T* __restrict__ P = reinterpret_cast<const T*>(p.P);
+    for (int i = tid; i < 4 * 10 * XS; i += 256) (&s_in[0][0][0])[i] = 0;       // halo columns and unused channels stay zero
+    for (int i = tid; i < 128 * PX; i += 256) s_x[i] = 0;                       // columns 16 C .. 63 stay zero
+    f32x4 acc[NI][4];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    auto tr2 = [&](const unsigned short* base, int pitch, int row, int blk) {   // 8 K-consecutive elements of column blk*16 + li (rows row .. row + 7)
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + (row + q) * pitch + blk * 16 + pc * 4));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + (row + 4 + q) * pitch + blk * 16 + pc * 4));
+        return make_uint4(((uint32_t)(uint16_t)lo[0]) | ((uint32_t)(uint16_t)lo[1] << 16), ((uint32_t)(uint16_t)lo[2]) | ((uint32_t)(uint16_t)lo[3] << 16),
+                          ((uint32_t)(uint16_t)hi[0]) | ((uint32_t)(uint16_t)hi[1] << 16), ((uint32_t)(uint16_t)hi[2]) | ((uint32_t)(uint16_t)hi[3] << 16));
+    };
+    for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+        const int ib = tile >> 3, oy0 = (tile & 7) * 4;  // image over all tapes; first of the tile's four output rows
+        const int tape = ib / p.B, b = ib - tape * p.B;
+        const float* __restrict__ img = p.img[tape] + (size_t)b * p.C * H * W;
+        __syncthreads();                                 // the previous tile's fragments have been read
+        // image rows 2 oy0 - 1 .. 2 oy0 + 8 of every channel, fp32 -> T; rows outside the image are zero
+        for (int e = tid; e < p.C * 10 * 16; e += 256) {
+            const int c = e / 160, rem = e - c * 160, r = rem >> 4, x4 = rem & 15;
+            const int iy = 2 * oy0 - 1 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < H) v = *reinterpret_cast<const float4*>(img + ((size_t)c * H + iy) * W + x4 * 4);
+            T h[4];
+            Elt<T>::st(h + 0, v.x); Elt<T>::st(h + 1, v.y); Elt<T>::st(h + 2, v.z); Elt<T>::st(h + 3, v.w);
+            const unsigned short* hb = reinterpret_cast<const unsigned short*>(h);
+            unsigned short* row = &s_in[c][r][1 + x4 * 4];
+            row[0] = hb[0]; row[1] = hb[1]; row[2] = hb[2]; row[3] = hb[3];
+        }
+        // the tile's 128 rows of P: contiguous in memory (4 output rows x 32 columns of one image)
+        const T* __restrict__ Pt = P + ((size_t)ib * 1024 + (size_t)oy0 * OW) * N;
+        for (int e = tid; e < 128 * (N / 8); e += 256) {
+            const int row = e / (N / 8), ch = e - row * (N / 8);
+            *reinterpret_cast<uint4*>(&s_p[row * PP + ch * 8]) = *reinterpret_cast<const uint4*>(Pt + (size_t)row * N + ch * 8);
+        }
+        __syncthreads();
+        // patch rows: pixel (ly, ox), column c*16 + ky*4 + kx <- image row 2 ly + ky of the staged ten, column 2 ox + kx
+        for (int e = tid; e < 128 * kc; e += 256) {
+            const int pix = e / kc, k = e - pix * kc;
+            const int c = k >> 4, ky = (k >> 2) & 3, kx = k & 3;
+            s_x[pix * PX + k] = s_in[c][2 * (pix >> 5) + ky][2 * (pix & 31) + kx];
+        }
+        __syncthreads();
+        // this wave's K step: the 32 pixels of output row oy0 + wave
+        const int kb = wave * 32 + 8 * g;
+        uint4 af[NI], bfr[4];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) af[i] = tr2(s_p, PP, kb, i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < nj) bfr[j] = tr2(s_x, PX, kb, j);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < nj) {
+                    if constexpr (std::is_same<T, f16_t>::value)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, af[i]), __builtin_bit_cast(f16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bfr[j]), acc[i][j], 0, 0, 0);
+                }
+    }
+    // acc[i][j][r] = S[n = i*16 + g*4 + r][k = j*16 + li] of this wave's pixels: sum the four waves (fixed order), one column tile at a time
+    float* slab = p.slab + (size_t)blockIdx.x * N * kc;
+    for (int j = 0; j < nj; ++j) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    if (jj == j) v = acc[i][jj][r];
+                s_red[wave][i * 16 + g * 4 + r][li] = v;
+            }
+        __syncthreads();
+        for (int e = tid; e < N * 16; e += 256) {
+            const int n = e >> 4, k = e & 15;
+            slab[(size_t)n * kc + j * 16 + k] = ((s_red[0][n][k] + s_red[1][n][k]) + s_red[2][n][k]) + s_red[3][n][k];
+        }
+    }
+}
+
+extern "C" int eg_wgrad_img_ok(int dtype, int C, int H, int W, int N, int k, int stride, int pad) {
+    return dtype != EG_F32 && C >= 1 && C <= 4 && (N == 32 || N == 64) && k == 4 && stride == 2 && pad == 1 && H == 64 && W == 64;
+}
+/* workgroups (= slabs of N x 16 C floats) an eg_wgrad_img launch over `images` images (all tapes) uses */
+extern "C" int eg_wgrad_img_splits(int images) {
+    const long long tiles = (long long)images * 8;
+    return (int)(tiles < 1024 ? tiles : 1024);
+}
+extern "C" int eg_wgrad_img(int dtype, const float* img0, const float* img1, const float* img2, int ntapes, const void* P, float* slab, int B, int C,
+                            int H, int W, int N, int* nsplit_out, eg_stream_t s) {
+    EG_REQUIRE(img0 && P && slab && nsplit_out && ntapes >= 1 && ntapes <= 3 && B > 0, "eg_wgrad_img: bad argument");
+    EG_REQUIRE((ntapes < 2 || img1) && (ntapes < 3 || img2), "eg_wgrad_img: one image pointer per tape");
+    EG_REQUIRE(eg_wgrad_img_ok(dtype, C, H, W, N, 4, 2, 1), "eg_wgrad_img: 16-bit types, C <= 4, N = 32 / 64, 64 x 64 images, 4x4 / stride 2 / pad 1 only (use eg_im2col_img + eg_conv_wgrad)");
+    ImgWgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.img[0] = img0; p.img[1] = img1; p.img[2] = img2;
+    p.P = P; p.slab = slab; p.B = B; p.C = C; p.ntiles = ntapes * B * 8;
+    const int grid = eg_wgrad_img_splits(ntapes * B);
+    hipStream_t st = (hipStream_t)s;
+    if (N == 32) {
+        if (dtype == EG_F16) hipLaunchKernelGGL((wgrad_img_kernel<f16_t, 32>), dim3(grid), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((wgrad_img_kernel<bf16_t, 32>), dim3(grid), dim3(256), 0, st, p);
+    } else {
+        if (dtype == EG_F16) hipLaunchKernelGGL((wgrad_img_kernel<f16_t, 64>), dim3(grid), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((wgrad_img_kernel<bf16_t, 64>), dim3(grid), dim3(256), 0, st, p);
+    }
+    *nsplit_out = grid;
+    EG_LAUNCH_CHECK();
+    return 0;
+}

@@ -330,6 +330,23 @@ def conv_img_mfma(dtype, imgs, wp, out, B, C, H, W, ep=None, gates=None, gate_ac
                ctypes.byref(ep) if ep is not None else None, gate_act, gate_slope, _stream())
 
 
+def wgrad_img_ok(dtype, C, H, W, N, k, stride, pad) -> bool:
+    return bool(lib().query("eg_wgrad_img_ok", dtype, C, H, W, N, k, stride, pad))
+
+
+def wgrad_img_splits(images) -> int:
+    return lib().query("eg_wgrad_img_splits", images)
+
+
+def wgrad_img(dtype, imgs, P, slab, B, C, H, W, N) -> int:
+    """weight gradient of an image-side 4x4 / stride-2 layer straight from the fp32 images of up to three tapes (no patch rows in HBM) ->
+    number of slabs [N][16 C] written to ``slab``"""
+    im = [_p(t) for t in imgs] + [None] * (3 - len(imgs))
+    ns = ctypes.c_int(0)
+    lib().call("eg_wgrad_img", dtype, im[0], im[1], im[2], len(imgs), _p(P), _p(slab), B, C, H, W, N, ctypes.byref(ns), _stream())
+    return ns.value
+
+
 def convt_img_mfma_ok(dtype, C, Hin, Win, K, k, stride, pad) -> bool:
     return bool(lib().query("eg_convt_img_mfma_ok", dtype, C, Hin, Win, K, k, stride, pad))
 

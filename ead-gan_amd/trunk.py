@@ -23,6 +23,9 @@ FUSE_STATS = os.environ.get("EG_FUSE_STATS", "1") != "0"  # as in celeba.py
 # of patch rows + a K = 64 GEMM over them; the patch rows are then only the weight gradient's operand (``forward(..., patches=False)`` skips
 # them where no weight gradient follows).  Same bits.  EG_IMG_DIRECT=0: patch rows + GEMM
 IMG_DIRECT = os.environ.get("EG_IMG_DIRECT", "1") != "0"
+# ... and its weight gradient straight from the images too (ops.wgrad_img: patch rows expanded in LDS): no patch rows in HBM at all for the
+# first layer.  EG_WGRAD_IMG=0: patch rows (eg_im2col_img at forward time) + the per-tap GEMM
+WGRAD_IMG = os.environ.get("EG_WGRAD_IMG", "1") != "0"
 
 SN_EPS = 1e-12
 
@@ -146,6 +149,10 @@ class TrunkEngine:
         self.patch_ok = [False] * NT
         self.img_direct = (IMG_DIRECT and NT <= 3 and self.l0p.Kpad_fwd == 64 and self.kp <= 64
                            and ops.conv_img_mfma_ok(dtype, in_ch, size, size, self.W[0], k, 2, pad))
+        self.wgrad_direct = (self.img_direct and WGRAD_IMG and self.kp == self.k0
+                             and ops.wgrad_img_ok(dtype, in_ch, size, size, self.W[0], k, 2, pad))
+        if self.wgrad_direct:
+            ws.need_slab(ops.wgrad_img_splits(NT * B) * self.W[0] * self.kp * 4)
         self.repack()
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -253,9 +260,9 @@ class TrunkEngine:
         if self.img_direct:
             ops.conv_img_mfma(dt, list(imgs), self.l0p.wp_fwd, self._sl(self.a[0], t0), B, self.in_ch, self.S, self.S, self._ep(0, t0), N=self.W[0])
             for kk, img in enumerate(imgs):             # the weight gradient's operand, behind the launch the next layer waits for
-                if patches:
+                if patches and not self.wgrad_direct:
                     ops.im2col_img(dt, img, self.patches[(t0 + kk) * npix:(t0 + kk + 1) * npix], B, self.in_ch, self.S, self.S, self.k, 2, 1, self.kp)
-                self.patch_ok[t0 + kk] = bool(patches)
+                self.patch_ok[t0 + kk] = bool(patches) and not self.wgrad_direct
         if self.has_bn:
             for kk in range(T):
                 self._fwd_pass(t0 + kk, 1, training, self.img_direct)
@@ -354,7 +361,7 @@ class TrunkEngine:
                                 ws.sums, ws.small, ACT_LRELU, self.slope, self.sigma[i][t0:t0 + 1])
             geo = g["l0p"] if i == 0 else g["mid"][i - 1]
             if need_wgrad:
-                assert i > 0 or all(self.patch_ok[t0:t0 + T]), "forward(..., patches=False) built no patch rows for these tapes"
+                assert i > 0 or self.wgrad_direct or all(self.patch_ok[t0:t0 + T]), "forward(..., patches=False) built no patch rows for these tapes"
 
                 def layer_wgrad(wsw, i=i, geo=geo, nm=self.conv_names[i], fused=fused):
                     if fused[0]:
@@ -363,7 +370,10 @@ class TrunkEngine:
                     else:
                         ops.bias_grad_sn(dt, self._sl(self.dz[i], t0), self._sl(self.a[i], t0), self.convs[i].bias, T * self.rows(i), self.W[i], self.rows(i),
                                          self.sigma[i][t0:], self.slope, wsw.small, gof(nm + ".bias"), self.coef[i])
-                    ns = ops.conv_wgrad(geo, dt, self._inp(i, t0), self._sl(self.dz[i], t0), wsw.slab, wsw.wgs_target)
+                    if i == 0 and self.wgrad_direct:    # straight from the tapes' images (they are intact until the caller joins this chain)
+                        ns = ops.wgrad_img(dt, [self.imgs[t] for t in range(t0, t0 + T)], self._sl(self.dz[0], t0), wsw.slab, B, self.in_ch, self.S, self.S, self.W[0])
+                    else:
+                        ns = ops.conv_wgrad(geo, dt, self._inp(i, t0), self._sl(self.dz[i], t0), wsw.slab, wsw.wgs_target)
                     ops.wgrad_reduce_rank1(wsw.slab, ns, self.W[i], self.W[i], self.cin[i], self.taps if i > 0 else 1, gof(nm + ".weight_orig"), T,
                                            self.coef[i], self.u[i][t0:], self.v[i][t0:], self.k0 if i == 0 else 0)
                 wgrad_side(layer_wgrad)

@@ -113,6 +113,50 @@ def test_generator_last_layer_input_gradient_without_patch_rows(dtype):
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("dtype", [1, 2])
+@pytest.mark.parametrize("T,B,C,N", [(1, 4, 1, 32), (3, 5, 3, 32), (2, 160, 3, 32), (1, 6, 3, 64), (2, 3, 4, 64)])
+def test_image_side_weight_gradient_without_patch_rows(T, B, C, N, dtype):
+    """eg_wgrad_img against eg_im2col_img + the per-tap GEMM over the patch rows (the path it replaces) and against torch's autograd on the
+    operands as the kernel sees them (images and output gradients rounded through the compute dtype); (2, 160): more tiles than workgroups"""
+    S = 64
+    g = torch.Generator().manual_seed(9)
+    tdt = ops.torch_dtype(dtype)
+    rq = lambda x: x.to(tdt).float()
+    imgs = [(torch.rand(B, C, S, S, generator=g) * 2 - 1) for _ in range(T)]
+    dy = rq(torch.randn(T * B, N, S // 2, S // 2, generator=g))
+    w = torch.zeros(N, C, 4, 4, requires_grad=True)
+    F.conv2d(rq(torch.cat(imgs)), w, None, 2, 1).backward(dy)
+    P = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(tdt)
+    dimgs = [im.to(DEV) for im in imgs]
+    assert ops.wgrad_img_ok(dtype, C, S, S, N, 4, 2, 1)
+    slab = torch.full((ops.wgrad_img_splits(T * B) * N * 16 * C,), float("nan"), device=DEV)
+    ns = ops.wgrad_img(dtype, dimgs, P, slab, B, C, S, S, N)
+    assert ns == ops.wgrad_img_splits(T * B)
+    got = torch.zeros(N, C, 4, 4, device=DEV)
+    ops.wgrad_reduce(slab, ns, N, N, 16 * C, 1, got, accumulate=True)
+    # the path it replaces
+    kp = 16 * C
+    npix = B * (S // 2) ** 2
+    patches = torch.empty(T * npix, kp, device=DEV, dtype=tdt)
+    for t in range(T):
+        ops.im2col_img(dtype, dimgs[t], patches[t * npix:(t + 1) * npix], B, C, S, S, 4, 2, 1, kp)
+    c = ops.make_conv(T * B, S // 2, S // 2, kp, N, 1, 1, 0)
+    slab2 = torch.empty(ops.conv_wgrad_ws_bytes(c, dtype) // 4, device=DEV)
+    ns2 = ops.conv_wgrad(c, dtype, patches, P, slab2)
+    ref = torch.zeros(N, C, 4, 4, device=DEV)
+    ops.wgrad_reduce(slab2, ns2, N, N, kp, 1, ref, accumulate=True)
+    torch.cuda.synchronize()
+    scale = (T * B * 1024) ** 0.5
+    torch.testing.assert_close(got.cpu(), w.grad, rtol=2e-3, atol=2e-4 * scale)
+    torch.testing.assert_close(got.cpu(), ref.cpu(), rtol=1e-4, atol=2e-5 * scale)      # same 16-bit products, fp32 sums in another order
+    # deterministic
+    slab3 = torch.zeros_like(slab)
+    ops.wgrad_img(dtype, dimgs, P, slab3, B, C, S, S, N)
+    torch.cuda.synchronize()
+    assert torch.equal(slab, slab3)
+    assert not ops.wgrad_img_ok(0, C, S, S, N, 4, 2, 1) and not ops.wgrad_img_ok(dtype, C, 32, 32, N, 4, 2, 1) and not ops.wgrad_img_ok(dtype, C, S, S, 128, 4, 2, 1)
+
+
 def test_other_shapes_are_refused():
     assert not ops.conv_img_mfma_ok(0, 3, 64, 64, 128, 4, 2, 1)          # fp32
     assert not ops.conv_img_mfma_ok(1, 3, 32, 32, 128, 4, 2, 1)          # 32-pixel rows
