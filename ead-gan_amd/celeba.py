@@ -490,6 +490,10 @@ class _DiscEngine:
         self.imgs = [None] * NT
         self.patch_ok = [False] * NT                    # tape has its patch rows (the weight gradient of layer 0 reads them)
         self.img_direct = IMG_DIRECT and ops.conv_img_mfma_ok(dtype, C, S, S, W[0], 4, 2, 1)
+        # ... and the first layer's weight gradient from the images too (ops.wgrad_img): no patch rows in HBM at all for that layer
+        self.wgrad_direct = self.img_direct and WGRAD_IMG and self.kp == 16 * C and ops.wgrad_img_ok(dtype, C, S, S, W[0], 4, 2, 1)
+        if self.wgrad_direct:
+            self.ws.need_slab(ops.wgrad_img_splits(NT * B, W[0]) * W[0] * self.kp * 4)
         self._stat = {}                                 # (layer, T) -> (row blocks, buffer) of the fused bias-gradient / coefficient sums
         self._sn_arrays = None
         self._sn(0)
@@ -662,14 +666,20 @@ class _DiscEngine:
             x_in = sl(self.a[i - 1]) if i > 0 else sl(self.patches)
             if need_wgrad:
                 def layer_wgrad(wsw, i=i, m=m, geo=geo, x_in=x_in, fused=fused):
-                    if i == 0:
+                    direct = i == 0 and self.wgrad_direct       # straight from the tapes' images: patch rows expanded in LDS (eg_wgrad_img)
+                    if i == 0 and not direct:
                         for t in range(t0, t0 + T):     # patch rows of tapes whose forward ran straight from the image
                             if not self.patch_ok[t]:
                                 self._im2col_tape(t, self.imgs[t])
+
+                    def gemm():
+                        if direct:
+                            return ops.wgrad_img(dt, [self.imgs[t] for t in range(t0, t0 + T)], sl(self.dz[0]), wsw.slab, B, self.C, self.S, self.S, W[0])
+                        return ops.conv_wgrad(geo, dt, x_in, sl(self.dz[i]), wsw.slab, wsw.wgs_target)
                     # the weight-gradient GEMM first: the column sums below (only the slab reduce needs their coefficient) do not fit on a CU
                     # beside a resident GEMM workgroup and used to hold the chain's GEMM back by ~50 us
                     if WGRAD_FIRST:
-                        ns = ops.conv_wgrad(geo, dt, x_in, sl(self.dz[i]), wsw.slab, wsw.wgs_target)
+                        ns = gemm()
                     if fused[0]:
                         tiles_m = fused[0] // 4         # row blocks (of 256 or 128 lattice rows: the kernel's tile height) per sub-pixel phase
                         ops.bias_grad_sn_fused(fused[1], fused[0], W[i], tiles_m, tiles_m // T, T, self.sigma[i][t0:], gof(f"main.{2 * i}.bias"), self.coef[i])
@@ -677,7 +687,7 @@ class _DiscEngine:
                         ops.bias_grad_sn(dt, sl(self.dz[i]), sl(self.a[i]), m.bias, T * self.rows(i), W[i], self.rows(i), self.sigma[i][t0:], LRELU_SLOPE,
                                          wsw.small, gof(f"main.{2 * i}.bias"), self.coef[i])
                     if not WGRAD_FIRST:
-                        ns = ops.conv_wgrad(geo, dt, x_in, sl(self.dz[i]), wsw.slab, wsw.wgs_target)
+                        ns = gemm()
                     taps = 16 if i > 0 else 1
                     ops.wgrad_reduce_rank1(wsw.slab, ns, W[i], W[i], self.cin[i], taps, gof(f"main.{2 * i}.weight_orig"), T, self.coef[i],
                                            self.u[i][t0:], self.v[i][t0:])
@@ -978,6 +988,11 @@ MULTI_GRAPH = os.environ.get("EG_MULTI_GRAPH", "0") != "0"
 # draws only), instead of in front of it on the main chain; same bits; EG_INPUTS_ON_PREP=0: on the main chain
 INPUTS_ON_PREP = os.environ.get("EG_INPUTS_ON_PREP", "1") != "0"
 LAZY_PATCHES = os.environ.get("EG_LAZY_PATCHES", "1") != "0"
+# EXPERIMENT (default off here; on in the small networks' trunks): the first D layer's weight gradient straight from the images (ops.wgrad_img,
+# N = 128) instead of lazily built patch rows + the per-tap GEMM.  Same gradient within fp32 summation order (tests), 7 launches fewer, but
+# SLOWER in the overlapped step, 4.27 -> 4.32 ms (profiles/r03_zzf_ab_wgrad_img_celeba.txt): its 59 KiB of LDS per workgroup do not fit on a CU
+# beside a resident 8-wave GEMM workgroup, so the lane chain waits for tiles to retire where the 12-18 us patch-row launches slipped in
+WGRAD_IMG = os.environ.get("EG_WGRAD_IMG_CELEBA", "0") != "0"
 WGRAD_FIRST = os.environ.get("EG_WGRAD_FIRST", "1") != "0"     # D's lane chains: the weight-gradient GEMM before the bias-gradient sums
 # kernel hint of the generator's first layer (ONE 128-row tile x 128 column tiles, 4 K steps: 1 GFLOP): the register-staged kernel (1) runs it
 # in ~10 us where the planner's persistent pipeline (0) takes 22-24; same bits; step -0.6 % (profiles/r03_zh_ab_g0_variant.txt)

@@ -429,9 +429,12 @@ __global__ __launch_bounds__(256) void wgrad_img_kernel(const ImgWgradParams p) 
     constexpr int PP = N + 8, PX = 72;                   // LDS pitches (elements) of a P row and of a patch row (64 columns used)
     constexpr int NI = N / 16;
     __shared__ __attribute__((aligned(16))) unsigned short s_in[4][10][XS];
-    __shared__ __attribute__((aligned(16))) unsigned short s_p[128 * PP];
-    __shared__ __attribute__((aligned(16))) unsigned short s_x[128 * PX];
-    __shared__ float s_red[4][N][16];                    // one column tile at a time
+    __shared__ __attribute__((aligned(16))) unsigned short s_px[128 * PP + 128 * PX];
+    unsigned short* s_p = s_px;
+    unsigned short* s_x = s_px + 128 * PP;
+    // the four waves' sums of one column tile at a time: over the operand tiles, behind the loop's last barrier (N = 128: 32 KiB over 52)
+    static_assert(4 * N * 16 * sizeof(float) <= (128 * PP + 128 * PX) * sizeof(unsigned short), "the reduction scratch lies over the operand tiles");
+    float (*s_red)[N][16] = reinterpret_cast<float (*)[N][16]>(s_px);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, li = lane & 15, q = li >> 2, pc = li & 3;
     const int kc = p.C * 16, nj = p.C;                   // patch columns, column tiles of 16
@@ -523,25 +526,29 @@ __global__ __launch_bounds__(256) void wgrad_img_kernel(const ImgWgradParams p) 
 }
 
 extern "C" int eg_wgrad_img_ok(int dtype, int C, int H, int W, int N, int k, int stride, int pad) {
-    return dtype != EG_F32 && C >= 1 && C <= 4 && (N == 32 || N == 64) && k == 4 && stride == 2 && pad == 1 && H == 64 && W == 64;
+    return dtype != EG_F32 && C >= 1 && C <= 4 && (N == 32 || N == 64 || N == 128) && k == 4 && stride == 2 && pad == 1 && H == 64 && W == 64;
 }
-/* workgroups (= slabs of N x 16 C floats) an eg_wgrad_img launch over `images` images (all tapes) uses */
-extern "C" int eg_wgrad_img_splits(int images) {
-    const long long tiles = (long long)images * 8;
-    return (int)(tiles < 1024 ? tiles : 1024);
+/* workgroups (= slabs of N x 16 C floats) an eg_wgrad_img launch over `images` images (all tapes) with N output channels uses */
+extern "C" int eg_wgrad_img_splits_n(int images, int N) {
+    const long long tiles = (long long)images * 8, cap = N >= 128 ? 256 : 1024;      // (wide slabs: fewer of them to reduce)
+    return (int)(tiles < cap ? tiles : cap);
 }
+extern "C" int eg_wgrad_img_splits(int images) { return eg_wgrad_img_splits_n(images, 32); }
 extern "C" int eg_wgrad_img(int dtype, const float* img0, const float* img1, const float* img2, int ntapes, const void* P, float* slab, int B, int C,
                             int H, int W, int N, int* nsplit_out, eg_stream_t s) {
     EG_REQUIRE(img0 && P && slab && nsplit_out && ntapes >= 1 && ntapes <= 3 && B > 0, "eg_wgrad_img: bad argument");
     EG_REQUIRE((ntapes < 2 || img1) && (ntapes < 3 || img2), "eg_wgrad_img: one image pointer per tape");
-    EG_REQUIRE(eg_wgrad_img_ok(dtype, C, H, W, N, 4, 2, 1), "eg_wgrad_img: 16-bit types, C <= 4, N = 32 / 64, 64 x 64 images, 4x4 / stride 2 / pad 1 only (use eg_im2col_img + eg_conv_wgrad)");
+    EG_REQUIRE(eg_wgrad_img_ok(dtype, C, H, W, N, 4, 2, 1), "eg_wgrad_img: 16-bit types, C <= 4, N = 32 / 64 / 128, 64 x 64 images, 4x4 / stride 2 / pad 1 only (use eg_im2col_img + eg_conv_wgrad)");
     ImgWgradParams p;
     memset(&p, 0, sizeof(p));
     p.img[0] = img0; p.img[1] = img1; p.img[2] = img2;
     p.P = P; p.slab = slab; p.B = B; p.C = C; p.ntiles = ntapes * B * 8;
-    const int grid = eg_wgrad_img_splits(ntapes * B);
+    const int grid = eg_wgrad_img_splits_n(ntapes * B, N);
     hipStream_t st = (hipStream_t)s;
-    if (N == 32) {
+    if (N == 128) {
+        if (dtype == EG_F16) hipLaunchKernelGGL((wgrad_img_kernel<f16_t, 128>), dim3(grid), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((wgrad_img_kernel<bf16_t, 128>), dim3(grid), dim3(256), 0, st, p);
+    } else if (N == 32) {
         if (dtype == EG_F16) hipLaunchKernelGGL((wgrad_img_kernel<f16_t, 32>), dim3(grid), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((wgrad_img_kernel<bf16_t, 32>), dim3(grid), dim3(256), 0, st, p);
     } else {

@@ -334,8 +334,8 @@ def wgrad_img_ok(dtype, C, H, W, N, k, stride, pad) -> bool:
     return bool(lib().query("eg_wgrad_img_ok", dtype, C, H, W, N, k, stride, pad))
 
 
-def wgrad_img_splits(images) -> int:
-    return lib().query("eg_wgrad_img_splits", images)
+def wgrad_img_splits(images, N=32) -> int:
+    return lib().query("eg_wgrad_img_splits_n", images, N)
 
 
 def wgrad_img(dtype, imgs, P, slab, B, C, H, W, N) -> int:

@@ -152,7 +152,7 @@ class TrunkEngine:
         self.wgrad_direct = (self.img_direct and WGRAD_IMG and self.kp == self.k0
                              and ops.wgrad_img_ok(dtype, in_ch, size, size, self.W[0], k, 2, pad))
         if self.wgrad_direct:
-            ws.need_slab(ops.wgrad_img_splits(NT * B) * self.W[0] * self.kp * 4)
+            ws.need_slab(ops.wgrad_img_splits(NT * B, self.W[0]) * self.W[0] * self.kp * 4)
         self.repack()
 
     # ------------------------------------------------------------------------------------------------------------------

@@ -240,10 +240,11 @@ int eg_conv_img_mfma_n(int dtype, const float* img0, const float* img1, const fl
  * images, C <= 4): S[n][c*16 + ky*4 + kx] = sum over output pixels of P[pixel][n] * img[b][c][2 oy - 1 + ky][2 ox - 1 + kx] for up to three
  * tapes (img_t fp32 NCHW; P [ntapes*B*1024][N] dtype T, tape-major rows) -- Conv2d(C -> 32, 4, 2, 1) of the trunks (dSprites/rp.py:95-97,
  * 165-167; N = 32, P = d(loss)/d(pre-activation)) and ConvTranspose2d(64 -> C, 4, 2, 1) of the generator (:139-140; N = 64, img = the image
- * gradient, P = the layer's input).  Writes *nsplit_out = eg_wgrad_img_splits(ntapes * B) slabs [N][16 C] (the per-tap kernel's layout over
+ * gradient, P = the layer's input).  Writes *nsplit_out = eg_wgrad_img_splits_n(ntapes * B, N) slabs [N][16 C] (the per-tap kernel's layout over
  * patch rows: finish with eg_wgrad_reduce / _rank1 / _perm as after eg_im2col_img + eg_conv_wgrad, which this replaces). */
 int eg_wgrad_img_ok(int dtype, int C, int H, int W, int N, int k, int stride, int pad);
-int eg_wgrad_img_splits(int images);
+int eg_wgrad_img_splits(int images);                 /* N = 32 / 64 */
+int eg_wgrad_img_splits_n(int images, int N);        /* ... and N = 128: the first Discriminator layer of the CelebA script (celebA/EAD-GAN_celebA.py:110) */
 int eg_wgrad_img(int dtype, const float* img0, const float* img1, const float* img2, int ntapes, const void* P, float* slab, int B, int C,
                  int H, int W, int N, int* nsplit_out, eg_stream_t s);
 /* ConvTranspose2d(128 -> C <= 3, 4, 2, 1) from 16-bit NHWC activations a [B][Hin][Win][128] to an fp32 NCHW image [B][C][2 Hin][2 Win] in ONE

@@ -114,10 +114,11 @@ def test_generator_last_layer_input_gradient_without_patch_rows(dtype):
 
 
 @pytest.mark.parametrize("dtype", [1, 2])
-@pytest.mark.parametrize("T,B,C,N", [(1, 4, 1, 32), (3, 5, 3, 32), (2, 160, 3, 32), (1, 6, 3, 64), (2, 3, 4, 64)])
+@pytest.mark.parametrize("T,B,C,N", [(1, 4, 1, 32), (3, 5, 3, 32), (2, 160, 3, 32), (1, 6, 3, 64), (2, 3, 4, 64), (3, 4, 3, 128), (1, 40, 3, 128)])
 def test_image_side_weight_gradient_without_patch_rows(T, B, C, N, dtype):
     """eg_wgrad_img against eg_im2col_img + the per-tap GEMM over the patch rows (the path it replaces) and against torch's autograd on the
-    operands as the kernel sees them (images and output gradients rounded through the compute dtype); (2, 160): more tiles than workgroups"""
+    operands as the kernel sees them (images and output gradients rounded through the compute dtype); (2, 160, .., 32) and (1, 40, .., 128): more
+    tiles than workgroups; N = 128: the first Discriminator layer of the CelebA script"""
     S = 64
     g = torch.Generator().manual_seed(9)
     tdt = ops.torch_dtype(dtype)
@@ -129,9 +130,9 @@ def test_image_side_weight_gradient_without_patch_rows(T, B, C, N, dtype):
     P = dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(tdt)
     dimgs = [im.to(DEV) for im in imgs]
     assert ops.wgrad_img_ok(dtype, C, S, S, N, 4, 2, 1)
-    slab = torch.full((ops.wgrad_img_splits(T * B) * N * 16 * C,), float("nan"), device=DEV)
+    slab = torch.full((ops.wgrad_img_splits(T * B, N) * N * 16 * C,), float("nan"), device=DEV)
     ns = ops.wgrad_img(dtype, dimgs, P, slab, B, C, S, S, N)
-    assert ns == ops.wgrad_img_splits(T * B)
+    assert ns == ops.wgrad_img_splits(T * B, N)
     got = torch.zeros(N, C, 4, 4, device=DEV)
     ops.wgrad_reduce(slab, ns, N, N, 16 * C, 1, got, accumulate=True)
     # the path it replaces
@@ -154,7 +155,7 @@ def test_image_side_weight_gradient_without_patch_rows(T, B, C, N, dtype):
     ops.wgrad_img(dtype, dimgs, P, slab3, B, C, S, S, N)
     torch.cuda.synchronize()
     assert torch.equal(slab, slab3)
-    assert not ops.wgrad_img_ok(0, C, S, S, N, 4, 2, 1) and not ops.wgrad_img_ok(dtype, C, 32, 32, N, 4, 2, 1) and not ops.wgrad_img_ok(dtype, C, S, S, 128, 4, 2, 1)
+    assert not ops.wgrad_img_ok(0, C, S, S, N, 4, 2, 1) and not ops.wgrad_img_ok(dtype, C, 32, 32, N, 4, 2, 1) and not ops.wgrad_img_ok(dtype, C, S, S, 48, 4, 2, 1)
 
 
 def test_other_shapes_are_refused():
