@@ -15,7 +15,7 @@ from torch.nn.utils import spectral_norm
 
 from . import ops
 from .celeba import FUSE_STATS, IMG_GEMM, _HipModule, _require_cuda, transformation_2D      # noqa: F401
-from .engine import Arena, ConvRec, DeviceSampler, ResidentStep, SideStream, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step, check_usable, parse_dtype
+from .engine import FUSE_DRAWS, Arena, ConvRec, DeviceSampler, ResidentStep, SideStream, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step, check_usable, parse_dtype
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, EG_F32, OUT_NCHW_F32
 from .trunk import IMG_DIRECT, Head, TrunkEngine
 
@@ -883,5 +883,10 @@ class DeviceInputs(DeviceSampler):
         idx = self.sample_indices(tr.B, 1)
         self.codes_and_labels(tr, 2)
         self.end_draws()
+        if FUSE_DRAWS and self.data.dim() == 3:
+            # gather + uint8 -> float + counter tick as one launch (the gather of the MNIST / CelebA samplers; the same {0, 1} values)
+            N, H, W = self.data.shape
+            ops.gather_u8_images(self.data, idx, None, tr.img, tr.B, 1, H, W, 1.0, 0.0, tick=self.step)
+            return
         ops.u8_to_f32(self.sprites(tr, idx), tr.img)
         self.tick()

@@ -220,6 +220,7 @@ def test_small_network_draws_in_one_launch_are_the_same_draws(family, monkeypatc
     for fuse in (False, True):
         monkeypatch.setattr(eg.engine, "FUSE_DRAWS", fuse)
         monkeypatch.setattr(eg.mnist, "FUSE_DRAWS", fuse)
+        monkeypatch.setattr(eg.dsprites, "FUSE_DRAWS", fuse)
         runs.append(_run_small(family, False))
     (l0, d0, i0, _), (l1, d1, i1, _) = runs
     assert int(i0.step.item()) == 4 and int(i1.step.item()) == 4
