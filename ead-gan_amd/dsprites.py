@@ -22,6 +22,12 @@ from .trunk import IMG_DIRECT, Head, TrunkEngine
 opt = argparse.Namespace(n_epochs=100, batch_size=128, lr=0.0001, b1=0.5, b2=0.999, n_cpu=8, latent_dim=200, code_dim=4, n_classes=3,
                          img_size=64, channels=1, sample_interval=1000)           # argparse defaults rp.py:40-51
 TRUNK = (32, 32, 64, 64)
+# EXPERIMENT (default off): two-chain step with the alignment pass behind the first generator forward (beside the second chain's generator
+# forward) instead of in front of both chains.  Same kernels on the same operands, and the node graph is shorter by ~7 launches -- but the
+# replayed step is far SLOWER, dSprites 1.31 -> 1.73 ms, colored 2.54 -> 3.05 (profiles/r03_zzh_ab_align_late.txt): the second chain then
+# forks from a point with main-chain work queued behind it, and hipGraph's stream-to-queue placement (profiles/r01_timeline_notes.md) runs
+# the two chains one after the other
+ALIGN_LATE = os.environ.get("EG_ALIGN_LATE", "0") != "0"
 
 
 def to_categorical(y, num_columns, device=None):
@@ -719,14 +725,22 @@ class DspritesTrainer(ResidentStep):
         sa_d = None if getattr(self, "tail_lanes", False) else sa          # lanes of the D step's backward
         join = lambda sd: sd.join_lanes() if sd is not None else None
         ops.fill_f32(L)
-        self._align()                                                                        # :374-377
+        align_late = ALIGN_LATE
+        if not align_late:
+            self._align()                                                                    # :374-377
         gen = ge.forward(self.onehot1, self.code1)
         chain.wait_event(mark())
+        if align_late:
+            # the alignment pass (frozen Encoder_pxy forward + warp: ~7 launches) reads only the real images: behind the first generator forward
+            # on the main chain it runs beside the second chain's generator forward instead of in front of both chains
+            self._align()
+        e_align = mark()
         with torch.cuda.stream(chain), self.ws2.active():
             ops.fill_f32(ga.grad)
             ops.fill_f32(ea.grad)
             gen2 = ge2.forward(self.onehot2, self.code2)
             e_gen2 = mark()
+            chain.wait_event(e_align)
             self._transform(self.code2, self.trans2, second=True)
             eo = ee.forward([gen2, self.align, self.trans2])
             cat, cont = eo["cat_layer.0"], eo["cont_layer.0"]
