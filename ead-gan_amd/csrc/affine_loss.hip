@@ -753,7 +753,8 @@ __global__ __launch_bounds__(1024) void affine_reg_rp_kernel(const float* __rest
 extern "C" int eg_loss_affine_rp(const float* o_real, const float* o_trans, int ld, int c0, int B, const float* code, int ldc, float scale,
                                  float* loss, float* d_real, float* d_trans, float* pred_out, eg_stream_t s) {
     EG_REQUIRE(o_real && o_trans && code && B > 0, "eg_loss_affine_rp: bad argument");
-    const int threads = B * 8 >= 1024 ? 1024 : ((B * 8 + 63) / 64) * 64;
+    static const int cap = [] { const char* e = getenv("EG_AFFINE_THREADS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 1024 ? v : 1024; }();
+    const int threads = B * 8 >= cap ? cap : ((B * 8 + 63) / 64) * 64;
     hipLaunchKernelGGL(affine_reg_rp_kernel, dim3(1), dim3(threads), 0, (hipStream_t)s, o_real, o_trans, ld, c0, B, code, ldc, scale, loss, d_real, d_trans, pred_out);
     EG_LAUNCH_CHECK();
     return 0;
@@ -842,6 +843,9 @@ extern "C" int eg_color_scale(const float* in, const float* code, int ldc, int c
 }
 
 // affine (4 codes, as dSprites) + colour (3 codes): relative gain = (t*.5+1)/(r*.5+1) -> latent (g-1)/.5 ; MSE over 7 values
+// (one thread per sample on Dual<14> stays: sixteen lanes per sample on Dual<1> repeat the value part -- sines, cosines, an arctangent --
+//  sixteen times and need eight passes of a 1024-thread workgroup at B = 512: measured SLOWER in the step, 2.54 -> 2.57 ms,
+//  profiles/r03_zzk_ab_affine_color.txt; the 8-lane form of affine_reg_rp_kernel fits B = 128 in one pass and is faster there)
 __global__ void affine_reg_rp_color_kernel(const float* __restrict__ o_real, const float* __restrict__ o_trans, int ld, int c0, int B,
                                            const float* __restrict__ code, int ldc, float scale, float* loss, float* __restrict__ d_real,
                                            float* __restrict__ d_trans, float* __restrict__ pred_out) {
