@@ -292,9 +292,11 @@ struct ImgTParams {
     float slope;
 };
 
-template <typename T, int R>
+// K = 128 (CelebA) or 64 (the dSprites generators' last layer, dSprites/rp.py:139-140): input channels
+template <typename T, int R, int K = 128>
 __global__ __launch_bounds__(256) void convt_img_mfma_kernel(const ImgTParams p) {
-    constexpr int K = 128, WMAX = 32, NP = 56;           // R input rows per workgroup (+ 2 halo rows); LDS pitch of a pixel's 48 columns
+    constexpr int KS = K / 32;                           // MFMA K steps
+    constexpr int WMAX = 32, NP = 56;           // R input rows per workgroup (+ 2 halo rows); LDS pitch of a pixel's 48 columns
     __shared__ __attribute__((aligned(16))) unsigned short s_cols[(R + 2) * WMAX * NP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
@@ -304,9 +306,9 @@ __global__ __launch_bounds__(256) void convt_img_mfma_kernel(const ImgTParams p)
     const T* __restrict__ a = reinterpret_cast<const T*>(p.a) + (size_t)b * p.Hin * p.Win * K;
 
     // weight fragments: column tile j (n = j*16 + frow), k step s
-    uint4 bf[4][3];
+    uint4 bf[KS][3];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int n = j * 16 + frow;
@@ -314,21 +316,21 @@ __global__ __launch_bounds__(256) void convt_img_mfma_kernel(const ImgTParams p)
         }
     // GEMM over the (R + 2) x Win pixels of this block, 16 pixels per wave and pass; rows outside the image are skipped (never gathered)
     const int npix = (R + 2) * p.Win, ngrp = npix / 16;
-    auto fetch = [&](int g, uint4 (&af)[4]) {            // fragments of pass g: pixel g*16 + frow, k chunks s*32 + fq*8
+    auto fetch = [&](int g, uint4 (&af)[KS]) {            // fragments of pass g: pixel g*16 + frow, k chunks s*32 + fq*8
         const int pl = g * 16 + frow;
         const int iy = r0 - 1 + pl / p.Win, ix = pl % p.Win;
         const bool ok = g < ngrp && iy >= 0 && iy < p.Hin;
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < KS; ++s)
             af[s] = ok ? *reinterpret_cast<const uint4*>(a + ((size_t)iy * p.Win + ix) * K + s * 32 + fq * 8) : make_uint4(0, 0, 0, 0);
     };
-    auto compute = [&](int g, const uint4 (&af)[4]) {
+    auto compute = [&](int g, const uint4 (&af)[KS]) {
         const int pl = g * 16 + frow;                    // local pixel: row pl / Win (0 = halo row r0 - 1), column pl % Win
         f32x4 acc[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int j = 0; j < 3; ++j) mfma_step<T>(af[s], bf[s][j], acc[j]);
         // acc[j][r] = cols[pixel frow][n = j*16 + fq*4 + r], rounded to T like the stored columns were
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void convt_img_mfma_kernel(const ImgTParams p)
         }
     };
     // two passes in flight: the loads of pass g + 4 are issued before pass g is multiplied (a wave alone would wait out every load)
-    uint4 fa[4], fb[4];
+    uint4 fa[KS], fb[KS];
     fetch(wave, fa);
     for (int g = wave; g < ngrp; g += 8) {
         fetch(g + 4, fb);
@@ -379,29 +381,41 @@ __global__ __launch_bounds__(256) void convt_img_mfma_kernel(const ImgTParams p)
 }
 
 extern "C" int eg_convt_img_mfma_ok(int dtype, int C, int Hin, int Win, int K, int k, int stride, int pad) {
-    return dtype != EG_F32 && C >= 1 && C <= 3 && K == 128 && k == 4 && stride == 2 && pad == 1 && Hin >= 16 && (Hin % 16) == 0 && (Win == 16 || Win == 32);
+    return dtype != EG_F32 && C >= 1 && C <= 3 && (K == 128 || K == 64) && k == 4 && stride == 2 && pad == 1 && Hin >= 16 && (Hin % 16) == 0 && (Win == 16 || Win == 32);
 }
 
-extern "C" int eg_convt_img_mfma(int dtype, const void* a, const void* wp, const float* bias, float* out, int B, int C, int Hin, int Win, int act,
-                                 float slope, eg_stream_t s) {
+extern "C" int eg_convt_img_mfma_k(int dtype, const void* a, const void* wp, const float* bias, float* out, int B, int C, int Hin, int Win, int K, int act,
+                                   float slope, eg_stream_t s) {
     EG_REQUIRE(a && wp && out && B > 0, "eg_convt_img_mfma: bad argument");
-    EG_REQUIRE(eg_convt_img_mfma_ok(dtype, C, Hin, Win, 128, 4, 2, 1), "eg_convt_img_mfma: 16-bit types, C <= 3, Hin %% 16 == 0, Win 16 or 32 only (use eg_conv_fwd + eg_col2im_img)");
+    EG_REQUIRE(eg_convt_img_mfma_ok(dtype, C, Hin, Win, K, 4, 2, 1), "eg_convt_img_mfma: 16-bit types, C <= 3, K = 64 / 128, Hin %% 16 == 0, Win 16 or 32 only (use eg_conv_fwd + eg_col2im_img)");
     ImgTParams p;
     memset(&p, 0, sizeof(p));
     p.a = a; p.wp = wp; p.bias = bias; p.out = out; p.B = B; p.C = C; p.Hin = Hin; p.Win = Win; p.act = act; p.slope = slope;
+    hipStream_t st = (hipStream_t)s;
+    if (K == 64) {                                      // (8 input rows per workgroup)
+        const dim3 grid(B * (Hin / 8));
+        if (dtype == EG_F16) hipLaunchKernelGGL((convt_img_mfma_kernel<f16_t, 8, 64>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((convt_img_mfma_kernel<bf16_t, 8, 64>), grid, dim3(256), 0, st, p);
+        EG_LAUNCH_CHECK();
+        return 0;
+    }
     // input rows per workgroup: 8 (+ 2 halo rows: 25 % of the GEMM done twice, 36 KiB of LDS, several workgroups per CU) or 16
     static const int rows = [] { const char* e = getenv("EG_CONVT_IMG_ROWS"); return e && atoi(e) == 16 ? 16 : 8; }();
     if (rows == 16) {
         const dim3 grid(B * (Hin / 16));
-        if (dtype == EG_F16) hipLaunchKernelGGL((convt_img_mfma_kernel<f16_t, 16>), grid, dim3(256), 0, (hipStream_t)s, p);
-        else hipLaunchKernelGGL((convt_img_mfma_kernel<bf16_t, 16>), grid, dim3(256), 0, (hipStream_t)s, p);
+        if (dtype == EG_F16) hipLaunchKernelGGL((convt_img_mfma_kernel<f16_t, 16>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((convt_img_mfma_kernel<bf16_t, 16>), grid, dim3(256), 0, st, p);
     } else {
         const dim3 grid(B * (Hin / 8));
-        if (dtype == EG_F16) hipLaunchKernelGGL((convt_img_mfma_kernel<f16_t, 8>), grid, dim3(256), 0, (hipStream_t)s, p);
-        else hipLaunchKernelGGL((convt_img_mfma_kernel<bf16_t, 8>), grid, dim3(256), 0, (hipStream_t)s, p);
+        if (dtype == EG_F16) hipLaunchKernelGGL((convt_img_mfma_kernel<f16_t, 8>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((convt_img_mfma_kernel<bf16_t, 8>), grid, dim3(256), 0, st, p);
     }
     EG_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int eg_convt_img_mfma(int dtype, const void* a, const void* wp, const float* bias, float* out, int B, int C, int Hin, int Win, int act,
+                                 float slope, eg_stream_t s) {
+    return eg_convt_img_mfma_k(dtype, a, wp, bias, out, B, C, Hin, Win, 128, act, slope, s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -296,7 +296,10 @@ class _GenEngine:
             else:
                 ops.bn_fwd_eval(dt, self.z[i], self.a[i], B * (8 << i) ** 2, 64, bn.weight, bn.bias, bn.eps, bn.running_mean, bn.running_var, ws.small, ACT_RELU)
             x = self.a[i]
-        if IMG_GEMM:
+        if IMG_GEMM and IMG_DIRECT and self.l4g.Kpad_fwd == 64 and ops.convt_img_mfma_ok(dt, self.CH, 32, 32, 64, 4, 2, 1):
+            # GEMM + col2im gather as ONE launch (the columns stay in LDS; celeba._GenEngine.forward): same bits
+            ops.convt_img_mfma(dt, x, self.l4g.wp_fwd, cb[9].bias, self.img, B, self.CH, 32, 32, ACT_SIGMOID, 0.0, K=64)
+        elif IMG_GEMM:
             ops.conv_fwd(self.l4g.c, dt, x, self.l4g.wp_fwd, self.cols4, None)
             ops.col2im_img(dt, self.cols4, B, self.CH, 32, 32, 4, 2, 1, cb[9].bias, ACT_SIGMOID, 0.0, self.img)
         else:

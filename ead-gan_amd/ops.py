@@ -351,9 +351,9 @@ def convt_img_mfma_ok(dtype, C, Hin, Win, K, k, stride, pad) -> bool:
     return bool(lib().query("eg_convt_img_mfma_ok", dtype, C, Hin, Win, K, k, stride, pad))
 
 
-def convt_img_mfma(dtype, a, wp, bias, out, B, C, Hin, Win, act=ACT_NONE, slope=0.0):
-    """ConvTranspose2d(128 -> C, 4, 2, 1) from NHWC activations to an fp32 NCHW image in one launch (GEMM columns stay in LDS)"""
-    lib().call("eg_convt_img_mfma", dtype, _p(a), _p(wp), _p(bias), _p(out), B, C, Hin, Win, act, slope, _stream())
+def convt_img_mfma(dtype, a, wp, bias, out, B, C, Hin, Win, act=ACT_NONE, slope=0.0, K=128):
+    """ConvTranspose2d(K = 128 / 64 -> C <= 3, 4, 2, 1) (+ bias + activation) from 16-bit NHWC activations to an fp32 NCHW image in one launch"""
+    lib().call("eg_convt_img_mfma_k", dtype, _p(a), _p(wp), _p(bias), _p(out), B, C, Hin, Win, K, act, slope, _stream())
 
 
 def cast_pad(dtype, src, dst, rows, n, npad):

@@ -252,6 +252,10 @@ int eg_wgrad_img(int dtype, const float* img0, const float* img1, const float* i
  * eg_pack_strided.  The Generator's last layer + Tanh (celebA.py:90-91) and the backward-to-image of the first Discriminator layer (:110).
  * Bit-identical to eg_conv_fwd (N = 16 C columns) + eg_col2im_img. */
 int eg_convt_img_mfma_ok(int dtype, int C, int Hin, int Win, int K, int k, int stride, int pad);
+/* ... with K = 64 or 128 input channels (a [B][Hin][Win][K], wp [16 * C][K]): the dSprites generators' last layer ConvTranspose2d(64 -> C, 4, 2, 1) +
+ * Sigmoid (dSprites/rp.py:139-141) */
+int eg_convt_img_mfma_k(int dtype, const void* a, const void* wp, const float* bias, float* out, int B, int C, int Hin, int Win, int K, int act,
+                        float slope, eg_stream_t s);
 int eg_convt_img_mfma(int dtype, const void* a, const void* wp, const float* bias, float* out, int B, int C, int Hin, int Win, int act,
                       float slope, eg_stream_t s);
 int eg_cast_pad(int dtype, const float* src, void* dst, int rows, int n, int npad, eg_stream_t s);

@@ -166,31 +166,33 @@ def test_other_shapes_are_refused():
 
 
 @pytest.mark.parametrize("dtype", [1, 2])
-@pytest.mark.parametrize("B,C,act", [(4, 3, 3), (128, 3, 3), (6, 3, 0), (5, 1, 3)])
-def test_transposed_image_convolution_in_one_launch(B, C, act, dtype):
-    """ConvTranspose2d(128 -> C, 4, 2, 1) (+ bias + Tanh: the Generator's last layer; plain: the backward-to-image of the first Discriminator
-    layer) as ONE launch with the GEMM's columns in LDS == eg_conv_fwd (N = 16 C columns, stored as dtype T) + eg_col2im_img, bit for bit"""
+@pytest.mark.parametrize("K", [128, 64])
+@pytest.mark.parametrize("B,C,act", [(4, 3, 3), (128, 3, 3), (6, 3, 0), (5, 1, 3), (7, 1, 4)])
+def test_transposed_image_convolution_in_one_launch(B, C, act, dtype, K):
+    """ConvTranspose2d(K -> C, 4, 2, 1) (+ bias + Tanh: the CelebA Generator's last layer, K = 128; + Sigmoid (act 4): the dSprites generators',
+    K = 64; plain: the backward-to-image of the first Discriminator layer) as ONE launch with the GEMM's columns in LDS == eg_conv_fwd (N = 16 C
+    columns, stored as dtype T) + eg_col2im_img, bit for bit"""
     Hin = 32
     g = torch.Generator().manual_seed(8)
     tdt = ops.torch_dtype(dtype)
-    a = torch.randn(B, Hin, Hin, 128, generator=g).to(DEV).to(tdt)
-    w = (torch.randn(128, C, 4, 4, generator=g) * 0.05).to(DEV)        # ConvTranspose2d master [in = 128][out = C][4][4]
+    a = torch.randn(B, Hin, Hin, K, generator=g).to(DEV).to(tdt)
+    w = (torch.randn(K, C, 4, 4, generator=g) * 0.05).to(DEV)          # ConvTranspose2d master [in = K][out = C][4][4]
     bias = (torch.randn(C, generator=g) * 0.1).to(DEV) if act else None
     kp = 16 * C
-    c = ops.make_conv(B, Hin, Hin, 128, kp, 1, 1, 0)
+    c = ops.make_conv(B, Hin, Hin, K, kp, 1, 1, 0)
     wp = torch.empty(ops.pack_fwd_elems(c, dtype), device=DEV, dtype=tdt)
-    ops.pack_strided(dtype, w, wp, kp, 128, 128, C, 1, 16, kp)          # wp[t*C + c][ci] = W[ci][c][t]
+    ops.pack_strided(dtype, w, wp, kp, K, K, C, 1, 16, kp)              # wp[t*C + c][ci] = W[ci][c][t]
     cols = torch.empty(B * Hin * Hin, kp, device=DEV, dtype=tdt)
     ops.conv_fwd(c, dtype, a, wp, cols, None)
     want = torch.empty(B, C, 2 * Hin, 2 * Hin, device=DEV)
     ops.col2im_img(dtype, cols, B, C, Hin, Hin, 4, 2, 1, bias, act, 0.0, want)
-    assert ops.convt_img_mfma_ok(dtype, C, Hin, Hin, 128, 4, 2, 1)
+    assert ops.convt_img_mfma_ok(dtype, C, Hin, Hin, K, 4, 2, 1) and not ops.convt_img_mfma_ok(dtype, C, Hin, Hin, 96, 4, 2, 1)
     got = torch.full_like(want, float("nan"))
-    ops.convt_img_mfma(dtype, a, wp, bias, got, B, C, Hin, Hin, act, 0.0)
+    ops.convt_img_mfma(dtype, a, wp, bias, got, B, C, Hin, Hin, act, 0.0, K=K)
     torch.cuda.synchronize()
     assert torch.equal(got, want)
     ref = F.conv_transpose2d(a.float().permute(0, 3, 1, 2), w.to(tdt).float(), bias, 2, 1)
-    ref = torch.tanh(ref) if act else ref
+    ref = torch.tanh(ref) if act == 3 else (torch.sigmoid(ref) if act == 4 else ref)
     torch.testing.assert_close(got, ref, rtol=2e-2, atol=2e-2)
 
 
