@@ -49,7 +49,7 @@ constexpr int img_conv_occ(int N) { return N == 128 ? EG_IMG_CONV_OCC : (N == 64
 template <typename T, bool STAT, int N = 128>
 __global__ __launch_bounds__(256, STAT ? 2 : img_conv_occ(N)) void conv_img_mfma_kernel(const ImgMfmaParams p, int ntiles) {
     static_assert(N == 128 || N == 64 || N == 32, "column tiles of 16, whole 64-byte chunks per pixel row");
-    static_assert(!STAT || N == 128, "the statistics epilogue is laid out for 128 channels");
+    static_assert(!STAT || N == 128 || N == 64, "the statistics epilogue writes 2 N sums from 256 threads");
     constexpr int NJ = N / 16;                            // column tiles of 16 channels
     constexpr int XS = 72, OS = N + 8;                    // LDS row pitches in elements: 66 used columns (x = -1 .. 64); 16-byte aligned pixel rows
     __shared__ __attribute__((aligned(16))) unsigned short s_in[4][6][XS];
@@ -198,9 +198,11 @@ __global__ __launch_bounds__(256, STAT ? 2 : img_conv_occ(N)) void conv_img_mfma
         }
         __syncthreads();                                 // output rows complete; every wave is done reading the image rows
         if constexpr (STAT) {
-            const int which = tid >> 7, n = tid & (N - 1);
-            const float t = ((s_red[(0 * 2 + which) * N + n] + s_red[(1 * 2 + which) * N + n]) + s_red[(2 * 2 + which) * N + n]) + s_red[(3 * 2 + which) * N + n];
-            p.stat_out[((size_t)which * N + n) * ntiles + tile] = t;
+            if (tid < 2 * N) {
+                const int which = tid / N, n = tid - which * N;
+                const float t = ((s_red[(0 * 2 + which) * N + n] + s_red[(1 * 2 + which) * N + n]) + s_red[(2 * 2 + which) * N + n]) + s_red[(3 * 2 + which) * N + n];
+                p.stat_out[((size_t)which * N + n) * ntiles + tile] = t;
+            }
         }
         constexpr int CPR = N / 8, RPI = 64 / CPR;       // 16-byte chunks per pixel row; pixel rows one store instruction covers
 #pragma unroll
@@ -228,7 +230,7 @@ extern "C" int eg_conv_img_mfma_n(int dtype, const float* img0, const float* img
     EG_REQUIRE(!ep || (!ep->mask && ep->out_mode == EG_OUT_NHWC && ep->bias_mod == 0 && (ep->stat_mode == EG_STAT_NONE || ep->stat_mode == EG_STAT_BN_BWD)),
                "eg_conv_img_mfma: unsupported epilogue field");
     const bool stat = ep && ep->stat_mode == EG_STAT_BN_BWD;
-    EG_REQUIRE(!stat || N == 128, "eg_conv_img_mfma: EG_STAT_BN_BWD with 128 output channels only");
+    EG_REQUIRE(!stat || N == 128 || N == 64, "eg_conv_img_mfma: EG_STAT_BN_BWD with 128 or 64 output channels only");
     EG_REQUIRE(!stat || (ep->stat_out && ep->stat_aux && ep->stat_p0 && ep->stat_p1 && ep->stat_p2 && ep->stat_p3), "eg_conv_img_mfma: EG_STAT_BN_BWD needs stat_out, stat_aux (z) and stat_p0..p3");
     ImgMfmaParams p;
     memset(&p, 0, sizeof(p));
@@ -250,7 +252,10 @@ extern "C" int eg_conv_img_mfma_n(int dtype, const float* img0, const float* img
     const dim3 grid(ntiles < wgs_n ? ntiles : wgs_n);     // persistent: a few workgroups per CU walk the tiles with the weight panel in registers
     if (stat) {
         const dim3 gs(ntiles < 512 ? ntiles : 512);      // two workgroups per CU: the sums take the registers
-        if (dtype == EG_F16) hipLaunchKernelGGL((conv_img_mfma_kernel<f16_t, true>), gs, dim3(256), 0, (hipStream_t)s, p, ntiles);
+        if (N == 64) {
+            if (dtype == EG_F16) hipLaunchKernelGGL((conv_img_mfma_kernel<f16_t, true, 64>), gs, dim3(256), 0, (hipStream_t)s, p, ntiles);
+            else hipLaunchKernelGGL((conv_img_mfma_kernel<bf16_t, true, 64>), gs, dim3(256), 0, (hipStream_t)s, p, ntiles);
+        } else if (dtype == EG_F16) hipLaunchKernelGGL((conv_img_mfma_kernel<f16_t, true>), gs, dim3(256), 0, (hipStream_t)s, p, ntiles);
         else hipLaunchKernelGGL((conv_img_mfma_kernel<bf16_t, true>), gs, dim3(256), 0, (hipStream_t)s, p, ntiles);
     } else if (N == 128) {
         if (dtype == EG_F16) hipLaunchKernelGGL((conv_img_mfma_kernel<f16_t, false>), grid, dim3(256), 0, (hipStream_t)s, p, ntiles);

@@ -17,11 +17,16 @@ from . import ops
 from .celeba import FUSE_STATS, IMG_GEMM, _HipModule, _require_cuda, transformation_2D      # noqa: F401
 from .engine import FUSE_DRAWS, Arena, ConvRec, DeviceSampler, ResidentStep, SideStream, SyncScratch, Workspace, bn_train_backward, bn_train_forward, capture_step, check_usable, parse_dtype
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_SIGMOID, EG_F32, OUT_NCHW_F32
-from .trunk import IMG_DIRECT, Head, TrunkEngine
+from .trunk import IMG_DIRECT, WGRAD_IMG, Head, TrunkEngine
 
 opt = argparse.Namespace(n_epochs=100, batch_size=128, lr=0.0001, b1=0.5, b2=0.999, n_cpu=8, latent_dim=200, code_dim=4, n_classes=3,
                          img_size=64, channels=1, sample_interval=1000)           # argparse defaults rp.py:40-51
 TRUNK = (32, 32, 64, 64)
+# EXPERIMENT (default off): the generator's last-layer backward straight from the image gradient -- eg_wgrad_img (N = 64) for the weight
+# gradient, eg_conv_img_mfma (N = 64) with the BatchNorm-backward sums in its epilogue for the input gradient -- instead of patch rows + the
+# two GEMMs over them.  Same results within fp32 summation order (tests), one launch fewer, but SLOWER in the step: dSprites 1.305 -> 1.32 ms,
+# colored 2.50 -> 2.53 (profiles/r03_zzo_ab_l4_direct.txt): the statistics instantiation of the image kernel runs two workgroups per CU
+L4_DIRECT = os.environ.get("EG_L4_DIRECT", "0") != "0"
 # EXPERIMENT (default off): two-chain step with the alignment pass behind the first generator forward (beside the second chain's generator
 # forward) instead of in front of both chains.  Same kernels on the same operands, and the node graph is shorter by ~7 launches -- but the
 # replayed step is far SLOWER, dSprites 1.31 -> 1.73 ms, colored 2.54 -> 3.05 (profiles/r03_zzh_ab_align_late.txt): the second chain then
@@ -218,6 +223,10 @@ class _GenEngine:
         # forward of the last ConvTranspose2d(64 -> C) as ONE GEMM over the 32x32 lattice with N = 16 taps x C columns + the col2im gather
         # (eg_col2im_img): every activation read once instead of 16 times (see celeba._GenEngine.l4g)
         self.l4g = ConvRec(dtype, B, 32, 32, 64, self.k0, 1, 1, 0, device=dev, want_bwd=False, want_wgrad=False, ws=ws)
+        self.l4_direct = (IMG_DIRECT and WGRAD_IMG and L4_DIRECT and self.kp == self.k0 and self.l4p.Kpad_fwd == 64
+                          and ops.conv_img_mfma_ok(dtype, self.CH, 64, 64, 64, 4, 2, 1) and ops.wgrad_img_ok(dtype, self.CH, 64, 64, 64, 4, 2, 1))
+        if self.l4_direct:
+            ws.need_slab(ops.wgrad_img_splits(B, 64) * 64 * self.kp * 4)
         self.cols4 = torch.empty(B * 32 * 32, self.k0, device=dev, dtype=tdt)
         e = lambda *s, dt=tdt: torch.empty(s, device=dev, dtype=dt)
         f = lambda *s: torch.empty(s, device=dev, dtype=torch.float32)
@@ -320,10 +329,17 @@ class _GenEngine:
                 side.defer(nlane[0], fn)
                 nlane[0] += 1
         ops.act_grad_mul_bias_nchw(dimg, self.img, self.dimg_z, B, self.CH, 64 * 64, ACT_SIGMOID, 0.0, ws.small, gof("conv_block.9.bias"))
-        ops.im2col_img(dt, self.dimg_z, self.patches, B, self.CH, 64, 64, 4, 2, 1, self.kp)
+        # the last layer's backward straight from the image gradient (no patch rows in HBM): weight gradient by eg_wgrad_img, input gradient by
+        # eg_conv_img_mfma with the BatchNorm-backward sums of the layer below in its epilogue (celeba._GenEngine.backward)
+        direct = self.l4_direct and sync is None and FUSE_STATS
+        if not direct:
+            ops.im2col_img(dt, self.dimg_z, self.patches, B, self.CH, 64, 64, 4, 2, 1, self.kp)
 
         def l4_wgrad(wsw):
-            ns = ops.conv_wgrad(self.l4p.c, dt, self.patches, self.a[2], wsw.slab, wsw.wgs_target)
+            if direct:
+                ns = ops.wgrad_img(dt, [self.dimg_z], self.a[2], wsw.slab, B, self.CH, 64, 64, 64)
+            else:
+                ns = ops.conv_wgrad(self.l4p.c, dt, self.patches, self.a[2], wsw.slab, wsw.wgs_target)
             ops.wgrad_reduce_perm(wsw.slab, ns, 64, 64, self.kp, 1, gof("conv_block.9.weight"), 0, 0, self.k0)
         wgrad_side(l4_wgrad)
 
@@ -336,8 +352,17 @@ class _GenEngine:
             bnl = cb[(0, 3, 6)[i] + 1]
             return nrb, stat, ops.epilogue(stat_mode=ops.STAT_BN_BWD, stat_out=stat, stat_aux=self.z[i], stat_p=(self.mean[i], self.invstd[i], bnl.weight, bnl.bias),
                                            stat_act=ACT_RELU)
-        fused = bn_bwd_ep(2, self.l4p.c)
-        ops.conv_fwd(self.l4p.c, dt, self.patches, self.l4p.wp_fwd, self.da[2], fused[2])
+        if direct:
+            if "bwd_img" not in self._stat:
+                nrb = ops.conv_img_mfma_stat_blocks(B, 64, 64)
+                self._stat["bwd_img"] = (nrb, torch.empty(2 * 64 * nrb, device=self.inp.device, dtype=torch.float32))
+            nrb, stat = self._stat["bwd_img"]
+            fused = (nrb, stat, ops.epilogue(stat_mode=ops.STAT_BN_BWD, stat_out=stat, stat_aux=self.z[2], stat_p=(self.mean[2], self.invstd[2], cb[7].weight, cb[7].bias),
+                                             stat_act=ACT_RELU))
+            ops.conv_img_mfma(dt, [self.dimg_z], self.l4p.wp_fwd, self.da[2], B, self.CH, 64, 64, fused[2], N=64)
+        else:
+            fused = bn_bwd_ep(2, self.l4p.c)
+            ops.conv_fwd(self.l4p.c, dt, self.patches, self.l4p.wp_fwd, self.da[2], fused[2])
         for i, idx in ((2, 6), (1, 3), (0, 0)):
             r = self.mid[i]
             bn = cb[idx + 1]

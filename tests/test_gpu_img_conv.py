@@ -197,10 +197,11 @@ def test_transposed_image_convolution_in_one_launch(B, C, act, dtype, K):
 
 
 @pytest.mark.parametrize("dtype", [1, 2])
-def test_input_gradient_with_batchnorm_backward_sums(dtype):
+@pytest.mark.parametrize("N", [128, 64])
+def test_input_gradient_with_batchnorm_backward_sums(dtype, N):
     """the same launch also forms dy = da * relu'(bn(z)) and the two sums of the BatchNorm backward of the layer below (EG_STAT_BN_BWD):
-    dy / dz / dgamma / dbeta against the stand-alone kernels on the plain launch's output"""
-    B, C, S, N = 16, 3, 64, 128
+    dy / dz / dgamma / dbeta against the stand-alone kernels on the plain launch's output (N = 64: the dSprites generators)"""
+    B, C, S = 16, 3, 64
     g = torch.Generator().manual_seed(9)
     tdt = ops.torch_dtype(dtype)
     dimg = torch.randn(B, C, S, S, generator=g).to(DEV)
@@ -215,11 +216,11 @@ def test_input_gradient_with_batchnorm_backward_sums(dtype):
     mean, istd = zf.mean(0).contiguous(), (zf.var(0, unbiased=False) + 1e-5).rsqrt().contiguous()
     da = torch.empty(B, S // 2, S // 2, N, device=DEV, dtype=tdt)
     dy = torch.empty_like(da)
-    ops.conv_img_mfma(dtype, [dimg], wp, da, B, C, S, S, None, gates=[img], gate_act=ops.ACT_TANH)
+    ops.conv_img_mfma(dtype, [dimg], wp, da, B, C, S, S, None, gates=[img], gate_act=ops.ACT_TANH, N=N)
     nrb = ops.conv_img_mfma_stat_blocks(B, S, S)
     stat = torch.full((2 * N * nrb,), float("nan"), device=DEV)
     ops.conv_img_mfma(dtype, [dimg], wp, dy, B, C, S, S, ops.epilogue(stat_mode=ops.STAT_BN_BWD, stat_out=stat, stat_aux=z, stat_p=(mean, istd, gamma, beta),
-                                                                    stat_act=ops.ACT_RELU), gates=[img], gate_act=ops.ACT_TANH)
+                                                                    stat_act=ops.ACT_RELU), gates=[img], gate_act=ops.ACT_TANH, N=N)
     torch.cuda.synchronize()
     assert torch.isfinite(stat).all()
     pre = zf * (gamma * istd) + (beta - mean * gamma * istd)
