@@ -117,6 +117,16 @@ def _small_net_dispatch(dt, B, ch):
     assert labels <= {32, 64, 128}, labels
     c64 = ops.make_conv(B, 8, 8, 64, 64, 4, 2, 1)
     assert ops.conv_wgrad_variant(c64, dt) == 2                                 # the 64-channel parity-class weight-gradient kernel
+    for H, ci, co in ((32, 32, 32), (16, 32, 64)):                              # ... and its 32-channel instantiation (round 3)
+        assert ops.conv_wgrad_variant(ops.make_conv(B, H, H, ci, co, 4, 2, 1), dt) == 2
+    # the image-side layers run without patch rows / column tensors in HBM: first trunk layer forward + weight gradient, generator's last layer
+    assert ops.conv_img_mfma_ok(dt, ch, 64, 64, 32, 4, 2, 1) and ops.wgrad_img_ok(dt, ch, 64, 64, 32, 4, 2, 1) and ops.convt_img_mfma_ok(dt, ch, 32, 32, 64, 4, 2, 1)
+
+
+def _small_net_engines_direct(tr):
+    """the trainer's own engines took those paths (not only 'the library could')"""
+    for eng in (tr.de, tr.ee):
+        assert eng.img_direct and eng.wgrad_direct, (eng.img_direct, eng.wgrad_direct)
 
 
 def test_dsprites_b128_bf16():
@@ -127,6 +137,7 @@ def test_dsprites_b128_bf16():
     eg_, ee = arena_rel_err(G, orc.G, tds.PRE_BN_BIAS), arena_rel_err(E, orc.E)
     assert eg_ < 0.25 and ee < 0.1, (eg_, ee)
     _small_net_dispatch(eg.ops.EG_BF16, B, 1)
+    _small_net_engines_direct(tr)
 
 
 def test_colored_b512_fp16():
@@ -137,6 +148,7 @@ def test_colored_b512_fp16():
     eg_, ee = arena_rel_err(G, orc.G, tco.PRE_BN_BIAS), arena_rel_err(E, orc.E)
     assert eg_ < 0.25 and ee < 0.1, (eg_, ee)
     _small_net_dispatch(eg.ops.EG_F16, B, 3)
+    _small_net_engines_direct(tr)
 
 
 def _rel(a, b):
