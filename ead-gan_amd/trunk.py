@@ -26,6 +26,9 @@ IMG_DIRECT = os.environ.get("EG_IMG_DIRECT", "1") != "0"
 # ... and its weight gradient straight from the images too (ops.wgrad_img: patch rows expanded in LDS): no patch rows in HBM at all for the
 # first layer.  EG_WGRAD_IMG=0: patch rows (eg_im2col_img at forward time) + the per-tap GEMM
 WGRAD_IMG = os.environ.get("EG_WGRAD_IMG", "1") != "0"
+# trunks with BatchNorm (the MNIST discriminator / encoder): the forward's convolutions, hidden layers and heads once over all T tapes with one
+# BatchNorm pass per tape in between, instead of T whole passes.  EG_BN_BATCH_TAPES=0: one pass per tape
+BN_BATCH_TAPES = os.environ.get("EG_BN_BATCH_TAPES", "1") != "0"
 
 SN_EPS = 1e-12
 
@@ -208,13 +211,15 @@ class TrunkEngine:
                 ops.conv_fwd(geo, dt, self._inp(i, t0), wp, self._sl(self.a[i], t0), self._ep(i, t0))
             bn = self.bns[i]
             if bn is not None:
-                assert T == 1
-                if training:
-                    ops.bn_fwd_train(dt, self._sl(self.a[i], t0), self._sl(self.y[i], t0), self.rows(i), self.W[i], bn.weight, bn.bias, bn.eps, bn.momentum,
-                                     bn.running_mean, bn.running_var, bn.num_batches_tracked, self.mean[i][t0], self.invstd[i][t0], self.ws.small, ACT_NONE)
-                else:       # module.eval() (score/*.load_encoder of the reference): running statistics, nothing updated
-                    ops.bn_fwd_eval(dt, self._sl(self.a[i], t0), self._sl(self.y[i], t0), self.rows(i), self.W[i], bn.weight, bn.bias, bn.eps,
-                                    bn.running_mean, bn.running_var, self.ws.small, ACT_NONE)
+                # BatchNorm is per forward call: one pass per tape, in tape order (every module's running statistics then see the tapes in the
+                # order of the reference's consecutive calls), while the convolutions around it run once over all T tapes
+                for t in range(t0, t0 + T):
+                    if training:
+                        ops.bn_fwd_train(dt, self._sl(self.a[i], t), self._sl(self.y[i], t), self.rows(i), self.W[i], bn.weight, bn.bias, bn.eps, bn.momentum,
+                                         bn.running_mean, bn.running_var, bn.num_batches_tracked, self.mean[i][t], self.invstd[i][t], self.ws.small, ACT_NONE)
+                    else:   # module.eval() (score/*.load_encoder of the reference): running statistics, nothing updated
+                        ops.bn_fwd_eval(dt, self._sl(self.a[i], t), self._sl(self.y[i], t), self.rows(i), self.W[i], bn.weight, bn.bias, bn.eps,
+                                        bn.running_mean, bn.running_var, self.ws.small, ACT_NONE)
         x = self._inp(self.L, t0)
         for i, f in enumerate(self.fcs):
             ops.conv_fwd(g["fc"][i], dt, x, self.frec[i].wp_fwd, self.fa[i][t0 * B:],
@@ -263,7 +268,7 @@ class TrunkEngine:
                 if patches and not self.wgrad_direct:
                     ops.im2col_img(dt, img, self.patches[(t0 + kk) * npix:(t0 + kk + 1) * npix], B, self.in_ch, self.S, self.S, self.k, 2, 1, self.kp)
                 self.patch_ok[t0 + kk] = bool(patches) and not self.wgrad_direct
-        if self.has_bn:
+        if self.has_bn and not BN_BATCH_TAPES:
             for kk in range(T):
                 self._fwd_pass(t0 + kk, 1, training, self.img_direct)
         else:
