@@ -359,11 +359,11 @@ class TrunkEngine:
         for i in range(L - 1, -1, -1):
             bn = self.bns[i]
             if bn is not None:
-                assert T == 1
                 nm = self.bn_names[i]
-                ops.bn_bwd_post(dt, self._sl(self.a[i], t0), self._sl(self.dyb[i], t0), self._sl(self.dz[i], t0), self.rows(i), self.W[i], bn.weight, bn.bias,
-                                self.mean[i][t0], self.invstd[i][t0], gof(nm + ".weight") if need_wgrad else None, gof(nm + ".bias") if need_wgrad else None,
-                                ws.sums, ws.small, ACT_LRELU, self.slope, self.sigma[i][t0:t0 + 1])
+                for t in range(t0, t0 + T):             # per tape, as the forward's statistics were (the convolutions around it take all tapes at once)
+                    ops.bn_bwd_post(dt, self._sl(self.a[i], t), self._sl(self.dyb[i], t), self._sl(self.dz[i], t), self.rows(i), self.W[i], bn.weight, bn.bias,
+                                    self.mean[i][t], self.invstd[i][t], gof(nm + ".weight") if need_wgrad else None, gof(nm + ".bias") if need_wgrad else None,
+                                    ws.sums, ws.small, ACT_LRELU, self.slope, self.sigma[i][t:t + 1])
             geo = g["l0p"] if i == 0 else g["mid"][i - 1]
             if need_wgrad:
                 assert i > 0 or self.wgrad_direct or all(self.patch_ok[t0:t0 + T]), "forward(..., patches=False) built no patch rows for these tapes"
@@ -406,7 +406,7 @@ class TrunkEngine:
         """douts: {head name: d(loss)/d(head output) [T*B, N] fp32} for every computed head (zeros where a head carries no
         loss).  Accumulates into flat ``grad``; returns d(loss)/d(img) of tape t0 if ``need_dimg``.  ``side`` (engine.SideStream): each
         layer's weight- / bias-gradient chain runs on a side lane; the caller joins the lanes before it reads ``grad``."""
-        if self.has_bn and T > 1:
+        if self.has_bn and T > 1 and not BN_BATCH_TAPES:
             dimg = None
             for kk in range(T):
                 sub = {k: v[kk * self.B:(kk + 1) * self.B] for k, v in douts.items()}
